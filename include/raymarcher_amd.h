@@ -1,0 +1,256 @@
+/*
+ * raymarcher_amd.h — C-ABI of the MI355X-native sphere-tracing renderer.
+ *
+ * This is the drop-in boundary for ONE path of KentaYoshii/Raymarcher: the per-pixel raymarch that
+ * the reference runs as a GLSL fragment shader behind one draw call.  The reference has no FFI for
+ * that path; its de-facto operator interface is the uniform block of resources/raymarch.frag:245-286
+ * plus glDrawArrays in Realtime::rayMarch() (src/realtimerender.cpp:53-87).  Every entry point below
+ * names the reference interface it replaces.  All paths are relative to the reference checkout.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; all structs are PODs with 4-byte members only (no padding surprises);
+ *  - matrices are column-major float[16] exactly as glm / glUniformMatrix4fv(…, GL_FALSE, …) hand them over;
+ *  - output frames are row-major float RGBA, **row 0 = bottom of the image** (GL convention,
+ *    frag:2572-2574); rm_frame_to_rgba8() applies the vertical flip of Realtime::saveViewportImage
+ *    (src/realtime.cpp:337-338);
+ *  - d_* pointers are DEVICE pointers owned by the caller (hipMalloc / torch tensor storage); the
+ *    launcher never allocates or frees in the render call and never synchronises the stream;
+ *  - every function returns an rm_status; no exception crosses this boundary (the reference throws
+ *    std::runtime_error on shader failure, src/utils/shaderloader.h:39,83, and prints + returns on
+ *    scene errors, src/raymarch/raymarchscene.cpp:111).
+ */
+#ifndef RAYMARCHER_AMD_H
+#define RAYMARCHER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_ABI_VERSION 1
+
+/* Capacity limits — src/realtime.h:17-27 (MAX_NUM_LIGHTS 10, MAX_NUM_SHAPES 30). */
+#define RM_MAX_LIGHTS 10
+#define RM_MAX_OBJECTS 30
+
+/* Primitive type tags — src/utils/scenedata.h:18-33 == frag:53-68. */
+enum {
+  RM_CUBE = 0, RM_CONE = 1, RM_CYLINDER = 2, RM_SPHERE = 3, RM_OCTAHEDRON = 4, RM_TORUS = 5,
+  RM_CAPSULE = 6, RM_DEATHSTAR = 7, RM_RECTANGLE = 8, RM_MANDELBROT = 9, RM_MANDELBULB = 10,
+  RM_MENGERSPONGE = 11, RM_SIERPINSKI = 12, RM_CUSTOM = 13
+};
+/* Light type tags — src/utils/scenedata.h:10-15 == frag:72-75. */
+enum { RM_LIGHT_POINT = 0, RM_LIGHT_DIRECTIONAL = 1, RM_LIGHT_SPOT = 2, RM_LIGHT_AREA = 3 };
+
+/* Compile-time #defines of the reference shader (frag:4-15) as a runtime feature mask. */
+enum {
+  RM_FEAT_SKY_BACKGROUND = 1u << 0,      /* frag:5  */
+  RM_FEAT_NIGHTSKY_BACKGROUND = 1u << 1, /* frag:6  (needs noise texture: not implemented, rejected) */
+  RM_FEAT_DARK_BACKGROUND = 1u << 2,     /* frag:8  */
+  RM_FEAT_WHITE_BACKGROUND = 1u << 3,    /* frag:9  */
+  RM_FEAT_CLOUD = 1u << 4,               /* frag:12 */
+  RM_FEAT_TERRAIN = 1u << 5,             /* frag:13 */
+  RM_FEAT_SEA = 1u << 6,                 /* frag:14 (not implemented, rejected) */
+  RM_FEAT_PERLIN_BUMP = 1u << 7          /* frag:15 */
+};
+/* The checked-in shader's state: WHITE_BACKGROUND + PERLIN_BUMP (frag:9,15). */
+#define RM_FEAT_REFERENCE_DEFAULT (RM_FEAT_WHITE_BACKGROUND | RM_FEAT_PERLIN_BUMP)
+
+typedef enum rm_status {
+  RM_OK = 0,
+  RM_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad size, rows out of range */
+  RM_ERR_CAPACITY = 2,         /* > RM_MAX_OBJECTS / RM_MAX_LIGHTS (reference silently drops: realtimerender.cpp:662,737) */
+  RM_ERR_UNSUPPORTED = 3,      /* feature outside the hot-path scope (area light, texture, skybox, SEA, NIGHTSKY, CUSTOM) */
+  RM_ERR_DEVICE = 4,           /* HIP runtime error; see rm_last_error() */
+  RM_ERR_IO = 5,               /* file missing / unreadable */
+  RM_ERR_PARSE = 6             /* scenefile schema violation */
+} rm_status;
+
+/* struct RayMarchObject — frag:135-168; uploaded by configureShapesUniforms, realtimerender.cpp:732-811. */
+typedef struct RmObject {
+  int32_t type;          /* RM_CUBE … RM_CUSTOM */
+  float invModel[16];    /* world → object, column-major (obj.m_ctmInv) */
+  float scaleFactor;     /* min diag of accumulated scale (realtimerender.cpp:749-751) */
+  float shininess;
+  float blend;
+  float ior;
+  float cAmbient[3];
+  float cDiffuse[3];
+  float cSpecular[3];
+  float cReflective[3];
+  float cTransparent[3];
+  int32_t texLoc;        /* -1 = untextured (only value accepted in this ABI version) */
+  float repeatU;
+  float repeatV;
+  int32_t isEmissive;    /* area-light rectangle (must be 0 in this ABI version) */
+  float color[3];
+  int32_t lightIdx;
+} RmObject;
+
+/* struct LightSource — frag:212-230; uploaded by configureLightsUniforms, realtimerender.cpp:651-704. */
+typedef struct RmLight {
+  int32_t type;          /* RM_LIGHT_* */
+  float color[3];
+  float dir[3];          /* ctm·dir, NOT normalised (shader normalises) */
+  float pos[3];
+  float func[3];         /* attenuation (c0, c1, c2) */
+  float angle;           /* spot outer angle, radians */
+  float penumbra;        /* radians */
+  float points[4][3];    /* area light corners (unused: area lights are out of scope) */
+  float intensity;
+  int32_t twoSided;
+} RmLight;
+
+/* Camera uniforms — configureCameraUniforms, realtimerender.cpp:596-615. */
+typedef struct RmCamera {
+  float invProjView[16]; /* inverse(proj·view), column-major */
+  float initialFar;      /* far plane (frag:247, 2425) */
+  float eyePosition[4];  /* declared by the shader, unused by it (frag:245) */
+} RmCamera;
+
+/* Scalar uniforms — frag:248-255, 274, 282-283; realtimerender.cpp:621-645, 651-661, 809-810. */
+typedef struct RmGlobals {
+  float ka, kd, ks, kt;
+  float power;           /* Mandelbulb power (settings.h:47, default 8) */
+  float juliaSeed[2];
+  float iTime;           /* seconds; 0 for offline frames */
+  int32_t isTwoD;        /* 2-D Mandelbrot mode (frag:2431) */
+} RmGlobals;
+
+/* Option uniforms (frag:277-281) + the shader's compile-time constants as runtime knobs. */
+typedef struct RmSettings {
+  int32_t enableSoftShadow;
+  int32_t enableReflection;
+  int32_t enableRefraction;
+  int32_t enableAmbientOcclusion;
+  int32_t enableSkyBox;  /* must be 0 (cubemap out of scope) */
+  int32_t maxSteps;      /* MAX_STEPS, frag:28 (reference 256) */
+  int32_t fractalIters;  /* MAX_STEPS_FRACTALS, frag:29 (reference 20) */
+  int32_t mengerLevels;  /* loop bound of frag:1056 (reference 4) */
+  int32_t numReflection; /* NUM_REFLECTION, frag:45 (reference 1) */
+  uint32_t features;     /* RM_FEAT_* mask (reference: RM_FEAT_REFERENCE_DEFAULT) */
+} RmSettings;
+
+/* Fill *s with the reference's constants (256 steps, 20 fractal iterations, 4 Menger levels, 1 bounce,
+ * WHITE_BACKGROUND|PERLIN_BUMP, all options off). */
+void rm_settings_default(RmSettings *s);
+
+/* ---- library / device ---------------------------------------------------------------------- */
+int rm_abi_version(void);
+const char *rm_status_string(int status);
+/* Thread-local text of the last failure in this thread ("" if none). */
+const char *rm_last_error(void);
+/* Number of HIP devices; <0 on error. */
+int rm_device_count(void);
+/* hipSetDevice for the calling thread. */
+int rm_set_device(int device);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/*
+ * rm_render — replaces Realtime::rayMarch(): the five configure*Uniforms calls + glDrawArrays
+ * (src/realtimerender.cpp:53-87) and everything resources/raymarch.{vert,frag} do per pixel.
+ * Renders rows [rowBegin,rowEnd) of a W×H frame.  d_rgba receives (rowEnd-rowBegin)·W float4
+ * (fragColor, frag:18), d_bright the same for BrightColor (frag:19) or NULL.  Asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream).  Host structs are copied before return.
+ */
+int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
+              int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
+              int rowEnd, float *d_rgba, float *d_bright, void *stream);
+
+/*
+ * rm_render_tiles — the multi-GPU shard of the same frame (no reference counterpart; the reference
+ * renders whole frames on one GPU).  The frame is cut into tiles of `tileRows` rows; this call renders
+ * tiles t with t % numShards == shard, packed contiguously in tile order into d_rgba
+ * (rm_shard_rows() rows × W float4).  Interleaving balances the centre-heavy cost across GPUs.
+ */
+int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
+                    int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int tileRows,
+                    int shard, int numShards, float *d_rgba, float *d_bright, void *stream);
+/* Rows owned by `shard` under the rm_render_tiles partition. */
+int rm_shard_rows(int H, int tileRows, int shard, int numShards);
+/* Frame row of the shard's packed row `localRow` (inverse map used when de-interleaving a gather). */
+int rm_shard_row_to_frame(int H, int tileRows, int shard, int numShards, int localRow);
+/*
+ * rm_deinterleave — scatter the concatenation of all shards' packed rows (shard 0 first, the layout an
+ * RCCL gather produces) into frame order.  d_gathered and d_frame: H·W float4, device, distinct.
+ */
+int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
+                    void *stream);
+
+/* Fractal / shading work counters of the last counted render (debug/roofline accounting). */
+typedef struct RmCounters {
+  uint64_t sceneEvals;   /* sdScene evaluations (frag:1406) */
+  uint64_t bulbIters;    /* Mandelbulb inner iterations (frag:785-799) */
+  uint64_t hitPixels;    /* pixels whose primary ray hit */
+} RmCounters;
+/* Same as rm_render but also accumulates counters with device atomics (slower; synchronises). */
+int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
+                      int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
+                      int rowEnd, float *d_rgba, float *d_bright, RmCounters *out);
+
+/* Average device time in ms of the last `rm_render*` kernel launches timed with hipEvents on their own
+ * stream when profiling is switched on with rm_set_timing(1); resets the accumulator. */
+int rm_set_timing(int on);
+int rm_get_timing(double *avgKernelMs, int *launches);
+
+/*
+ * rm_frame_to_rgba8 — clamp→×255→round and vertical flip, the read-back of
+ * Realtime::saveViewportImage (src/realtime.cpp:284-350).  d_rgba: H·W float4 (row 0 = bottom);
+ * d_out: H·W·4 bytes, row 0 = top.
+ */
+int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *stream);
+
+/* ---- math spec probes (tests only: evaluate the device implementation of one rm_math function
+ *      element-wise so it can be compared bit-for-bit with the oracle) ---------------------------- */
+enum { RM_FN_SIN = 0, RM_FN_COS, RM_FN_ACOS, RM_FN_ATAN2, RM_FN_LOG2, RM_FN_EXP2, RM_FN_POW, RM_FN_SQRT,
+       RM_FN_DIV, RM_FN_PNOISE3, RM_FN_COUNT };
+int rm_probe_math(int fn, const float *d_x, const float *d_y, const float *d_z, float *d_out, int n,
+                  void *stream);
+/* Evaluate sdScene (frag:1406-1430) at n world-space points: d_out[4n] = (minD, minObjIdx, trap.y, trap.z). */
+int rm_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s,
+                     const float *d_pts, float *d_out, int n, void *stream);
+
+/* ---- host side kept from the reference: scenefile loader, camera, Settings -------------------- */
+/* Settings surface — src/settings.h:19-55 (render-relevant fields only). */
+typedef struct RmHostSettings {
+  int32_t screenWidth, screenHeight; /* settings.h:21-22 */
+  float nearPlane, farPlane;         /* settings.h:28-29 (GUI defaults 0.1 / 100, mainwindow.cpp:129-130) */
+  int32_t twoDSpace;
+  int32_t enableSoftShadow, enableReflection, enableRefraction, enableAmbientOcculusion;
+  float power;                       /* settings.h:47 */
+  float juliaSeed[2];                /* settings.h:48 */
+} RmHostSettings;
+void rm_host_settings_default(RmHostSettings *s);
+
+/* Camera — src/camera/camera.cpp:8-34 (initializeCamera), :74-97 (view), :105-133 (proj). */
+typedef struct RmCameraData {
+  float pos[4], look[4], up[4]; /* SceneCameraData, scenedata.h:110-120 */
+  float heightAngle;            /* radians */
+} RmCameraData;
+int rm_camera_build(const RmCameraData *cd, int W, int H, float nearPlane, float farPlane,
+                    float view[16], float proj[16], RmCamera *out);
+
+/* Opaque parsed scene — SceneParser::parse (src/utils/sceneparser.cpp:117-133) +
+ * RayMarchScene::initScene (src/raymarch/raymarchscene.cpp:104-134). */
+typedef struct RmScene RmScene;
+int rm_scene_load(const char *path, RmScene **out);
+int rm_scene_load_string(const char *json, RmScene **out);
+void rm_scene_free(RmScene *scene);
+int rm_scene_num_objects(const RmScene *scene);
+int rm_scene_num_lights(const RmScene *scene);
+/* Pointers stay valid until rm_scene_free. */
+const RmObject *rm_scene_objects(const RmScene *scene);
+const RmLight *rm_scene_lights(const RmScene *scene);
+int rm_scene_globals(const RmScene *scene, const RmHostSettings *hs, RmGlobals *out);
+int rm_scene_camera_data(const RmScene *scene, RmCameraData *out);
+/* Texture file referenced by object i, or NULL (kept for callers; textures are not rendered yet). */
+const char *rm_scene_object_texture(const RmScene *scene, int i);
+
+/* PNG writer for RGBA8 rows (top row first) — stands in for QImage::save (realtime.cpp:346). */
+int rm_write_png(const char *path, const uint8_t *rgba, int W, int H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYMARCHER_AMD_H */

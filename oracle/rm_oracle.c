@@ -1,0 +1,728 @@
+/*
+ * oracle/rm_oracle.c — TEST INFRASTRUCTURE.  CPU restatement of the reference's per-pixel raymarch
+ * (resources/raymarch.vert + resources/raymarch.frag of KentaYoshii/Raymarcher), scalar binary32,
+ * function by function, each citing the shader lines it follows ("frag:N").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.  The product
+ * (raymarcher_amd/csrc) never links or calls it.
+ *
+ * PARITY STATUS: the reference has no tests or golden vectors for this path and its GLSL cannot be
+ * run unmodified in this container, so this restatement is pinned by (i) analytic known-answer
+ * tests, (ii) the SwiftShader cross-check fixtures under tests/golden/ (see oracle/tools/), and
+ * (iii) accuracy tests of rm_math.h against libm — see DESIGN.md §2 for what is and is not pinned.
+ *
+ * Numeric contract: oracle/rm_math.h (scalar built-ins) + the vector forms below.  Build with
+ * -ffp-contract=off: an fma appears only where rm_fma is written.
+ *
+ * Decisions on the shader's undefined behaviour (SURVEY §8a "UB"), all documented in DESIGN.md §4:
+ *   UB1 softshadow miss: r.d = res (the penumbra factor the author evidently meant, frag:1718-1722)
+ *   UB2 raymarch miss:   res.d = rayDepth ("distance travelled along ray direction", frag:190-191)
+ *   UB3 sdScene trap:    the trap of the LAST fractal object evaluated, as written (frag:1419-1428)
+ *   UB4 unknown / CUSTOM type: object is skipped (never nearest)
+ *   UB5 emissive objects / area lights: rejected by the host (out of scope)
+ *   UB9 2-D mode BrightColor: (0,0,0,1)
+ */
+#include "rm_oracle.h"
+#include "rm_math.h"
+
+#include <stdlib.h>
+
+/* ---------------------------------------------------------------- vector forms of the contract */
+typedef struct { float x, y; } v2;
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v4 V4(float x, float y, float z, float w) { v4 r = {x, y, z, w}; return r; }
+static inline v3 v3_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v3_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 v3_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+/* a*s + b, fused per component */
+static inline v3 v3_madd(v3 a, float s, v3 b) {
+  return V3(rm_fma(a.x, s, b.x), rm_fma(a.y, s, b.y), rm_fma(a.z, s, b.z));
+}
+/* GLSL dot: products accumulated left to right, each accumulation fused */
+static inline float dot2(float ax, float ay, float bx, float by) { return rm_fma(ay, by, ax * bx); }
+static inline float dot3(v3 a, v3 b) { return rm_fma(a.z, b.z, rm_fma(a.y, b.y, a.x * b.x)); }
+static inline float len2(float x, float y) { return rm_sqrt(dot2(x, y, x, y)); }
+static inline float len3(v3 a) { return rm_sqrt(dot3(a, a)); }
+/* GLSL normalize(v) = v · (1 / length(v)) */
+static inline v3 normalize3(v3 a) { float inv = 1.0f / len3(a); return v3_scale(a, inv); }
+/* GLSL reflect(I,N) = I − 2·dot(N,I)·N */
+static inline v3 reflect3(v3 I, v3 N) { float k = 2.0f * dot3(N, I); return v3_madd(N, -k, I); }
+/* GLSL refract(I,N,eta) */
+static inline v3 refract3(v3 I, v3 N, float eta) {
+  float d = dot3(N, I);
+  float k = rm_fma(-(eta * eta), rm_fma(-d, d, 1.0f), 1.0f);
+  if (k < 0.0f) return V3(0.0f, 0.0f, 0.0f);
+  float t = rm_fma(eta, d, rm_sqrt(k));
+  return V3(rm_fma(-t, N.x, eta * I.x), rm_fma(-t, N.y, eta * I.y), rm_fma(-t, N.z, eta * I.z));
+}
+static inline v3 mix3(v3 a, v3 b, float t) {
+  return V3(rm_mix(a.x, b.x, t), rm_mix(a.y, b.y, t), rm_mix(a.z, b.z, t));
+}
+/* vec3(M * vec4(p,1)), M column-major: ((M3 + M0·x) + M1·y) + M2·z, fused */
+static inline v3 xform_point(const float *M, v3 p) {
+  v3 r;
+  r.x = rm_fma(M[8], p.z, rm_fma(M[4], p.y, rm_fma(M[0], p.x, M[12])));
+  r.y = rm_fma(M[9], p.z, rm_fma(M[5], p.y, rm_fma(M[1], p.x, M[13])));
+  r.z = rm_fma(M[10], p.z, rm_fma(M[6], p.y, rm_fma(M[2], p.x, M[14])));
+  return r;
+}
+/* M * vec4(x,y,z,w): ((M0·x + M1·y) + M2·z) + M3·w, fused */
+static inline v4 mat4_mul_v4(const float *M, float x, float y, float z, float w) {
+  v4 r;
+  r.x = rm_fma(M[12], w, rm_fma(M[8], z, rm_fma(M[4], y, M[0] * x)));
+  r.y = rm_fma(M[13], w, rm_fma(M[9], z, rm_fma(M[5], y, M[1] * x)));
+  r.z = rm_fma(M[14], w, rm_fma(M[10], z, rm_fma(M[6], y, M[2] * x)));
+  r.w = rm_fma(M[15], w, rm_fma(M[11], z, rm_fma(M[7], y, M[3] * x)));
+  return r;
+}
+
+/* ---------------------------------------------------------------- context */
+#define SURFACE_DIST 0.001f /* frag:32 */
+#define OUTSIDE 1.0f        /* frag:26 */
+#define INSIDE (-1.0f)      /* frag:25 */
+
+typedef struct {
+  const RmCamera *cam;
+  const RmObject *objs;
+  int numObjects;
+  const RmLight *lights;
+  int numLights;
+  RmGlobals g;
+  RmSettings s;
+  uint64_t nEval, nIter, nHit; /* per-thread work counters */
+} Ctx;
+
+typedef struct { int minObjIdx; float minD; v4 trap; } SceneMin;        /* frag:170-182 */
+typedef struct { int intersectObj; float d; v4 trap; } RayMarchRes;     /* frag:184-196 */
+typedef struct { v3 rd, p, n; int intersectObj; } IntersectionInfo;     /* frag:198-210 */
+typedef struct { v4 fragColor; float d; int isEnv; } RenderInfo;        /* frag:232-241 */
+
+/* ---------------------------------------------------------------- SDF primitives (frag:832-1019) */
+/* frag:843-846 */
+static float sdBox(v3 p, v3 b) {
+  v3 q = V3(rm_abs(p.x) - b.x, rm_abs(p.y) - b.y, rm_abs(p.z) - b.z);
+  v3 qm = V3(rm_max(q.x, 0.0f), rm_max(q.y, 0.0f), rm_max(q.z, 0.0f));
+  return len3(qm) + rm_min(rm_max(q.x, rm_max(q.y, q.z)), 0.0f);
+}
+/* frag:832-834 */
+static float sdSphere(v3 p, float r) { return len3(p) - r; }
+/* frag:852-861 */
+static float sdCone(v3 p, float r, float h) {
+  float pox = len2(p.x, p.z) - r, poy = p.y + h;
+  float ex = -r, ey = 2.0f * h;
+  float t = rm_clamp(dot2(pox, poy, ex, ey) / dot2(ex, ey, ex, ey), 0.0f, 1.0f);
+  float qx = rm_fma(-ex, t, pox), qy = rm_fma(-ey, t, poy);
+  float d = len2(qx, qy);
+  if (rm_max(qx, qy) > 0.0f) return d;
+  return -rm_min(d, poy);
+}
+/* frag:867-870 */
+static float sdCylinder(v3 p, float h, float r) {
+  float dx = rm_abs(len2(p.x, p.z)) - r, dy = rm_abs(p.y) - h;
+  return rm_min(rm_max(dx, dy), 0.0f) + len2(rm_max(dx, 0.0f), rm_max(dy, 0.0f));
+}
+/* frag:875-886 */
+static float sdOctahedron(v3 p, float s) {
+  p = V3(rm_abs(p.x), rm_abs(p.y), rm_abs(p.z));
+  float m = ((p.x + p.y) + p.z) - s;
+  v3 r = V3(rm_fma(3.0f, p.x, -m), rm_fma(3.0f, p.y, -m), rm_fma(3.0f, p.z, -m));
+  v3 q;
+  if (r.x < 0.0f) q = p;
+  else if (r.y < 0.0f) q = V3(p.y, p.z, p.x);
+  else if (r.z < 0.0f) q = V3(p.z, p.x, p.y);
+  else return m * 0.57735027f;
+  float k = rm_clamp(0.5f * ((q.z - q.y) + s), 0.0f, s);
+  return len3(V3(q.x, (q.y - s) + k, q.z - k));
+}
+/* frag:891-894 */
+static float sdTorus(v3 p, float tx, float ty) {
+  float qx = len2(p.x, p.z) - tx;
+  return len2(qx, p.y) - ty;
+}
+/* frag:991-994 */
+static float sdCapsule(v3 p, float h, float r) {
+  p.y = p.y - rm_clamp(p.y, 0.0f, h);
+  return len3(p) - r;
+}
+/* frag:1005-1019 */
+static float sdDeathStar(v3 p2, float ra, float rb, float d) {
+  float px = p2.x, py = len2(p2.y, p2.z);
+  float a = (((ra * ra) - (rb * rb)) + (d * d)) / (2.0f * d);
+  float b = rm_sqrt(rm_max((ra * ra) - (a * a), 0.0f));
+  if (rm_fma(px, b, -(py * a)) > d * rm_max(b - py, 0.0f)) {
+    return len2(px - a, py - b);
+  }
+  return rm_max(len2(px, py) - ra, -(len2(px - d, py) - rb));
+}
+
+/* ---------------------------------------------------------------- fractals */
+/* frag:751-769 */
+static float sdMandelBrot(const Ctx *c, float px, float py) {
+  float ltime = rm_fma(-0.5f, rm_cos(c->g.iTime * 0.06f), 0.5f);
+  float zoom = rm_pow(0.9f, 50.0f * ltime);
+  float k = (0.045f * zoom) * rm_fma(-ltime, 0.5f, 1.0f);
+  float cx = -0.745f - k, cy = 0.186f - k;
+  float ld2 = 1.0f;
+  float lz2 = dot2(px, py, px, py);
+  for (int i = 0; i < c->s.maxSteps; i++) {
+    ld2 = ld2 * (4.0f * lz2);
+    float nx = rm_fma(px, px, -(py * py)) + cx;
+    float ny = rm_fma(2.0f * px, py, cy);
+    px = nx; py = ny;
+    lz2 = dot2(px, py, px, py);
+    if (lz2 > 200.0f) break;
+  }
+  float d = rm_sqrt(lz2 / ld2) * rm_log(lz2);
+  return rm_sqrt(rm_clamp((150.0f / zoom) * d, 0.0f, 1.0f));
+}
+
+/* frag:775-803 */
+static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
+  const float power = c->g.power;
+  v3 w = pos;
+  float m = dot3(w, w);
+  v4 trap = V4(rm_abs(w.x), rm_abs(w.y), rm_abs(w.z), m);
+  float dz = 1.0f;
+  v3 cc = pos;
+  /* frag:782-784 */
+  if (len2(c->g.juliaSeed[0], c->g.juliaSeed[1]) != 0.0f) cc = V3(c->g.juliaSeed[0], c->g.juliaSeed[1], 0.0f);
+  const float pexp = (power - 1.0f) / 2.0f;
+  for (int i = 0; i < c->s.fractalIters; i++) {
+    c->nIter++;
+    /* frag:787 */
+    dz = rm_fma(power * rm_pow(m, pexp), dz, 1.0f);
+    /* frag:789-793 */
+    float r = len3(w);
+    float b = power * rm_acos(w.y / r);
+    float a = power * rm_atan2(w.x, w.z);
+    float pr = rm_pow(r, power);
+    float sb = rm_sin(b), cb = rm_cos(b), sa = rm_sin(a), ca = rm_cos(a);
+    w = V3(rm_fma(pr, sb * sa, cc.x), rm_fma(pr, cb, cc.y), rm_fma(pr, sb * ca, cc.z));
+    /* frag:795 — uses the OLD m */
+    trap = V4(rm_min(trap.x, rm_abs(w.x)), rm_min(trap.y, rm_abs(w.y)), rm_min(trap.z, rm_abs(w.z)),
+              rm_min(trap.w, m));
+    /* frag:797-798 */
+    m = dot3(w, w);
+    if (m > 2.0f) break;
+  }
+  *resColor = V4(m, trap.y, trap.z, trap.w);
+  /* frag:802 */
+  return ((0.25f * rm_log(m)) * rm_sqrt(m)) / dz;
+}
+
+/* frag:808-827 */
+static float sdSierpinski(v3 p) {
+  const float Scale = 1.85f, Offset = 2.0f;
+  const float k = Offset * (Scale - 1.0f);
+  for (int n = 0; n < 14; n++) {
+    if (p.x + p.y < 0.0f) { float t = p.x; p.x = -p.y; p.y = -t; }
+    if (p.x + p.z < 0.0f) { float t = p.x; p.x = -p.z; p.z = -t; }
+    if (p.y + p.z < 0.0f) { float t = p.z; p.z = -p.y; p.y = -t; }
+    p = V3(rm_fma(p.x, Scale, -k), rm_fma(p.y, Scale, -k), rm_fma(p.z, Scale, -k));
+  }
+  return len3(p) * rm_pow(Scale, -14.0f);
+}
+
+/* const mat3 ma, frag:124-126 (columns (.6,0,.8),(0,1,0),(-.8,0,.6)) */
+static inline v3 mul_ma(v3 v) {
+  return V3(rm_fma(-0.80f, v.z, rm_fma(0.00f, v.y, 0.60f * v.x)),
+            rm_fma(0.00f, v.z, rm_fma(1.00f, v.y, 0.00f * v.x)),
+            rm_fma(0.60f, v.z, rm_fma(0.00f, v.y, 0.80f * v.x)));
+}
+/* frag:1049-1071 */
+static float sdMengerSponge(const Ctx *c, v3 p, v4 *res) {
+  float d = sdBox(p, V3(1.0f, 1.0f, 1.0f));
+  *res = V4(d, 1.0f, 0.0f, 0.0f);
+  float ani = rm_smoothstep(-0.2f, 0.2f, -rm_cos(0.5f * c->g.iTime));
+  float off = 1.5f * rm_sin(0.01f * c->g.iTime);
+  float s = 1.0f;
+  for (int m = 0; m < c->s.mengerLevels; m++) {
+    /* frag:1057 */
+    p = mix3(p, mul_ma(V3(p.x + off, p.y + off, p.z + off)), ani);
+    /* frag:1058-1060 */
+    v3 a = V3(rm_mod(p.x * s, 2.0f) - 1.0f, rm_mod(p.y * s, 2.0f) - 1.0f, rm_mod(p.z * s, 2.0f) - 1.0f);
+    s = s * 3.0f;
+    v3 r = V3(rm_abs(rm_fma(-3.0f, rm_abs(a.x), 1.0f)), rm_abs(rm_fma(-3.0f, rm_abs(a.y), 1.0f)),
+              rm_abs(rm_fma(-3.0f, rm_abs(a.z), 1.0f)));
+    float da = rm_max(r.x, r.y), db = rm_max(r.y, r.z), dc = rm_max(r.z, r.x);
+    float cc = (rm_min(da, rm_min(db, dc)) - 1.0f) / s;
+    if (cc > d) {
+      d = cc;
+      *res = V4(d, rm_min(res->y, ((0.2f * da) * db) * dc), (1.0f + (float)m) / 4.0f, 0.0f);
+    }
+  }
+  return d;
+}
+
+/* ---------------------------------------------------------------- scene union (frag:1262-1293, 1406-1430) */
+static SceneMin sdScene(Ctx *c, v3 p) {
+  SceneMin res;
+  float minD = 1000000.0f;
+  int minObj = -1;
+  v4 trapCol = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  c->nEval++;
+  for (int i = 0; i < c->numObjects; i++) {
+    const RmObject *obj = &c->objs[i];
+    v3 po = xform_point(obj->invModel, p); /* frag:1417 */
+    float d;
+    switch (obj->type) { /* sdMatch, frag:1262-1293 */
+      case RM_CUBE: d = sdBox(po, V3(0.5f, 0.5f, 0.5f)); break;
+      case RM_CONE: d = sdCone(po, 0.5f, 0.5f); break;
+      case RM_CYLINDER: d = sdCylinder(po, 0.5f, 0.5f); break;
+      case RM_SPHERE: d = sdSphere(po, 0.5f); break;
+      case RM_OCTAHEDRON: d = sdOctahedron(po, 0.5f); break;
+      case RM_TORUS: d = sdTorus(po, 0.5f, 0.125f); break;
+      case RM_CAPSULE: d = sdCapsule(po, 0.5f, 0.1f); break;
+      case RM_DEATHSTAR: d = sdDeathStar(po, 0.5f, 0.35f, 0.5f); break;
+      case RM_RECTANGLE: d = sdBox(po, V3(0.5f, 0.5f, 0.0f)); break;
+      case RM_MANDELBROT: d = sdMandelBrot(c, po.x, po.y); break;
+      case RM_MANDELBULB: d = sdMandelBulb(c, po, &trapCol); break;
+      case RM_MENGERSPONGE: d = sdMengerSponge(c, po, &trapCol); break;
+      case RM_SIERPINSKI: d = sdSierpinski(po); break;
+      default: continue; /* UB4 */
+    }
+    float currD = d * obj->scaleFactor; /* frag:1419 */
+    if (currD < minD) { minD = currD; minObj = i; }
+  }
+  res.minD = minD; res.minObjIdx = minObj; res.trap = trapCol; /* UB3 */
+  return res;
+}
+
+/* frag:1436-1444 */
+static v3 getNormal(Ctx *c, v3 p) {
+  const float ex = (1.0f * 0.5773f) * 0.0005f, ey = (-1.0f * 0.5773f) * 0.0005f;
+  float d1 = sdScene(c, V3(p.x + ex, p.y + ey, p.z + ey)).minD; /* e.xyy */
+  float d2 = sdScene(c, V3(p.x + ey, p.y + ey, p.z + ex)).minD; /* e.yyx */
+  float d3 = sdScene(c, V3(p.x + ey, p.y + ex, p.z + ey)).minD; /* e.yxy */
+  float d4 = sdScene(c, V3(p.x + ex, p.y + ex, p.z + ex)).minD; /* e.xxx */
+  /* ((e.xyy*d1 + e.yyx*d2) + e.yxy*d3) + e.xxx*d4, accumulations fused */
+  v3 n;
+  n.x = rm_fma(ex, d4, rm_fma(ey, d3, rm_fma(ey, d2, ex * d1)));
+  n.y = rm_fma(ex, d4, rm_fma(ex, d3, rm_fma(ey, d2, ey * d1)));
+  n.z = rm_fma(ex, d4, rm_fma(ey, d3, rm_fma(ex, d2, ey * d1)));
+  return normalize3(n);
+}
+
+/* frag:1453-1484 */
+static RayMarchRes raymarch(Ctx *c, v3 ro, v3 rd, float end, float side) {
+  float rayDepth = 0.0f;
+  SceneMin closest;
+  closest.minD = 1000000.0f; closest.minObjIdx = -1; closest.trap = V4(0, 0, 0, 0);
+  for (int i = 0; i < c->s.maxSteps; i++) {
+    v3 p = v3_madd(rd, rayDepth, ro);
+    closest = sdScene(c, p);
+    if (rm_abs(closest.minD) < SURFACE_DIST || rayDepth > end) break;
+    rayDepth = rm_fma(closest.minD, side, rayDepth);
+  }
+  RayMarchRes res;
+  if (rm_abs(closest.minD) < SURFACE_DIST) {
+    res.intersectObj = closest.minObjIdx;
+    res.d = rayDepth - closest.minD; /* frag:1477 */
+    res.trap = closest.trap;
+  } else {
+    res.intersectObj = -1;
+    res.d = rayDepth; /* UB2 */
+    res.trap = V4(0, 0, 0, 0);
+  }
+  return res;
+}
+
+/* ---------------------------------------------------------------- Perlin bump (frag:1587-1691) */
+static inline float permute1(float x) { return rm_mod(rm_fma(x, 34.0f, 1.0f) * x, 289.0f); } /* frag:1602 */
+static inline float taylorInvSqrt1(float r) { return rm_fma(-0.85373472095314f, r, 1.79284291400159f); } /* frag:1606 */
+static inline float fade1(float t) { return ((t * t) * t) * rm_fma(t, rm_fma(t, 6.0f, -15.0f), 10.0f); } /* frag:1587 */
+
+/* frag:1610-1676; lanes k = 0..3 are the vec4 components */
+static float pnoise(v3 p) {
+  v3 Pi0 = V3(rm_floor(p.x), rm_floor(p.y), rm_floor(p.z));
+  v3 Pi1 = V3(Pi0.x + 1.0f, Pi0.y + 1.0f, Pi0.z + 1.0f);
+  Pi0 = V3(rm_mod(Pi0.x, 256.0f), rm_mod(Pi0.y, 256.0f), rm_mod(Pi0.z, 256.0f));
+  Pi1 = V3(rm_mod(Pi1.x, 256.0f), rm_mod(Pi1.y, 256.0f), rm_mod(Pi1.z, 256.0f));
+  v3 Pf0 = V3(rm_fract(p.x), rm_fract(p.y), rm_fract(p.z));
+  v3 Pf1 = V3(Pf0.x - 1.0f, Pf0.y - 1.0f, Pf0.z - 1.0f);
+  float ix[4] = {Pi0.x, Pi1.x, Pi0.x, Pi1.x};
+  float iy[4] = {Pi0.y, Pi0.y, Pi1.y, Pi1.y};
+  float gx0[4], gy0[4], gz0[4], gx1[4], gy1[4], gz1[4];
+  for (int k = 0; k < 4; k++) {
+    float ixy = permute1(permute1(ix[k]) + iy[k]);
+    float ixy0 = permute1(ixy + Pi0.z);
+    float ixy1 = permute1(ixy + Pi1.z);
+    /* frag:1626-1632 */
+    float gx = ixy0 / 7.0f;
+    float gy = rm_fract(rm_floor(gx) / 7.0f) - 0.5f;
+    gx = rm_fract(gx);
+    float gz = (0.5f - rm_abs(gx)) - rm_abs(gy);
+    float sz = rm_step(gz, 0.0f);
+    gx = rm_fma(-sz, rm_step(0.0f, gx) - 0.5f, gx);
+    gy = rm_fma(-sz, rm_step(0.0f, gy) - 0.5f, gy);
+    gx0[k] = gx; gy0[k] = gy; gz0[k] = gz;
+    /* frag:1634-1640 */
+    gx = ixy1 / 7.0f;
+    gy = rm_fract(rm_floor(gx) / 7.0f) - 0.5f;
+    gx = rm_fract(gx);
+    gz = (0.5f - rm_abs(gx)) - rm_abs(gy);
+    sz = rm_step(gz, 0.0f);
+    gx = rm_fma(-sz, rm_step(0.0f, gx) - 0.5f, gx);
+    gy = rm_fma(-sz, rm_step(0.0f, gy) - 0.5f, gy);
+    gx1[k] = gx; gy1[k] = gy; gz1[k] = gz;
+  }
+  /* lane order: x=000/001, y=100/101, z=010/011, w=110/111 (frag:1642-1649) */
+  v3 g000 = V3(gx0[0], gy0[0], gz0[0]), g100 = V3(gx0[1], gy0[1], gz0[1]);
+  v3 g010 = V3(gx0[2], gy0[2], gz0[2]), g110 = V3(gx0[3], gy0[3], gz0[3]);
+  v3 g001 = V3(gx1[0], gy1[0], gz1[0]), g101 = V3(gx1[1], gy1[1], gz1[1]);
+  v3 g011 = V3(gx1[2], gy1[2], gz1[2]), g111 = V3(gx1[3], gy1[3], gz1[3]);
+  /* frag:1651-1660 */
+  g000 = v3_scale(g000, taylorInvSqrt1(dot3(g000, g000)));
+  g010 = v3_scale(g010, taylorInvSqrt1(dot3(g010, g010)));
+  g100 = v3_scale(g100, taylorInvSqrt1(dot3(g100, g100)));
+  g110 = v3_scale(g110, taylorInvSqrt1(dot3(g110, g110)));
+  g001 = v3_scale(g001, taylorInvSqrt1(dot3(g001, g001)));
+  g011 = v3_scale(g011, taylorInvSqrt1(dot3(g011, g011)));
+  g101 = v3_scale(g101, taylorInvSqrt1(dot3(g101, g101)));
+  g111 = v3_scale(g111, taylorInvSqrt1(dot3(g111, g111)));
+  /* frag:1662-1669 */
+  float n000 = dot3(g000, Pf0);
+  float n100 = dot3(g100, V3(Pf1.x, Pf0.y, Pf0.z));
+  float n010 = dot3(g010, V3(Pf0.x, Pf1.y, Pf0.z));
+  float n110 = dot3(g110, V3(Pf1.x, Pf1.y, Pf0.z));
+  float n001 = dot3(g001, V3(Pf0.x, Pf0.y, Pf1.z));
+  float n101 = dot3(g101, V3(Pf1.x, Pf0.y, Pf1.z));
+  float n011 = dot3(g011, V3(Pf0.x, Pf1.y, Pf1.z));
+  float n111 = dot3(g111, Pf1);
+  /* frag:1671-1675 */
+  v3 f = V3(fade1(Pf0.x), fade1(Pf0.y), fade1(Pf0.z));
+  float nzx = rm_mix(n000, n001, f.z), nzy = rm_mix(n100, n101, f.z);
+  float nzz = rm_mix(n010, n011, f.z), nzw = rm_mix(n110, n111, f.z);
+  float nyzx = rm_mix(nzx, nzz, f.y), nyzy = rm_mix(nzy, nzw, f.y);
+  return 2.2f * rm_mix(nyzx, nyzy, f.x);
+}
+
+/* frag:1679-1691 (scale = BUMP_SCALE 10, intensity = BUMP_INTENSITY 2, frag:128-129) */
+static v3 bumpNormal(v3 normal, v3 pos, float scale, float intensity) {
+  v3 ps = v3_scale(pos, scale);
+  float nv = pnoise(ps);
+  v3 grad = V3(pnoise(V3(ps.x + 0.1f, ps.y + 0.0f, ps.z + 0.0f)) - nv,
+               pnoise(V3(ps.x + 0.0f, ps.y + 0.1f, ps.z + 0.0f)) - nv,
+               pnoise(V3(ps.x + 0.0f, ps.y + 0.0f, ps.z + 0.1f)) - nv);
+  return normalize3(v3_madd(grad, intensity, normal));
+}
+
+/* ---------------------------------------------------------------- shading (frag:439-461, 1703-1933) */
+/* frag:1703-1725 */
+static RayMarchRes softshadow(Ctx *c, v3 ro, v3 rd, float mint, float maxt, float k) {
+  float res = 1.0f;
+  float rayDepth = mint;
+  SceneMin closest;
+  closest.minD = 1000000.0f; closest.minObjIdx = -1; closest.trap = V4(0, 0, 0, 0);
+  for (int i = 0; i < c->s.maxSteps; i++) {
+    closest = sdScene(c, v3_madd(rd, rayDepth, ro));
+    if (rm_abs(closest.minD) < SURFACE_DIST || rayDepth > maxt) break;
+    res = rm_min(res, (k * closest.minD) / rayDepth);
+    rayDepth = rayDepth + rm_abs(closest.minD);
+  }
+  RayMarchRes r;
+  r.trap = V4(0, 0, 0, 0);
+  r.d = res; /* frag:1718; UB1 on the miss branch */
+  r.intersectObj = (rm_abs(closest.minD) < SURFACE_DIST) ? closest.minObjIdx : -1;
+  return r;
+}
+
+/* frag:1729-1740 */
+static float calcAO(Ctx *c, v3 pos, v3 nor) {
+  float occ = 0.0f, sca = 1.0f;
+  for (int i = 0; i < 5; i++) {
+    float h = 0.01f + ((0.12f * (float)i) / 4.0f);
+    float d = sdScene(c, v3_madd(nor, h, pos)).minD;
+    occ = rm_fma(h - d, sca, occ);
+    sca = sca * 0.95f;
+    if (occ > 0.35f) break;
+  }
+  return rm_clamp(rm_fma(-3.0f, occ, 1.0f), 0.0f, 1.0f) * rm_fma(0.5f, nor.y, 0.5f);
+}
+
+/* frag:445-447 */
+static float attenuationFactor(float d, const float *func) {
+  return rm_min(1.0f / rm_fma(d * d, func[2], rm_fma(d, func[1], func[0])), 1.0f);
+}
+/* frag:439-442, 450-461 */
+static float angularFalloff(const RmLight *li, v3 L) {
+  v3 nd = normalize3(V3(li->dir[0], li->dir[1], li->dir[2]));
+  float cosalpha = dot3(v3_neg(nd), L);
+  float inner = li->angle - li->penumbra;
+  if (cosalpha <= rm_cos(li->angle)) return 0.0f;
+  if (cosalpha > rm_cos(inner)) return 1.0f;
+  float t = (rm_acos(cosalpha) - inner) / (li->angle - inner);
+  return 1.0f - rm_fma(-2.0f, rm_pow(t, 3.0f), 3.0f * rm_pow(t, 2.0f));
+}
+
+/* frag:1842-1933 (texLoc == -1 path of getDiffuse, frag:1749-1752; getSpecular frag:1787-1792) */
+static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
+  const RmObject *obj = &c->objs[intersectObj];
+  const float ka = c->g.ka, kd = c->g.kd, ks = c->g.ks;
+  float ao = 1.0f;
+  if (c->s.enableAmbientOcclusion) ao = calcAO(c, p, N);
+  v3 total = V3((obj->cAmbient[0] * ka) * ao, (obj->cAmbient[1] * ka) * ao, (obj->cAmbient[2] * ka) * ao);
+  for (int i = 0; i < c->numLights; i++) {
+    const RmLight *li = &c->lights[i];
+    float fAtt = 1.0f, aFall = 1.0f;
+    v3 lpos = V3(li->pos[0], li->pos[1], li->pos[2]);
+    float d = len3(v3_sub(p, lpos));
+    v3 L; float maxT;
+    if (li->type == RM_LIGHT_POINT) {
+      L = normalize3(v3_sub(lpos, p));
+      fAtt = attenuationFactor(d, li->func);
+      maxT = len3(v3_sub(lpos, p));
+    } else if (li->type == RM_LIGHT_DIRECTIONAL) {
+      L = normalize3(V3(-li->dir[0], -li->dir[1], -li->dir[2]));
+      maxT = far;
+    } else { /* SPOT */
+      L = normalize3(v3_sub(lpos, p));
+      fAtt = attenuationFactor(d, li->func);
+      maxT = len3(v3_sub(lpos, p));
+      aFall = angularFalloff(li, L);
+    }
+    v3 V = normalize3(v3_neg(rd));
+    /* frag:1908: origin p + N*SURFACE_DIST*5 */
+    v3 so = V3(rm_fma(N.x * SURFACE_DIST, 5.0f, p.x), rm_fma(N.y * SURFACE_DIST, 5.0f, p.y),
+               rm_fma(N.z * SURFACE_DIST, 5.0f, p.z));
+    RayMarchRes sh = softshadow(c, so, L, 0.0f, maxT, 8.0f);
+    if (sh.intersectObj != -1) continue;
+    float NdotL = dot3(N, L);
+    if (NdotL <= 0.005f) continue;
+    NdotL = rm_clamp(NdotL, 0.0f, 1.0f);
+    v3 lc = V3(li->color[0], li->color[1], li->color[2]);
+    v3 cur = V3(((kd * obj->cDiffuse[0]) * NdotL) * lc.x, ((kd * obj->cDiffuse[1]) * NdotL) * lc.y,
+                ((kd * obj->cDiffuse[2]) * NdotL) * lc.z);
+    v3 R = reflect3(v3_neg(L), N);
+    float RdotV = rm_clamp(dot3(R, V), 0.0f, 1.0f);
+    float sp = (obj->shininess == 0.0f) ? (ks * RdotV) : (ks * rm_pow(RdotV, obj->shininess));
+    cur = V3(rm_fma(sp * obj->cSpecular[0], lc.x, cur.x), rm_fma(sp * obj->cSpecular[1], lc.y, cur.y),
+             rm_fma(sp * obj->cSpecular[2], lc.z, cur.z));
+    cur = v3_scale(cur, fAtt * aFall);
+    if (c->s.enableSoftShadow) cur = v3_scale(cur, sh.d);
+    total = v3_add(total, cur);
+  }
+  return total;
+}
+
+/* ---------------------------------------------------------------- render (frag:2318-2375) */
+static RenderInfo render(Ctx *c, v3 ro, v3 rd, IntersectionInfo *info, float side, float maxT, v3 bgCol) {
+  RenderInfo ri;
+  info->intersectObj = -1;
+  RayMarchRes res = raymarch(c, ro, rd, maxT, side);
+  if (res.intersectObj == -1) {
+    ri.fragColor = V4(bgCol.x, bgCol.y, bgCol.z, 1.0f);
+    ri.isEnv = 1; ri.d = maxT;
+    return ri;
+  }
+  ri.isEnv = 0; ri.d = res.d;
+  v3 p = v3_madd(rd, res.d, ro);
+  v3 pn = getNormal(c, p);
+  if (c->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p, 10.0f, 2.0f);
+  const RmObject *obj = &c->objs[res.intersectObj];
+  v3 col;
+  if (obj->type == RM_MANDELBULB) { /* frag:2354-2361 */
+    col = V3(0.2f, 0.2f, 0.2f);
+    col = mix3(col, V3(0.10f, 0.20f, 0.30f), rm_clamp(res.trap.y, 0.0f, 1.0f));
+    col = mix3(col, V3(0.02f, 0.10f, 0.30f), rm_clamp(res.trap.z * res.trap.z, 0.0f, 1.0f));
+    col = mix3(col, V3(0.30f, 0.10f, 0.02f), rm_clamp(rm_pow(res.trap.w, 6.0f), 0.0f, 1.0f));
+    col = v3_scale(col, 0.5f);
+    v3 ph = getPhong(c, pn, res.intersectObj, p, rd, maxT);
+    col = V3(col.x * (ph.x * 8.0f), col.y * (ph.y * 8.0f), col.z * (ph.z * 8.0f));
+  } else if (obj->type == RM_MENGERSPONGE) { /* frag:2362-2365 */
+    col = V3(rm_fma(0.5f, rm_cos(rm_fma(2.0f, res.trap.z, 0.0f)), 0.5f),
+             rm_fma(0.5f, rm_cos(rm_fma(2.0f, res.trap.z, 1.0f)), 0.5f),
+             rm_fma(0.5f, rm_cos(rm_fma(2.0f, res.trap.z, 2.0f)), 0.5f));
+    col = v3_mul(col, getPhong(c, pn, res.intersectObj, p, rd, maxT));
+  } else {
+    col = getPhong(c, pn, res.intersectObj, p, rd, maxT);
+  }
+  info->p = p; info->n = pn; info->rd = rd; info->intersectObj = res.intersectObj;
+  ri.fragColor = V4(col.x, col.y, col.z, 1.0f);
+  return ri;
+}
+
+/* frag:1938-1946 */
+static v4 brightOf(v3 color) {
+  float brightness = dot3(color, V3(0.2126f, 0.7152f, 0.0722f));
+  if (brightness > 1.0f) return V4(color.x, color.y, color.z, 1.0f);
+  return V4(0.0f, 0.0f, 0.0f, 1.0f);
+}
+
+/* raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for pixel (px,py), py = 0 at the bottom */
+static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, float *outBright) {
+  /* NDC of the pixel centre */
+  float ndcx = rm_fma(((float)px + 0.5f) / (float)W, 2.0f, -1.0f);
+  float ndcy = rm_fma(((float)py + 0.5f) / (float)H, 2.0f, -1.0f);
+  v4 fragColor, bright = V4(0.0f, 0.0f, 0.0f, 1.0f);
+  if (c->g.isTwoD) { /* frag:2431, 2377-2380 */
+    float scol = sdMandelBrot(c, ndcx, ndcy);
+    fragColor = V4(rm_pow(scol, 0.9f), rm_pow(scol, 1.1f), rm_pow(scol, 1.4f), 1.0f);
+    goto done;
+  }
+  {
+    /* vert:23-24 */
+    v4 nearClip = mat4_mul_v4(c->cam->invProjView, ndcx, ndcy, -1.0f, 1.0f);
+    v4 farClip = mat4_mul_v4(c->cam->invProjView, ndcx, ndcy, 1.0f, 1.0f);
+    /* frag:2388-2392 */
+    v3 ro = V3(nearClip.x / nearClip.w, nearClip.y / nearClip.w, nearClip.z / nearClip.w);
+    v3 farC = V3(farClip.x / farClip.w, farClip.y / farClip.w, farClip.z / farClip.w);
+    v3 rd = normalize3(v3_sub(farC, ro));
+    /* frag:2405-2419 (later #ifdefs override earlier ones) */
+    v3 bgCol = V3(0.0f, 0.0f, 0.0f);
+    if (c->s.features & RM_FEAT_WHITE_BACKGROUND) bgCol = V3(1.0f, 1.0f, 1.0f);
+    if (c->s.features & RM_FEAT_DARK_BACKGROUND) bgCol = V3(0.0f, 0.0f, 0.0f);
+    float far = c->cam->initialFar; /* frag:2425 */
+
+    IntersectionInfo info, oi;
+    RenderInfo ri = render(c, ro, rd, &info, OUTSIDE, far, bgCol); /* frag:2443 */
+    if (ri.isEnv) { /* frag:2459-2465 */
+      fragColor = ri.fragColor;
+      goto done;
+    }
+    c->nHit++;
+    v4 phong = ri.fragColor;
+    v4 refl = V4(0, 0, 0, 0), refr = V4(0, 0, 0, 0);
+    oi = info; /* frag:2481 */
+    const RmObject *obj = &c->objs[info.intersectObj];
+    v3 cRefl = V3(obj->cReflective[0], obj->cReflective[1], obj->cReflective[2]);
+    v3 cRefr = V3(obj->cTransparent[0], obj->cTransparent[1], obj->cTransparent[2]);
+    if (c->s.enableReflection && len3(cRefl) != 0.0f) { /* frag:2491-2524 */
+      v3 fil = V3(1.0f, 1.0f, 1.0f);
+      for (int i = 0; i < c->s.numReflection; i++) {
+        v3 r = reflect3(info.rd, info.n);
+        v3 sro = V3(rm_fma(r.x * SURFACE_DIST, 3.0f, info.p.x), rm_fma(r.y * SURFACE_DIST, 3.0f, info.p.y),
+                    rm_fma(r.z * SURFACE_DIST, 3.0f, info.p.z));
+        fil = v3_mul(fil, cRefl);
+        RenderInfo res = render(c, sro, r, &info, OUTSIDE, far, bgCol);
+        refl.x += (c->g.ks * fil.x) * res.fragColor.x;
+        refl.y += (c->g.ks * fil.y) * res.fragColor.y;
+        refl.z += (c->g.ks * fil.z) * res.fragColor.z;
+        refl.w += 1.0f;
+        if (res.isEnv) break;
+      }
+    }
+    if (c->s.enableRefraction && len3(cRefr) != 0.0f) { /* frag:2526-2570 */
+      const RmObject *o2 = &c->objs[oi.intersectObj];
+      float ior = o2->ior;
+      v3 ct = V3(o2->cTransparent[0], o2->cTransparent[1], o2->cTransparent[2]);
+      v3 rdIn = refract3(oi.rd, oi.n, 1.0f / ior);
+      v3 pEnter = V3(rm_fma(-(oi.n.x * SURFACE_DIST), 3.0f, oi.p.x), rm_fma(-(oi.n.y * SURFACE_DIST), 3.0f, oi.p.y),
+                     rm_fma(-(oi.n.z * SURFACE_DIST), 3.0f, oi.p.z));
+      float dIn = raymarch(c, pEnter, rdIn, far, INSIDE).d;
+      v3 pExit = v3_madd(rdIn, dIn, pEnter);
+      v3 nExit = v3_neg(getNormal(c, pExit));
+      v3 rdOut = refract3(rdIn, nExit, ior);
+      if (len3(rdOut) == 0.0f) {
+        refr = V4(0, 0, 0, 0);
+      } else {
+        v3 sro = V3(rm_fma(-(nExit.x * SURFACE_DIST), 5.0f, pExit.x), rm_fma(-(nExit.y * SURFACE_DIST), 5.0f, pExit.y),
+                    rm_fma(-(nExit.z * SURFACE_DIST), 5.0f, pExit.z));
+        RenderInfo res = render(c, sro, rdOut, &info, OUTSIDE, far, bgCol);
+        refr.x += (c->g.kt * ct.x) * res.fragColor.x;
+        refr.y += (c->g.kt * ct.y) * res.fragColor.y;
+        refr.z += (c->g.kt * ct.z) * res.fragColor.z;
+        refr.w += 1.0f;
+      }
+    }
+    /* frag:2572-2574 */
+    fragColor = V4((phong.x + refl.x) + refr.x, (phong.y + refl.y) + refr.y, (phong.z + refl.z) + refr.z,
+                   (phong.w + refl.w) + refr.w);
+    bright = brightOf(V3(fragColor.x, fragColor.y, fragColor.z));
+  }
+done:
+  outColor[0] = fragColor.x; outColor[1] = fragColor.y; outColor[2] = fragColor.z; outColor[3] = fragColor.w;
+  if (outBright) { outBright[0] = bright.x; outBright[1] = bright.y; outBright[2] = bright.z; outBright[3] = bright.w; }
+}
+
+/* ---------------------------------------------------------------- public oracle API */
+static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
+                    int numLights, const RmGlobals *g, const RmSettings *s) {
+  if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights)) return RM_ERR_INVALID_ARGUMENT;
+  if (numObjects < 0 || numLights < 0) return RM_ERR_INVALID_ARGUMENT;
+  if (numObjects > RM_MAX_OBJECTS || numLights > RM_MAX_LIGHTS) return RM_ERR_CAPACITY;
+  if (s->features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA | RM_FEAT_CLOUD | RM_FEAT_TERRAIN | RM_FEAT_SKY_BACKGROUND))
+    return RM_ERR_UNSUPPORTED;
+  if (s->enableSkyBox) return RM_ERR_UNSUPPORTED;
+  for (int i = 0; i < numObjects; i++) {
+    if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM) return RM_ERR_UNSUPPORTED;
+    if (objs[i].texLoc != -1 || objs[i].isEmissive) return RM_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < numLights; i++)
+    if (lights[i].type < 0 || lights[i].type > RM_LIGHT_SPOT) return RM_ERR_UNSUPPORTED;
+  return RM_OK;
+}
+
+int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+               const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *rgba,
+               float *bright, RmCounters *counters, int threads) {
+  int st = validate(cam, objs, numObjects, lights, numLights, g, s);
+  if (st != RM_OK) return st;
+  if (W <= 0 || H <= 0 || rowBegin < 0 || rowEnd > H || rowBegin > rowEnd || !rgba) return RM_ERR_INVALID_ARGUMENT;
+  uint64_t nEval = 0, nIter = 0, nHit = 0;
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : nEval, nIter, nHit)
+  for (int y = rowBegin; y < rowEnd; y++) {
+    Ctx c;
+    c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
+    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0;
+    for (int x = 0; x < W; x++) {
+      size_t o = ((size_t)(y - rowBegin) * W + x) * 4;
+      shadePixel(&c, x, y, W, H, rgba + o, bright ? bright + o : NULL);
+    }
+    nEval += c.nEval; nIter += c.nIter; nHit += c.nHit;
+  }
+  if (counters) { counters->sceneEvals = nEval; counters->bulbIters = nIter; counters->hitPixels = nHit; }
+  return RM_OK;
+}
+
+/* element-wise probes of the numeric contract (same fn ids as rm_probe_math) */
+int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float *out, int n) {
+  for (int i = 0; i < n; i++) {
+    switch (fn) {
+      case RM_FN_SIN: out[i] = rm_sin(x[i]); break;
+      case RM_FN_COS: out[i] = rm_cos(x[i]); break;
+      case RM_FN_ACOS: out[i] = rm_acos(x[i]); break;
+      case RM_FN_ATAN2: out[i] = rm_atan2(x[i], y[i]); break;
+      case RM_FN_LOG2: out[i] = rm_log2(x[i]); break;
+      case RM_FN_EXP2: out[i] = rm_exp2(x[i]); break;
+      case RM_FN_POW: out[i] = rm_pow(x[i], y[i]); break;
+      case RM_FN_SQRT: out[i] = rm_sqrt(x[i]); break;
+      case RM_FN_DIV: out[i] = x[i] / y[i]; break;
+      case RM_FN_PNOISE3: out[i] = pnoise(V3(x[i], y[i], z[i])); break;
+      default: return RM_ERR_INVALID_ARGUMENT;
+    }
+  }
+  return RM_OK;
+}
+
+int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s,
+                      const float *pts, float *out, int n) {
+  Ctx c;
+  c.cam = NULL; c.objs = objs; c.numObjects = numObjects; c.lights = NULL; c.numLights = 0;
+  c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0;
+  for (int i = 0; i < n; i++) {
+    SceneMin m = sdScene(&c, V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    out[4 * i] = m.minD; out[4 * i + 1] = (float)m.minObjIdx; out[4 * i + 2] = m.trap.y; out[4 * i + 3] = m.trap.z;
+  }
+  return RM_OK;
+}
+
+/* bits of the contract's constants, for tests */
+uint32_t rmo_const_bits(int which) {
+  switch (which) {
+    case 0: return rm_f2u(RM_PI);
+    case 1: return rm_f2u(RM_PIO2_HI);
+    case 2: return rm_f2u(RM_PIO2_MID);
+    case 3: return rm_f2u(RM_PIO2_LO);
+    case 4: return rm_f2u(RM_2OPI);
+    case 5: return rm_f2u(RM_LN2);
+    case 6: return rm_f2u(RM_LOG2E);
+    default: return 0;
+  }
+}

@@ -1,0 +1,23 @@
+/*
+ * oracle/rm_oracle.h — TEST INFRASTRUCTURE.  API of the CPU oracle (see rm_oracle.c).
+ * Uses the product's public PODs (include/raymarcher_amd.h) so tests feed both sides the same bytes.
+ * Host buffers only; nothing here touches a GPU.
+ */
+#ifndef RM_ORACLE_H
+#define RM_ORACLE_H
+#include "../include/raymarcher_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Render rows [rowBegin,rowEnd) into host buffers (row 0 = bottom). `threads` OpenMP threads. */
+int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+               const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *rgba,
+               float *bright, RmCounters *counters, int threads);
+int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float *out, int n);
+int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s,
+                      const float *pts, float *out, int n);
+uint32_t rmo_const_bits(int which);
+#ifdef __cplusplus
+}
+#endif
+#endif

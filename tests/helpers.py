@@ -1,0 +1,150 @@
+"""Shared test helpers: oracle loader, an independent numpy camera, scene builders."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from raymarcher_amd import abi  # noqa: E402
+
+_ORACLE = None
+
+
+def oracle():
+    """ctypes handle of oracle/_build/librm_oracle.so (built on demand with make)."""
+    global _ORACLE
+    if _ORACLE is None:
+        so = os.path.join(ROOT, "oracle", "_build", "librm_oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+        lib.rmo_const_bits.restype = C.c_uint32
+        _ORACLE = lib
+    return _ORACLE
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ------------------------------------------------------------------ numpy camera (camera.cpp:74-133)
+def camera_numpy(pos, look, up, height_angle_rad, W, H, near=0.1, far=100.0):
+    f = np.float32
+    pos, look, up = (np.asarray(v, dtype=f)[:3] for v in (pos, look, up))
+    T = np.eye(4, dtype=f)
+    T[:3, 3] = -pos
+    w = -look / np.linalg.norm(look).astype(f)
+    v = up - np.dot(up, w) * w
+    v = v / np.linalg.norm(v).astype(f)
+    u = np.cross(v, w)
+    R = np.eye(4, dtype=f)
+    R[0, :3], R[1, :3], R[2, :3] = u, v, w
+    view = (R @ T).astype(f)
+    aspect = f(W) / f(H)
+    vh = f(2) * f(far) * np.tan(f(height_angle_rad) / f(2)).astype(f)
+    vw = aspect * vh
+    S = np.diag([f(2) / vw, f(2) / vh, f(1) / f(far), f(1)]).astype(f)
+    c = -f(near) / f(far)
+    U = np.eye(4, dtype=f)
+    U[2, 2] = f(1) / (f(1) + c)
+    U[2, 3] = -c / (f(1) + c)
+    U[3, 2] = f(-1)
+    U[3, 3] = f(0)
+    G = np.eye(4, dtype=f)
+    G[2, 2] = f(-2)
+    G[2, 3] = f(-1)
+    proj = (G @ U @ S).astype(f)
+    inv = np.linalg.inv((proj @ view).astype(np.float64)).astype(f)
+    return view, proj, inv
+
+
+def make_camera(pos, look, up, height_angle_deg, W, H, near=0.1, far=100.0):
+    _, _, inv = camera_numpy(pos, look, up, np.deg2rad(height_angle_deg), W, H, near, far)
+    cam = abi.RmCamera()
+    colmajor = inv.T.reshape(-1)  # column-major storage
+    for i in range(16):
+        cam.invProjView[i] = float(colmajor[i])
+    cam.initialFar = far
+    for i in range(3):
+        cam.eyePosition[i] = float(pos[i])
+    cam.eyePosition[3] = 1.0
+    return cam
+
+
+def make_object(type_, model=None, scale_factor=1.0, ambient=(0, 0, 0), diffuse=(1, 1, 1), specular=(0, 0, 0),
+                shininess=0.0, reflective=(0, 0, 0), transparent=(0, 0, 0), ior=0.0):
+    o = abi.RmObject()
+    o.type = type_
+    M = np.eye(4) if model is None else np.asarray(model, dtype=np.float64)
+    inv = np.linalg.inv(M).astype(np.float32).T.reshape(-1)
+    for i in range(16):
+        o.invModel[i] = float(inv[i])
+    o.scaleFactor = scale_factor
+    o.shininess = shininess
+    o.ior = ior
+    for i in range(3):
+        o.cAmbient[i], o.cDiffuse[i], o.cSpecular[i] = ambient[i], diffuse[i], specular[i]
+        o.cReflective[i], o.cTransparent[i] = reflective[i], transparent[i]
+    o.texLoc = -1
+    o.lightIdx = -1
+    return o
+
+
+def make_light(type_, color=(1, 1, 1), direction=(0, 0, 0), pos=(0, 0, 0), func=(1, 0, 0), angle=0.0, penumbra=0.0):
+    li = abi.RmLight()
+    li.type = type_
+    for i in range(3):
+        li.color[i], li.dir[i], li.pos[i], li.func[i] = color[i], direction[i], pos[i], func[i]
+    li.angle, li.penumbra = angle, penumbra
+    return li
+
+
+def make_globals(ka=0.5, kd=0.5, ks=0.5, kt=0.5, power=8.0, julia=(0, 0), itime=0.0, two_d=0):
+    g = abi.RmGlobals(ka, kd, ks, kt, power)
+    g.juliaSeed[0], g.juliaSeed[1] = julia
+    g.iTime = itime
+    g.isTwoD = two_d
+    return g
+
+
+def translate(x, y, z):
+    M = np.eye(4)
+    M[:3, 3] = (x, y, z)
+    return M
+
+
+def scale(x, y, z):
+    return np.diag([x, y, z, 1.0])
+
+
+def scene_mandelbulb(W, H):
+    """scenefiles/simple/unit_mandelbulb.json as constants."""
+    cam = make_camera((0, 0, 4.5), (0, 0, -4.5), (0, 1, 0), 30.0, W, H)
+    objs = (abi.RmObject * 1)(make_object(abi.RM_MANDELBULB, ambient=(.3, .3, .3), diffuse=(1, 1, 1),
+                                          specular=(1, 1, 1), shininess=100.0, ior=1.5))
+    lights = (abi.RmLight * 3)(
+        make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (0, 0, 1)),
+        make_light(abi.RM_LIGHT_DIRECTIONAL, (1.5, 1.1, 0.7), (0, -1, 0)),
+        make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (0, 0, -1)))
+    return cam, objs, 1, lights, 3, make_globals()
+
+
+def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=False, counters=False):
+    cam, objs, no, lights, nl, g = scene
+    row1 = H if row1 is None else row1
+    out = np.zeros((row1 - row0, W, 4), dtype=np.float32)
+    br = np.zeros_like(out) if bright else None
+    cnt = abi.RmCounters()
+    st = oracle().rmo_render(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(settings), W, H, row0, row1,
+                             fptr(out), fptr(br) if bright else None, C.byref(cnt), threads)
+    assert st == 0, f"oracle status {st}"
+    res = [out]
+    if bright:
+        res.append(br)
+    if counters:
+        res.append(cnt)
+    return res[0] if len(res) == 1 else tuple(res)
