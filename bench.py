@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the per-pixel raymarch on the north-star workload.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one 3840×2160 Mandelbulb frame (scenefiles/simple/unit_mandelbulb.json as constants, power 8,
+256 march steps, 12 fractal iterations — BASELINE.json configs[2]) rendered through the C-ABI into a
+float4 HBM framebuffer.  With N > 1 the frame is strong-scaled: rank r renders row tiles t ≡ r (mod N)
+(rm_render_tiles) and rank 0 gathers them with RCCL (dist.gather) and de-interleaves; the gather is
+inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 3840, 2160
+TILE_ROWS = 8
+FRACTAL_ITERS = 12
+# algorithmic work of the reference's formulation (fma = 2 flop, SFU = 1 flop-equivalent)
+FLOP_PER_ITER = 67 + 12     # one Mandelbulb inner iteration (frag:786-798)
+FLOP_PER_EVAL = 38 + 3      # one sdScene evaluation besides its iterations (frag:1406-1430, 802, 1461-1469)
+FLOP_PER_HIT = 1800         # 4×pnoise + Phong per shaded pixel
+PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def cpu_baseline(settings):
+    """Oracle (CPU port of the same frame) on a bounded, unbiased sample: every 8th row of the 4K frame."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as h
+    from raymarcher_amd import scenes
+    t = scenes.mandelbulb(W, H)
+    cores = len(os.sched_getaffinity(0))
+    rows = list(range(4, H, 8))
+    out = np.empty((1, W, 4), dtype=np.float32)
+    lib = h.oracle()
+    t0 = time.perf_counter()
+    # rows are independent; the oracle parallelises inside a row range, so feed it 8-row strides as 1-row calls
+    # grouped per call to keep all threads busy: render the strided rows through one call per row with OpenMP
+    # over pixels would serialise, so instead render [r, r+1) ranges from a thread pool of `cores` callers.
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(r):
+        buf = np.empty((1, W, 4), dtype=np.float32)
+        st = lib.rmo_render(C.byref(t.camera), t.objects, t.num_objects, t.lights, t.num_lights, C.byref(t.globals_),
+                            C.byref(settings), W, H, r, r + 1, h.fptr(buf), None, None, 1)
+        assert st == 0
+        return r
+
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(one, rows))
+    dt = time.perf_counter() - t0
+    del out
+    return {"value": round(len(rows) * W / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"rows 4,12,…,{rows[-1]} ({len(rows)} of {H} rows, {len(rows) * W} px) of the same 3840x2160 frame, "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raymarcher_amd import Renderer, abi, lib, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    r = Renderer(local_rank)
+    tables = scenes.mandelbulb(W, H)
+    settings = abi.default_settings(fractalIters=FRACTAL_ITERS)
+    L = lib()
+    my_rows = L.rm_shard_rows(H, TILE_ROWS, rank, world)
+    slot_rows = L.rm_shard_rows(H, TILE_ROWS, 0, world)  # shard 0 owns the most rows → equal gather slots
+    mine = torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device)
+    gathered = torch.empty((world * slot_rows, W, 4), dtype=torch.float32, device=r.device) if (distributed and rank == 0) else None
+    frame_holder = {}
+
+    def step():
+        if not distributed:
+            frame_holder["f"] = r.render(tables, settings, W, H, out=mine)
+            return
+        r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=mine[:my_rows])
+        if rank == 0:
+            dist.gather(mine, list(gathered.view(world, slot_rows, W, 4).unbind(0)), dst=0)
+            frame_holder["f"] = r.deinterleave(gathered, W, H, TILE_ROWS, world, slot_rows)
+        else:
+            dist.gather(mine, None, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(r.device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(r.device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    L.rm_set_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    import ctypes as C
+    kms, kn = C.c_double(), C.c_int()
+    L.rm_get_timing(C.byref(kms), C.byref(kn))
+    L.rm_set_timing(0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=r.device)
+    kmax = torch.tensor([kms.value], dtype=torch.float64, device=r.device)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    kernel_ms = float(kmax.item())
+
+    # algorithmic work of this rank's launch, from the frame's deterministic counters (outside the timed region)
+    cnt = None
+    if rank == 0:
+        _, cnt = r.render_counted(tables, settings, W, H)
+    if rank == 0:
+        mpix = W * H * args.steps / dt / 1e6
+        flops_frame = cnt.bulbIters * FLOP_PER_ITER + cnt.sceneEvals * FLOP_PER_EVAL + cnt.hitPixels * FLOP_PER_HIT
+        # the dominant kernel of one launch processes 1/world of the frame (interleaved tiles ≈ equal work)
+        flops_launch = flops_frame / world
+        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        bytes_launch = W * H * 16 / world
+        line = {
+            "metric": "Mpixels/s at 3840x2160 Mandelbulb, 256 march steps",
+            "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Mandelbulb power 8, 12 iters, 3840x2160, 256 steps, 3 directional lights, "
+                                   "Perlin bump, white background (unit_mandelbulb.json as constants)",
+                       "rows": "whole frame" if world == 1 else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs + RCCL gather",
+                       "parity": "bit-exact vs CPU oracle (rm_math contract)"},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "kernel": "rm::render_kernel<bulb>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic": {"flop_per_launch": flops_launch, "sceneEvals": cnt.sceneEvals,
+                                         "bulbIters": cnt.bulbIters, "hitPixels": cnt.hitPixels},
+                         "hbm": {"achieved": round(bytes_launch / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes_per_pixel": 16}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(settings)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,9 @@ void rm_settings_default(RmSettings *s);
 
 /* ---- library / device ---------------------------------------------------------------------- */
 int rm_abi_version(void);
+/* sizeof() of ABI struct `which` as compiled into the library (0 RmObject, 1 RmLight, 2 RmCamera, 3 RmGlobals,
+ * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData; -1 otherwise) so bindings can verify layout. */
+int rm_abi_sizeof(int which);
 const char *rm_status_string(int status);
 /* Thread-local text of the last failure in this thread ("" if none). */
 const char *rm_last_error(void);
@@ -173,10 +176,12 @@ int rm_shard_rows(int H, int tileRows, int shard, int numShards);
 int rm_shard_row_to_frame(int H, int tileRows, int shard, int numShards, int localRow);
 /*
  * rm_deinterleave — scatter the concatenation of all shards' packed rows (shard 0 first, the layout an
- * RCCL gather produces) into frame order.  d_gathered and d_frame: H·W float4, device, distinct.
+ * RCCL gather produces) into frame order.  Shard k's rows start at row k·shardStrideRows of d_gathered
+ * (equal-sized gather slots, padded at the end); shardStrideRows = 0 means tightly packed.
+ * d_frame: H·W float4, device, distinct from d_gathered.
  */
 int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
-                    void *stream);
+                    int shardStrideRows, void *stream);
 
 /* Fractal / shading work counters of the last counted render (debug/roofline accounting). */
 typedef struct RmCounters {

@@ -1,0 +1,86 @@
+"""Loader of the C-ABI shared library (raymarcher_amd/lib/libraymarcher_amd.so).
+
+The product path has no CPU fallback: if the library is missing this raises, it never routes
+anywhere else.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C raymarcher_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libraymarcher_amd.so")
+_LIB = None
+
+_P = C.POINTER
+_SCENE_ARGS = [_P(abi.RmCamera), _P(abi.RmObject), C.c_int, _P(abi.RmLight), C.c_int, _P(abi.RmGlobals),
+               _P(abi.RmSettings)]
+
+# name -> (restype, argtypes); every symbol include/raymarcher_amd.h declares.
+SIGNATURES = {
+    "rm_settings_default": (None, [_P(abi.RmSettings)]),
+    "rm_abi_version": (C.c_int, []),
+    "rm_status_string": (C.c_char_p, [C.c_int]),
+    "rm_last_error": (C.c_char_p, []),
+    "rm_device_count": (C.c_int, []),
+    "rm_set_device": (C.c_int, [C.c_int]),
+    "rm_render": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rm_render_tiles": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]),
+    "rm_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rm_shard_row_to_frame": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rm_deinterleave": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rm_render_counted": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                  _P(abi.RmCounters)]),
+    "rm_set_timing": (C.c_int, [C.c_int]),
+    "rm_get_timing": (C.c_int, [_P(C.c_double), _P(C.c_int)]),
+    "rm_frame_to_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rm_probe_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "rm_probe_sdscene": (C.c_int, [_P(abi.RmObject), C.c_int, _P(abi.RmGlobals), _P(abi.RmSettings), C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_void_p]),
+    "rm_host_settings_default": (None, [_P(abi.RmHostSettings)]),
+    "rm_camera_build": (C.c_int, [_P(abi.RmCameraData), C.c_int, C.c_int, C.c_float, C.c_float, _P(C.c_float),
+                                  _P(C.c_float), _P(abi.RmCamera)]),
+    "rm_scene_load": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
+    "rm_scene_load_string": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
+    "rm_scene_free": (None, [C.c_void_p]),
+    "rm_scene_num_objects": (C.c_int, [C.c_void_p]),
+    "rm_scene_num_lights": (C.c_int, [C.c_void_p]),
+    "rm_scene_objects": (_P(abi.RmObject), [C.c_void_p]),
+    "rm_scene_lights": (_P(abi.RmLight), [C.c_void_p]),
+    "rm_scene_globals": (C.c_int, [C.c_void_p, _P(abi.RmHostSettings), _P(abi.RmGlobals)]),
+    "rm_scene_camera_data": (C.c_int, [C.c_void_p, _P(abi.RmCameraData)]),
+    "rm_scene_object_texture": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "rm_write_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+    "rm_abi_sizeof": (C.c_int, [C.c_int]),
+}
+
+
+class RaymarcherError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"{text} (status {status})")
+        self.status = status
+
+
+def lib():
+    """The loaded library with argtypes set; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built and there is no fallback path. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError = header/library drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(status):
+    if status != abi.RM_OK:
+        L = lib()
+        raise RaymarcherError(status, f"{L.rm_status_string(status).decode()}: {L.rm_last_error().decode()}")

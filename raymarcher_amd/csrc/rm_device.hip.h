@@ -1,0 +1,557 @@
+// rm_device.hip.h — per-pixel sphere tracing for gfx950: SDF table, march loops, normals, Perlin bump,
+// Phong + shadow + AO, reflection / refraction compositing.
+//
+// MI355X-native replacement of resources/raymarch.frag (reference line numbers are cited as frag:N).
+// Numeric contract: every value follows DESIGN.md §3 — binary32, fused multiply-add only where fma()
+// is written (-ffp-contract=off), built-ins from rm_math.hip.h — so the frame is bit-reproducible and
+// is checked bit-for-bit against the separately written CPU oracle.
+//
+// Execution shape: one lane per pixel, a wave = an 8×8 pixel tile (coherent rays).  The object loop of
+// the scene union is wave-uniform: object records are read with a uniform index from the constant
+// scene block (scalar loads → SGPR operands, no per-lane table traffic) and the switch on the
+// primitive type is a scalar branch.  Per-lane (divergent) material lookups after a hit read the LDS
+// copy of the table.
+#pragma once
+#include "../../include/raymarcher_amd.h"
+#include "rm_math.hip.h"
+
+namespace rm {
+
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+RM_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RM_DEV V4 v4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
+RM_DEV V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RM_DEV V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RM_DEV V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RM_DEV V3 scale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+RM_DEV V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+RM_DEV V3 madd(V3 a, float s, V3 b) { return v3(fma(a.x, s, b.x), fma(a.y, s, b.y), fma(a.z, s, b.z)); }
+RM_DEV float dot2(float ax, float ay, float bx, float by) { return fma(ay, by, ax * bx); }
+RM_DEV float dot(V3 a, V3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+RM_DEV float len2(float x, float y) { return sqrt_(dot2(x, y, x, y)); }
+RM_DEV float len(V3 a) { return sqrt_(dot(a, a)); }
+RM_DEV V3 normalize(V3 a) { float inv = 1.0f / len(a); return scale(a, inv); }
+RM_DEV V3 reflect(V3 I, V3 N) { float k = 2.0f * dot(N, I); return madd(N, -k, I); }
+RM_DEV V3 refract(V3 I, V3 N, float eta) {
+  float d = dot(N, I);
+  float k = fma(-(eta * eta), fma(-d, d, 1.0f), 1.0f);
+  float t = fma(eta, d, sqrt_(k));
+  V3 r = v3(fma(-t, N.x, eta * I.x), fma(-t, N.y, eta * I.y), fma(-t, N.z, eta * I.z));
+  return (k < 0.0f) ? v3(0.0f, 0.0f, 0.0f) : r;
+}
+RM_DEV V3 mix(V3 a, V3 b, float t) { return v3(mix_(a.x, b.x, t), mix_(a.y, b.y, t), mix_(a.z, b.z, t)); }
+
+constexpr float kSurfaceDist = 0.001f;  // frag:32
+
+// Everything a frame needs, in one constant block (uploaded once per launch by the launcher).
+struct SceneBlock {
+  RmCamera cam;
+  RmGlobals g;
+  RmSettings s;
+  int32_t numObjects;
+  int32_t numLights;
+  RmObject objs[RM_MAX_OBJECTS];
+  RmLight lights[RM_MAX_LIGHTS];
+};
+
+struct SceneMin { int idx; float d; V4 trap; };
+struct MarchRes { int obj; float d; V4 trap; };
+struct Hit { V3 rd, p, n; int obj; };
+struct RenderOut { V3 col; int isEnv; };
+
+// Per-lane work counters (only live in the COUNT instantiation).
+struct Counters { unsigned long long evals, iters; };
+
+// ---- primitives (frag:832-894, 991-1019), unit sizes of sdMatch (frag:1262-1293) -------------------
+RM_DEV float sdBox(V3 p, float bx, float by, float bz) {
+  float qx = fabs_(p.x) - bx, qy = fabs_(p.y) - by, qz = fabs_(p.z) - bz;
+  V3 qm = v3(max_(qx, 0.0f), max_(qy, 0.0f), max_(qz, 0.0f));
+  return len(qm) + min_(max_(qx, max_(qy, qz)), 0.0f);
+}
+RM_DEV float sdCone(V3 p, float r, float h) {
+  float pox = len2(p.x, p.z) - r, poy = p.y + h;
+  float ex = -r, ey = 2.0f * h;
+  float t = clamp_(dot2(pox, poy, ex, ey) / dot2(ex, ey, ex, ey), 0.0f, 1.0f);
+  float qx = fma(-ex, t, pox), qy = fma(-ey, t, poy);
+  float d = len2(qx, qy);
+  return (max_(qx, qy) > 0.0f) ? d : -min_(d, poy);
+}
+RM_DEV float sdCylinder(V3 p, float h, float r) {
+  float dx = len2(p.x, p.z) - r, dy = fabs_(p.y) - h;
+  return min_(max_(dx, dy), 0.0f) + len2(max_(dx, 0.0f), max_(dy, 0.0f));
+}
+RM_DEV float sdOctahedron(V3 p, float s) {
+  p = v3(fabs_(p.x), fabs_(p.y), fabs_(p.z));
+  float m = ((p.x + p.y) + p.z) - s;
+  float rx = fma(3.0f, p.x, -m), ry = fma(3.0f, p.y, -m), rz = fma(3.0f, p.z, -m);
+  bool cx = rx < 0.0f, cy = ry < 0.0f, cz = rz < 0.0f;
+  V3 q = cx ? p : (cy ? v3(p.y, p.z, p.x) : v3(p.z, p.x, p.y));
+  float k = clamp_(0.5f * ((q.z - q.y) + s), 0.0f, s);
+  float dl = len(v3(q.x, (q.y - s) + k, q.z - k));
+  return (cx || cy || cz) ? dl : (m * 0.57735027f);
+}
+RM_DEV float sdTorus(V3 p, float tx, float ty) { return len2(len2(p.x, p.z) - tx, p.y) - ty; }
+RM_DEV float sdCapsule(V3 p, float h, float r) {
+  p.y = p.y - clamp_(p.y, 0.0f, h);
+  return len(p) - r;
+}
+RM_DEV float sdDeathStar(V3 p2, float ra, float rb, float d) {
+  float px = p2.x, py = len2(p2.y, p2.z);
+  float a = (((ra * ra) - (rb * rb)) + (d * d)) / (2.0f * d);
+  float b = sqrt_(max_((ra * ra) - (a * a), 0.0f));
+  float inner = len2(px - a, py - b);
+  float outer = max_(len2(px, py) - ra, -(len2(px - d, py) - rb));
+  return (fma(px, b, -(py * a)) > d * max_(b - py, 0.0f)) ? inner : outer;
+}
+
+// ---- fractals ---------------------------------------------------------------------------------------
+// frag:751-769
+RM_DEV float sdMandelBrot(const SceneBlock *sb, float px, float py) {
+  float ltime = fma(-0.5f, cos_(sb->g.iTime * 0.06f), 0.5f);
+  float zoom = pow_(0.9f, 50.0f * ltime);
+  float k = (0.045f * zoom) * fma(-ltime, 0.5f, 1.0f);
+  float cx = -0.745f - k, cy = 0.186f - k;
+  float ld2 = 1.0f;
+  float lz2 = dot2(px, py, px, py);
+  const int n = sb->s.maxSteps;
+  for (int i = 0; i < n; i++) {
+    ld2 = ld2 * (4.0f * lz2);
+    float nx = fma(px, px, -(py * py)) + cx;
+    float ny = fma(2.0f * px, py, cy);
+    px = nx; py = ny;
+    lz2 = dot2(px, py, px, py);
+    if (lz2 > 200.0f) break;
+  }
+  float d = sqrt_(lz2 / ld2) * log_(lz2);
+  return sqrt_(clamp_((150.0f / zoom) * d, 0.0f, 1.0f));
+}
+
+// frag:775-803.  r = length(w) is sqrt of the same dot product that produced m, so r = sqrt(m) bit for bit.
+template <bool COUNT>
+RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
+  const float power = sb->g.power;
+  const float pexp = (power - 1.0f) / 2.0f;
+  const int iters = sb->s.fractalIters;
+  const bool julia = len2(sb->g.juliaSeed[0], sb->g.juliaSeed[1]) != 0.0f;  // frag:782
+  V3 w = pos;
+  float m = dot(w, w);
+  V4 trap = v4(fabs_(w.x), fabs_(w.y), fabs_(w.z), m);
+  float dz = 1.0f;
+  V3 c = julia ? v3(sb->g.juliaSeed[0], sb->g.juliaSeed[1], 0.0f) : pos;
+  for (int i = 0; i < iters; i++) {
+    if (COUNT) cnt.iters++;
+    dz = fma(power * pow_(m, pexp), dz, 1.0f);  // frag:787
+    float r = sqrt_(m);                         // frag:789
+    float b = power * acos_(w.y / r);           // frag:790
+    float a = power * atan2_(w.x, w.z);         // frag:791
+    float pr = pow_(r, power);
+    float sb_, cb_, sa_, ca_;
+    sincos_(b, sb_, cb_);
+    sincos_(a, sa_, ca_);
+    w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
+    trap = v4(min_(trap.x, fabs_(w.x)), min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
+    m = dot(w, w);
+    if (m > 2.0f) break;  // frag:798 (FRACTALS_BAILOUT)
+  }
+  resColor = v4(m, trap.y, trap.z, trap.w);
+  return ((0.25f * log_(m)) * sqrt_(m)) / dz;  // frag:802
+}
+
+// frag:808-827
+RM_DEV float sdSierpinski(V3 p) {
+  const float Scale = 1.85f, Offset = 2.0f;
+  const float k = Offset * (Scale - 1.0f);
+  for (int n = 0; n < 14; n++) {
+    if (p.x + p.y < 0.0f) { float t = p.x; p.x = -p.y; p.y = -t; }
+    if (p.x + p.z < 0.0f) { float t = p.x; p.x = -p.z; p.z = -t; }
+    if (p.y + p.z < 0.0f) { float t = p.z; p.z = -p.y; p.y = -t; }
+    p = v3(fma(p.x, Scale, -k), fma(p.y, Scale, -k), fma(p.z, Scale, -k));
+  }
+  return len(p) * pow_(Scale, -14.0f);
+}
+
+// frag:1049-1071 (ma = frag:124-126, column-major)
+RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
+  float d = sdBox(p, 1.0f, 1.0f, 1.0f);
+  res = v4(d, 1.0f, 0.0f, 0.0f);
+  const float ani = smoothstep_(-0.2f, 0.2f, -cos_(0.5f * sb->g.iTime));
+  const float off = 1.5f * sin_(0.01f * sb->g.iTime);
+  const int levels = sb->s.mengerLevels;
+  float s = 1.0f;
+  for (int m = 0; m < levels; m++) {
+    V3 v = v3(p.x + off, p.y + off, p.z + off);
+    V3 mv = v3(fma(-0.80f, v.z, fma(0.00f, v.y, 0.60f * v.x)), fma(0.00f, v.z, fma(1.00f, v.y, 0.00f * v.x)),
+               fma(0.60f, v.z, fma(0.00f, v.y, 0.80f * v.x)));
+    p = mix(p, mv, ani);
+    V3 a = v3(mod_(p.x * s, 2.0f) - 1.0f, mod_(p.y * s, 2.0f) - 1.0f, mod_(p.z * s, 2.0f) - 1.0f);
+    s = s * 3.0f;
+    float rx = fabs_(fma(-3.0f, fabs_(a.x), 1.0f)), ry = fabs_(fma(-3.0f, fabs_(a.y), 1.0f)),
+          rz = fabs_(fma(-3.0f, fabs_(a.z), 1.0f));
+    float da = max_(rx, ry), db = max_(ry, rz), dc = max_(rz, rx);
+    float c = (min_(da, min_(db, dc)) - 1.0f) / s;
+    if (c > d) {
+      d = c;
+      res = v4(d, min_(res.y, ((0.2f * da) * db) * dc), (1.0f + (float)m) / 4.0f, 0.0f);
+    }
+  }
+  return d;
+}
+
+// ---- scene union (frag:1406-1430) ---------------------------------------------------------------------
+// BULB=true is the single-Mandelbulb scene class (numObjects == 1, type MANDELBULB): same arithmetic,
+// no table walk.
+template <bool BULB, bool COUNT>
+RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
+  SceneMin res;
+  res.d = 1000000.0f;
+  res.idx = -1;
+  res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (COUNT) cnt.evals++;
+  const int n = BULB ? 1 : sb->numObjects;
+  for (int i = 0; i < n; i++) {
+    const RmObject &o = sb->objs[i];  // uniform index → scalar loads
+    const float *M = o.invModel;
+    V3 po = v3(fma(M[8], p.z, fma(M[4], p.y, fma(M[0], p.x, M[12]))),
+               fma(M[9], p.z, fma(M[5], p.y, fma(M[1], p.x, M[13]))),
+               fma(M[10], p.z, fma(M[6], p.y, fma(M[2], p.x, M[14]))));  // frag:1417
+    float d;
+    const int type = BULB ? (int)RM_MANDELBULB : o.type;
+    switch (type) {  // sdMatch, frag:1262-1293 — wave-uniform branch
+      case RM_CUBE: d = sdBox(po, 0.5f, 0.5f, 0.5f); break;
+      case RM_CONE: d = sdCone(po, 0.5f, 0.5f); break;
+      case RM_CYLINDER: d = sdCylinder(po, 0.5f, 0.5f); break;
+      case RM_SPHERE: d = len(po) - 0.5f; break;
+      case RM_OCTAHEDRON: d = sdOctahedron(po, 0.5f); break;
+      case RM_TORUS: d = sdTorus(po, 0.5f, 0.125f); break;
+      case RM_CAPSULE: d = sdCapsule(po, 0.5f, 0.1f); break;
+      case RM_DEATHSTAR: d = sdDeathStar(po, 0.5f, 0.35f, 0.5f); break;
+      case RM_RECTANGLE: d = sdBox(po, 0.5f, 0.5f, 0.0f); break;
+      case RM_MANDELBROT: d = sdMandelBrot(sb, po.x, po.y); break;
+      case RM_MANDELBULB: d = sdMandelBulb<COUNT>(sb, po, res.trap, cnt); break;
+      case RM_MENGERSPONGE: d = sdMengerSponge(sb, po, res.trap); break;
+      case RM_SIERPINSKI: d = sdSierpinski(po); break;
+      default: continue;
+    }
+    float cur = d * o.scaleFactor;  // frag:1419
+    if (cur < res.d) { res.d = cur; res.idx = i; }
+  }
+  return res;
+}
+
+// frag:1436-1444
+template <bool BULB, bool COUNT>
+RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
+  const float ex = (1.0f * 0.5773f) * 0.0005f, ey = (-1.0f * 0.5773f) * 0.0005f;
+  float d[4];
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    // taps e.xyy, e.yyx, e.yxy, e.xxx
+    float ox = (k == 0 || k == 3) ? ex : ey;
+    float oy = (k >= 2) ? ex : ey;
+    float oz = (k == 1 || k == 3) ? ex : ey;
+    float v = sdScene<BULB, COUNT>(sb, v3(p.x + ox, p.y + oy, p.z + oz), cnt).d;
+    d[0] = (k == 0) ? v : d[0];
+    d[1] = (k == 1) ? v : d[1];
+    d[2] = (k == 2) ? v : d[2];
+    d[3] = (k == 3) ? v : d[3];
+  }
+  V3 n;
+  n.x = fma(ex, d[3], fma(ey, d[2], fma(ey, d[1], ex * d[0])));
+  n.y = fma(ex, d[3], fma(ex, d[2], fma(ey, d[1], ey * d[0])));
+  n.z = fma(ex, d[3], fma(ey, d[2], fma(ex, d[1], ey * d[0])));
+  return normalize(n);
+}
+
+// frag:1453-1484 (side = +1 outside, −1 inside) and frag:1703-1725 (SHADOW) share one loop body.
+// SHADOW=false: returns obj, d = rayDepth − minD on a hit, rayDepth on a miss (contract UB2).
+// SHADOW=true : returns obj, d = penumbra factor res (contract UB1), k = 8, start depth 0.
+template <bool BULB, bool COUNT, bool SHADOW>
+RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
+  float depth = 0.0f;
+  float pen = 1.0f;
+  SceneMin c;
+  c.d = 1000000.0f; c.idx = -1; c.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
+  const int steps = sb->s.maxSteps;
+  for (int i = 0; i < steps; i++) {
+    c = sdScene<BULB, COUNT>(sb, madd(rd, depth, ro), cnt);
+    if (fabs_(c.d) < kSurfaceDist || depth > end) break;
+    if (SHADOW) {
+      pen = min_(pen, (8.0f * c.d) / depth);
+      depth = depth + fabs_(c.d);
+    } else {
+      depth = fma(c.d, side, depth);
+    }
+  }
+  MarchRes r;
+  bool hit = fabs_(c.d) < kSurfaceDist;
+  r.obj = hit ? c.idx : -1;
+  r.trap = c.trap;
+  if (SHADOW) r.d = pen;
+  else r.d = hit ? (depth - c.d) : depth;
+  return r;
+}
+
+// ---- Perlin bump (frag:1587-1691) ---------------------------------------------------------------------
+RM_DEV float permute(float x) { return mod_(fma(x, 34.0f, 1.0f) * x, 289.0f); }
+RM_DEV float taylorInvSqrt(float r) { return fma(-0.85373472095314f, r, 1.79284291400159f); }
+RM_DEV float fade(float t) { return ((t * t) * t) * fma(t, fma(t, 6.0f, -15.0f), 10.0f); }
+
+RM_DEV void pgrad(float ixyz, float &gx, float &gy, float &gz) {  // frag:1626-1632 / 1634-1640
+  float x = ixyz / 7.0f;
+  float y = fract_(floor_(x) / 7.0f) - 0.5f;
+  x = fract_(x);
+  float z = (0.5f - fabs_(x)) - fabs_(y);
+  float sz = step_(z, 0.0f);
+  gx = fma(-sz, step_(0.0f, x) - 0.5f, x);
+  gy = fma(-sz, step_(0.0f, y) - 0.5f, y);
+  gz = z;
+}
+RM_DEV float pcorner(float ixyz, float fx, float fy, float fz) {  // gradient · offset (frag:1642-1669)
+  float gx, gy, gz;
+  pgrad(ixyz, gx, gy, gz);
+  V3 g = v3(gx, gy, gz);
+  g = scale(g, taylorInvSqrt(dot(g, g)));
+  return dot(g, v3(fx, fy, fz));
+}
+RM_DEV float pnoise(V3 p) {  // frag:1610-1676
+  float i0x = floor_(p.x), i0y = floor_(p.y), i0z = floor_(p.z);
+  float i1x = mod_(i0x + 1.0f, 256.0f), i1y = mod_(i0y + 1.0f, 256.0f), i1z = mod_(i0z + 1.0f, 256.0f);
+  i0x = mod_(i0x, 256.0f); i0y = mod_(i0y, 256.0f); i0z = mod_(i0z, 256.0f);
+  float f0x = fract_(p.x), f0y = fract_(p.y), f0z = fract_(p.z);
+  float f1x = f0x - 1.0f, f1y = f0y - 1.0f, f1z = f0z - 1.0f;
+  float px0 = permute(i0x), px1 = permute(i1x);
+  float ixy00 = permute(px0 + i0y), ixy10 = permute(px1 + i0y);  // lanes x, y of frag:1622
+  float ixy01 = permute(px0 + i1y), ixy11 = permute(px1 + i1y);  // lanes z, w
+  float n000 = pcorner(permute(ixy00 + i0z), f0x, f0y, f0z);
+  float n100 = pcorner(permute(ixy10 + i0z), f1x, f0y, f0z);
+  float n010 = pcorner(permute(ixy01 + i0z), f0x, f1y, f0z);
+  float n110 = pcorner(permute(ixy11 + i0z), f1x, f1y, f0z);
+  float n001 = pcorner(permute(ixy00 + i1z), f0x, f0y, f1z);
+  float n101 = pcorner(permute(ixy10 + i1z), f1x, f0y, f1z);
+  float n011 = pcorner(permute(ixy01 + i1z), f0x, f1y, f1z);
+  float n111 = pcorner(permute(ixy11 + i1z), f1x, f1y, f1z);
+  float fx = fade(f0x), fy = fade(f0y), fz = fade(f0z);
+  float nzx = mix_(n000, n001, fz), nzy = mix_(n100, n101, fz), nzz = mix_(n010, n011, fz), nzw = mix_(n110, n111, fz);
+  float nyx = mix_(nzx, nzz, fy), nyy = mix_(nzy, nzw, fy);
+  return 2.2f * mix_(nyx, nyy, fx);
+}
+RM_DEV V3 bumpNormal(V3 normal, V3 pos) {  // frag:1679-1691, BUMP_SCALE 10, BUMP_INTENSITY 2
+  V3 ps = scale(pos, 10.0f);
+  float nv = pnoise(ps);
+  float g[3];
+#pragma unroll 1
+  for (int k = 0; k < 3; k++) {
+    float v = pnoise(v3(ps.x + ((k == 0) ? 0.1f : 0.0f), ps.y + ((k == 1) ? 0.1f : 0.0f),
+                        ps.z + ((k == 2) ? 0.1f : 0.0f))) - nv;
+    g[0] = (k == 0) ? v : g[0];
+    g[1] = (k == 1) ? v : g[1];
+    g[2] = (k == 2) ? v : g[2];
+  }
+  return normalize(madd(v3(g[0], g[1], g[2]), 2.0f, normal));
+}
+
+// ---- shading --------------------------------------------------------------------------------------------
+// frag:1729-1740
+template <bool BULB, bool COUNT>
+RM_DEV float calcAO(const SceneBlock *sb, V3 pos, V3 nor, Counters &cnt) {
+  float occ = 0.0f, sca = 1.0f;
+  for (int i = 0; i < 5; i++) {
+    float h = 0.01f + ((0.12f * (float)i) / 4.0f);
+    float d = sdScene<BULB, COUNT>(sb, madd(nor, h, pos), cnt).d;
+    occ = fma(h - d, sca, occ);
+    sca = sca * 0.95f;
+    if (occ > 0.35f) break;
+  }
+  return clamp_(fma(-3.0f, occ, 1.0f), 0.0f, 1.0f) * fma(0.5f, nor.y, 0.5f);
+}
+// frag:445-447
+RM_DEV float attenuation(float d, float f0, float f1, float f2) {
+  return min_(1.0f / fma(d * d, f2, fma(d, f1, f0)), 1.0f);
+}
+// frag:439-442, 450-461
+RM_DEV float angularFalloff(const RmLight &li, V3 L) {
+  V3 nd = normalize(v3(li.dir[0], li.dir[1], li.dir[2]));
+  float cosalpha = dot(neg(nd), L);
+  float inner = li.angle - li.penumbra;
+  float t = (acos_(cosalpha) - inner) / (li.angle - inner);
+  float mid = 1.0f - fma(-2.0f, pow_(t, 3.0f), 3.0f * pow_(t, 2.0f));
+  float r = (cosalpha > cos_(inner)) ? 1.0f : mid;
+  return (cosalpha <= cos_(li.angle)) ? 0.0f : r;
+}
+
+// Material of the hit object, fetched per lane (the index may differ across the wave).
+struct Material { V3 amb, dif, spec; float shininess; };
+
+// frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
+template <bool BULB, bool COUNT>
+RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
+  const float ka = sb->g.ka, kd = sb->g.kd, ks = sb->g.ks;
+  float ao = 1.0f;
+  if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT>(sb, p, N, cnt);
+  V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);
+  const V3 V = normalize(neg(rd));
+  const V3 so = v3(fma(N.x * kSurfaceDist, 5.0f, p.x), fma(N.y * kSurfaceDist, 5.0f, p.y),
+                   fma(N.z * kSurfaceDist, 5.0f, p.z));  // frag:1908
+  const int nl = sb->numLights;
+  const bool soft = sb->s.enableSoftShadow != 0;
+  for (int i = 0; i < nl; i++) {
+    const RmLight &li = sb->lights[i];  // uniform index → scalar loads
+    float fAtt = 1.0f, aFall = 1.0f, maxT;
+    V3 L;
+    if (li.type == RM_LIGHT_DIRECTIONAL) {
+      L = normalize(v3(-li.dir[0], -li.dir[1], -li.dir[2]));
+      maxT = far;
+    } else {
+      V3 lpos = v3(li.pos[0], li.pos[1], li.pos[2]);
+      float d = len(sub(p, lpos));
+      V3 toL = sub(lpos, p);
+      L = normalize(toL);
+      fAtt = attenuation(d, li.func[0], li.func[1], li.func[2]);
+      maxT = len(toL);
+      if (li.type == RM_LIGHT_SPOT) aFall = angularFalloff(li, L);
+    }
+    MarchRes sh = march<BULB, COUNT, true>(sb, so, L, maxT, 1.0f, cnt);
+    float NdotL = dot(N, L);
+    bool lit = (sh.obj == -1) && !(NdotL <= 0.005f);
+    NdotL = clamp_(NdotL, 0.0f, 1.0f);
+    V3 lc = v3(li.color[0], li.color[1], li.color[2]);
+    V3 cur = v3(((kd * mat.dif.x) * NdotL) * lc.x, ((kd * mat.dif.y) * NdotL) * lc.y, ((kd * mat.dif.z) * NdotL) * lc.z);
+    V3 R = reflect(neg(L), N);
+    float RdotV = clamp_(dot(R, V), 0.0f, 1.0f);
+    float sp = (mat.shininess == 0.0f) ? (ks * RdotV) : (ks * pow_(RdotV, mat.shininess));
+    cur = v3(fma(sp * mat.spec.x, lc.x, cur.x), fma(sp * mat.spec.y, lc.y, cur.y), fma(sp * mat.spec.z, lc.z, cur.z));
+    cur = scale(cur, fAtt * aFall);
+    if (soft) cur = scale(cur, sh.d);
+    if (lit) total = add(total, cur);
+  }
+  return total;
+}
+
+// frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
+template <bool BULB, bool COUNT>
+RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
+                        V3 bg, Counters &cnt) {
+  RenderOut out;
+  info.obj = -1;
+  MarchRes res = march<BULB, COUNT, false>(sb, ro, rd, maxT, side, cnt);
+  if (res.obj == -1) {
+    out.col = bg;
+    out.isEnv = 1;
+    return out;
+  }
+  out.isEnv = 0;
+  V3 p = madd(rd, res.d, ro);
+  V3 pn = getNormal<BULB, COUNT>(sb, p, cnt);
+  if (sb->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p);
+  const RmObject &o = objs[BULB ? 0 : res.obj];
+  Material mat;
+  mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
+  mat.dif = v3(o.cDiffuse[0], o.cDiffuse[1], o.cDiffuse[2]);
+  mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
+  mat.shininess = o.shininess;
+  const int type = BULB ? (int)RM_MANDELBULB : o.type;
+  V3 ph = getPhong<BULB, COUNT>(sb, mat, pn, p, rd, maxT, cnt);
+  V3 col = ph;
+  if (type == RM_MANDELBULB) {  // frag:2354-2361
+    V3 c = v3(0.2f, 0.2f, 0.2f);
+    c = mix(c, v3(0.10f, 0.20f, 0.30f), clamp_(res.trap.y, 0.0f, 1.0f));
+    c = mix(c, v3(0.02f, 0.10f, 0.30f), clamp_(res.trap.z * res.trap.z, 0.0f, 1.0f));
+    c = mix(c, v3(0.30f, 0.10f, 0.02f), clamp_(pow_(res.trap.w, 6.0f), 0.0f, 1.0f));
+    c = scale(c, 0.5f);
+    col = v3(c.x * (ph.x * 8.0f), c.y * (ph.y * 8.0f), c.z * (ph.z * 8.0f));
+  } else if (type == RM_MENGERSPONGE) {  // frag:2362-2365
+    V3 c = v3(fma(0.5f, cos_(fma(2.0f, res.trap.z, 0.0f)), 0.5f), fma(0.5f, cos_(fma(2.0f, res.trap.z, 1.0f)), 0.5f),
+              fma(0.5f, cos_(fma(2.0f, res.trap.z, 2.0f)), 0.5f));
+    col = mul(c, ph);
+  }
+  info.p = p; info.n = pn; info.rd = rd; info.obj = res.obj;
+  out.col = col;
+  return out;
+}
+
+// raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
+template <bool BULB, bool COUNT>
+RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
+                       V4 &bright, Counters &cnt, bool &hitFlag) {
+  float ndcx = fma(((float)px + 0.5f) / (float)W, 2.0f, -1.0f);
+  float ndcy = fma(((float)py + 0.5f) / (float)H, 2.0f, -1.0f);
+  bright = v4(0.0f, 0.0f, 0.0f, 1.0f);
+  hitFlag = false;
+  if (sb->g.isTwoD) {  // frag:2431, 2377-2380
+    float s = sdMandelBrot(sb, ndcx, ndcy);
+    fragColor = v4(pow_(s, 0.9f), pow_(s, 1.1f), pow_(s, 1.4f), 1.0f);
+    return;
+  }
+  const float *M = sb->cam.invProjView;
+  // invProjView · (x, y, ∓1, 1): ((M0·x + M1·y) + M2·z) + M3·w
+  float bx = fma(M[4], ndcy, M[0] * ndcx), by = fma(M[5], ndcy, M[1] * ndcx), bz = fma(M[6], ndcy, M[2] * ndcx),
+        bw = fma(M[7], ndcy, M[3] * ndcx);
+  float nw = fma(M[15], 1.0f, fma(M[11], -1.0f, bw)), fw = fma(M[15], 1.0f, fma(M[11], 1.0f, bw));
+  V3 ro = v3(fma(M[12], 1.0f, fma(M[8], -1.0f, bx)) / nw, fma(M[13], 1.0f, fma(M[9], -1.0f, by)) / nw,
+             fma(M[14], 1.0f, fma(M[10], -1.0f, bz)) / nw);  // frag:2388
+  V3 fc = v3(fma(M[12], 1.0f, fma(M[8], 1.0f, bx)) / fw, fma(M[13], 1.0f, fma(M[9], 1.0f, by)) / fw,
+             fma(M[14], 1.0f, fma(M[10], 1.0f, bz)) / fw);   // frag:2389
+  V3 rd = normalize(sub(fc, ro));                             // frag:2392
+  V3 bg = v3(0.0f, 0.0f, 0.0f);
+  if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
+  if (sb->s.features & RM_FEAT_DARK_BACKGROUND) bg = v3(0.0f, 0.0f, 0.0f);
+  const float far = sb->cam.initialFar;
+
+  Hit info;
+  RenderOut ri = render<BULB, COUNT>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
+  if (ri.isEnv) {  // frag:2459-2465
+    fragColor = v4(ri.col.x, ri.col.y, ri.col.z, 1.0f);
+    return;
+  }
+  hitFlag = true;
+  V4 phong = v4(ri.col.x, ri.col.y, ri.col.z, 1.0f);
+  V4 refl = v4(0.0f, 0.0f, 0.0f, 0.0f), refr = v4(0.0f, 0.0f, 0.0f, 0.0f);
+  const Hit oi = info;  // frag:2481
+  const RmObject &o = objs[BULB ? 0 : info.obj];
+  const V3 cRefl = v3(o.cReflective[0], o.cReflective[1], o.cReflective[2]);
+  const V3 cRefr = v3(o.cTransparent[0], o.cTransparent[1], o.cTransparent[2]);
+  const float ior = o.ior;
+  if (sb->s.enableReflection && len(cRefl) != 0.0f) {  // frag:2491-2524
+    V3 fil = v3(1.0f, 1.0f, 1.0f);
+    const int nb = sb->s.numReflection;
+    for (int i = 0; i < nb; i++) {
+      V3 r = reflect(info.rd, info.n);
+      V3 sro = v3(fma(r.x * kSurfaceDist, 3.0f, info.p.x), fma(r.y * kSurfaceDist, 3.0f, info.p.y),
+                  fma(r.z * kSurfaceDist, 3.0f, info.p.z));
+      fil = mul(fil, cRefl);
+      RenderOut res = render<BULB, COUNT>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
+      refl.x += (sb->g.ks * fil.x) * res.col.x;
+      refl.y += (sb->g.ks * fil.y) * res.col.y;
+      refl.z += (sb->g.ks * fil.z) * res.col.z;
+      refl.w += 1.0f;
+      if (res.isEnv) break;
+    }
+  }
+  if (sb->s.enableRefraction && len(cRefr) != 0.0f) {  // frag:2526-2570
+    V3 rdIn = refract(oi.rd, oi.n, 1.0f / ior);
+    V3 pEnter = v3(fma(-(oi.n.x * kSurfaceDist), 3.0f, oi.p.x), fma(-(oi.n.y * kSurfaceDist), 3.0f, oi.p.y),
+                   fma(-(oi.n.z * kSurfaceDist), 3.0f, oi.p.z));
+    float dIn = march<BULB, COUNT, false>(sb, pEnter, rdIn, far, -1.0f, cnt).d;
+    V3 pExit = madd(rdIn, dIn, pEnter);
+    V3 nExit = neg(getNormal<BULB, COUNT>(sb, pExit, cnt));
+    V3 rdOut = refract(rdIn, nExit, ior);
+    if (len(rdOut) != 0.0f) {
+      V3 sro = v3(fma(-(nExit.x * kSurfaceDist), 5.0f, pExit.x), fma(-(nExit.y * kSurfaceDist), 5.0f, pExit.y),
+                  fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
+      RenderOut res = render<BULB, COUNT>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
+      refr.x += (sb->g.kt * cRefr.x) * res.col.x;
+      refr.y += (sb->g.kt * cRefr.y) * res.col.y;
+      refr.z += (sb->g.kt * cRefr.z) * res.col.z;
+      refr.w += 1.0f;
+    }
+  }
+  fragColor = v4((phong.x + refl.x) + refr.x, (phong.y + refl.y) + refr.y, (phong.z + refl.z) + refr.z,
+                 (phong.w + refl.w) + refr.w);  // frag:2572
+  V3 c = v3(fragColor.x, fragColor.y, fragColor.z);
+  float brightness = dot(c, v3(0.2126f, 0.7152f, 0.0722f));  // frag:1938-1946
+  if (brightness > 1.0f) bright = v4(c.x, c.y, c.z, 1.0f);
+}
+
+}  // namespace rm

@@ -1,0 +1,224 @@
+// rm_host.cpp — host side kept from the reference: status/error plumbing, Settings defaults, camera
+// matrices, row-tile partition helpers and the PNG writer.  No GPU work happens in this file.
+//
+// Reference counterparts: src/settings.h:19-55, src/camera/camera.cpp:8-133,
+// src/realtime.cpp:284-350 (saveViewportImage).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raymarcher_amd.h"
+#include "rm_internal.h"
+
+namespace rm {
+namespace {
+thread_local std::string t_error;
+}
+void set_error(const std::string &msg) { t_error = msg; }
+
+// ---- 4×4 column-major float matrices (element (row r, col c) at m[c*4 + r]) ---------------------------
+struct Mat4 {
+  float m[16];
+  float &at(int r, int c) { return m[c * 4 + r]; }
+  float at(int r, int c) const { return m[c * 4 + r]; }
+};
+Mat4 mat_identity() {
+  Mat4 r{};
+  for (int i = 0; i < 4; i++) r.at(i, i) = 1.0f;
+  return r;
+}
+// column-combination product: each result column is Σ_k A.col(k)·B(k,c), accumulated left to right in
+// binary32 (the evaluation order of the reference's math library, so camera matrices agree to the bit
+// wherever the inputs do).
+Mat4 mat_mul(const Mat4 &A, const Mat4 &B) {
+  Mat4 R{};
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      float acc = A.at(r, 0) * B.at(0, c);
+      acc = acc + A.at(r, 1) * B.at(1, c);
+      acc = acc + A.at(r, 2) * B.at(2, c);
+      acc = acc + A.at(r, 3) * B.at(3, c);
+      R.at(r, c) = acc;
+    }
+  return R;
+}
+// Cofactor (adjugate / determinant) inverse in binary32.
+Mat4 mat_inverse(const Mat4 &M) {
+  auto m = [&](int c, int r) { return M.m[c * 4 + r]; };  // m(col,row)
+  // 2×2 sub-determinants of rows/cols of the lower-right 3×3 blocks
+  float c00 = m(2, 2) * m(3, 3) - m(3, 2) * m(2, 3), c02 = m(1, 2) * m(3, 3) - m(3, 2) * m(1, 3),
+        c03 = m(1, 2) * m(2, 3) - m(2, 2) * m(1, 3);
+  float c04 = m(2, 1) * m(3, 3) - m(3, 1) * m(2, 3), c06 = m(1, 1) * m(3, 3) - m(3, 1) * m(1, 3),
+        c07 = m(1, 1) * m(2, 3) - m(2, 1) * m(1, 3);
+  float c08 = m(2, 1) * m(3, 2) - m(3, 1) * m(2, 2), c10 = m(1, 1) * m(3, 2) - m(3, 1) * m(1, 2),
+        c11 = m(1, 1) * m(2, 2) - m(2, 1) * m(1, 2);
+  float c12 = m(2, 0) * m(3, 3) - m(3, 0) * m(2, 3), c14 = m(1, 0) * m(3, 3) - m(3, 0) * m(1, 3),
+        c15 = m(1, 0) * m(2, 3) - m(2, 0) * m(1, 3);
+  float c16 = m(2, 0) * m(3, 2) - m(3, 0) * m(2, 2), c18 = m(1, 0) * m(3, 2) - m(3, 0) * m(1, 2),
+        c19 = m(1, 0) * m(2, 2) - m(2, 0) * m(1, 2);
+  float c20 = m(2, 0) * m(3, 1) - m(3, 0) * m(2, 1), c22 = m(1, 0) * m(3, 1) - m(3, 0) * m(1, 1),
+        c23 = m(1, 0) * m(2, 1) - m(2, 0) * m(1, 1);
+  const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+  const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+  const float v0[4] = {m(1, 0), m(0, 0), m(0, 0), m(0, 0)}, v1[4] = {m(1, 1), m(0, 1), m(0, 1), m(0, 1)};
+  const float v2[4] = {m(1, 2), m(0, 2), m(0, 2), m(0, 2)}, v3[4] = {m(1, 3), m(0, 3), m(0, 3), m(0, 3)};
+  Mat4 inv{};
+  for (int i = 0; i < 4; i++) {
+    const float sa = (i & 1) ? -1.0f : 1.0f, sb = -sa;
+    inv.m[0 * 4 + i] = ((v1[i] * f0[i] - v2[i] * f1[i]) + v3[i] * f2[i]) * sa;
+    inv.m[1 * 4 + i] = ((v0[i] * f0[i] - v2[i] * f3[i]) + v3[i] * f4[i]) * sb;
+    inv.m[2 * 4 + i] = ((v0[i] * f1[i] - v1[i] * f3[i]) + v3[i] * f5[i]) * sa;
+    inv.m[3 * 4 + i] = ((v0[i] * f2[i] - v1[i] * f4[i]) + v2[i] * f5[i]) * sb;
+  }
+  const float d0 = m(0, 0) * inv.m[0], d1 = m(0, 1) * inv.m[4], d2 = m(0, 2) * inv.m[8], d3 = m(0, 3) * inv.m[12];
+  const float ood = 1.0f / ((d0 + d1) + (d2 + d3));
+  for (float &x : inv.m) x = x * ood;
+  return inv;
+}
+
+}  // namespace rm
+
+using namespace rm;
+
+extern "C" {
+
+int rm_abi_version(void) { return RM_ABI_VERSION; }
+
+const char *rm_status_string(int status) {
+  switch (status) {
+    case RM_OK: return "RM_OK";
+    case RM_ERR_INVALID_ARGUMENT: return "RM_ERR_INVALID_ARGUMENT";
+    case RM_ERR_CAPACITY: return "RM_ERR_CAPACITY";
+    case RM_ERR_UNSUPPORTED: return "RM_ERR_UNSUPPORTED";
+    case RM_ERR_DEVICE: return "RM_ERR_DEVICE";
+    case RM_ERR_IO: return "RM_ERR_IO";
+    case RM_ERR_PARSE: return "RM_ERR_PARSE";
+    default: return "RM_ERR_UNKNOWN";
+  }
+}
+const char *rm_last_error(void) { return t_error.c_str(); }
+
+void rm_settings_default(RmSettings *s) {
+  if (!s) return;
+  std::memset(s, 0, sizeof(*s));
+  s->maxSteps = 256;     // frag:28
+  s->fractalIters = 20;  // frag:29
+  s->mengerLevels = 4;   // frag:1056
+  s->numReflection = 1;  // frag:45
+  s->features = RM_FEAT_REFERENCE_DEFAULT;
+}
+
+void rm_host_settings_default(RmHostSettings *s) {
+  if (!s) return;
+  std::memset(s, 0, sizeof(*s));
+  s->screenWidth = 1024;  // settings.h:21-22
+  s->screenHeight = 768;
+  s->nearPlane = 0.1f;    // GUI defaults, mainwindow.cpp:129-130
+  s->farPlane = 100.0f;
+  s->power = 8.0f;        // settings.h:47
+}
+
+// camera.cpp:8-34 (initializeCamera) → :74-97 (view = R·T) and :105-133 (proj = remap·unhinge·scale),
+// then invProjView = inverse(proj·view) as configureCameraUniforms does (realtimerender.cpp:596-615).
+int rm_camera_build(const RmCameraData *cd, int W, int H, float nearPlane, float farPlane, float view[16],
+                    float proj[16], RmCamera *out) {
+  if (!cd || W <= 0 || H <= 0 || !(farPlane > 0.0f)) { set_error("bad camera arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  const float lx = cd->look[0], ly = cd->look[1], lz = cd->look[2];
+  const float ux = cd->up[0], uy = cd->up[1], uz = cd->up[2];
+  // w = −normalize(look); v = normalize(up − dot(up,w)·w); u = v × w
+  const float ll = std::sqrt(lx * lx + ly * ly + lz * lz);
+  if (!(ll > 0.0f)) { set_error("camera look vector has zero length"); return RM_ERR_INVALID_ARGUMENT; }
+  const float il = 1.0f / ll;
+  const float wx = -(lx * il), wy = -(ly * il), wz = -(lz * il);
+  const float duw = ux * wx + uy * wy + uz * wz;
+  float vx = ux - duw * wx, vy = uy - duw * wy, vz = uz - duw * wz;
+  const float vl = std::sqrt(vx * vx + vy * vy + vz * vz);
+  if (!(vl > 0.0f)) { set_error("camera up vector is parallel to look"); return RM_ERR_INVALID_ARGUMENT; }
+  const float iv = 1.0f / vl;
+  vx *= iv; vy *= iv; vz *= iv;
+  const float uxx = vy * wz - wy * vz, uyy = vz * wx - wz * vx, uzz = vx * wy - wx * vy;
+  Mat4 T = mat_identity();
+  T.at(0, 3) = -cd->pos[0]; T.at(1, 3) = -cd->pos[1]; T.at(2, 3) = -cd->pos[2];
+  Mat4 R = mat_identity();
+  R.at(0, 0) = uxx; R.at(0, 1) = uyy; R.at(0, 2) = uzz;
+  R.at(1, 0) = vx; R.at(1, 1) = vy; R.at(1, 2) = vz;
+  R.at(2, 0) = wx; R.at(2, 1) = wy; R.at(2, 2) = wz;
+  const Mat4 V = mat_mul(R, T);
+  // projection
+  const float aspect = (float)W / (float)H;
+  const float vh = 2.0f * farPlane * std::tan(cd->heightAngle / 2.0f);
+  const float vw = aspect * vh;
+  Mat4 S = mat_identity();
+  S.at(0, 0) = 2.0f / vw; S.at(1, 1) = 2.0f / vh; S.at(2, 2) = 1.0f / farPlane;
+  const float c = -nearPlane / farPlane;
+  Mat4 U = mat_identity();
+  U.at(2, 2) = 1.0f / (1.0f + c); U.at(3, 2) = -1.0f; U.at(2, 3) = -c / (1.0f + c); U.at(3, 3) = 0.0f;
+  Mat4 G = mat_identity();
+  G.at(2, 2) = -2.0f; G.at(2, 3) = -1.0f;
+  const Mat4 P = mat_mul(mat_mul(G, U), S);
+  const Mat4 inv = mat_inverse(mat_mul(P, V));
+  if (view) std::memcpy(view, V.m, sizeof(V.m));
+  if (proj) std::memcpy(proj, P.m, sizeof(P.m));
+  if (out) {
+    std::memcpy(out->invProjView, inv.m, sizeof(inv.m));
+    out->initialFar = farPlane;
+    out->eyePosition[0] = cd->pos[0]; out->eyePosition[1] = cd->pos[1]; out->eyePosition[2] = cd->pos[2];
+    out->eyePosition[3] = cd->pos[3];
+  }
+  return RM_OK;
+}
+
+int rm_shard_rows(int H, int tileRows, int shard, int numShards) {
+  if (H <= 0 || tileRows <= 0 || numShards <= 0 || shard < 0 || shard >= numShards) return -1;
+  return shard_rows(H, tileRows, shard, numShards);
+}
+int rm_shard_row_to_frame(int H, int tileRows, int shard, int numShards, int localRow) {
+  if (H <= 0 || tileRows <= 0 || numShards <= 0 || shard < 0 || shard >= numShards) return -1;
+  if (localRow < 0 || localRow >= shard_rows(H, tileRows, shard, numShards)) return -1;
+  return ((localRow / tileRows) * numShards + shard) * tileRows + (localRow % tileRows);
+}
+
+// RGBA8, filter 0 on every row, one zlib stream.
+int rm_write_png(const char *path, const uint8_t *rgba, int W, int H) {
+  if (!path || !rgba || W <= 0 || H <= 0) { set_error("bad png arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  std::vector<uint8_t> raw((size_t)H * ((size_t)W * 4 + 1));
+  for (int y = 0; y < H; y++) {
+    raw[(size_t)y * (W * 4 + 1)] = 0;
+    std::memcpy(&raw[(size_t)y * (W * 4 + 1) + 1], rgba + (size_t)y * W * 4, (size_t)W * 4);
+  }
+  uLongf zlen = compressBound(raw.size());
+  std::vector<uint8_t> z(zlen);
+  if (compress2(z.data(), &zlen, raw.data(), raw.size(), 1) != Z_OK) { set_error("zlib compress failed"); return RM_ERR_IO; }
+  FILE *f = std::fopen(path, "wb");
+  if (!f) { set_error(std::string("cannot open ") + path); return RM_ERR_IO; }
+  auto be32 = [](uint8_t *p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+  auto chunk = [&](const char *tag, const uint8_t *data, uint32_t len) {
+    uint8_t hdr[8];
+    be32(hdr, len);
+    std::memcpy(hdr + 4, tag, 4);
+    std::fwrite(hdr, 1, 8, f);
+    if (len) std::fwrite(data, 1, len, f);
+    uLong crc = crc32(0L, reinterpret_cast<const Bytef *>(tag), 4);
+    if (len) crc = crc32(crc, data, len);
+    uint8_t c[4];
+    be32(c, (uint32_t)crc);
+    std::fwrite(c, 1, 4, f);
+  };
+  const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  std::fwrite(sig, 1, 8, f);
+  uint8_t ihdr[13];
+  be32(ihdr, (uint32_t)W); be32(ihdr + 4, (uint32_t)H);
+  ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  chunk("IHDR", ihdr, 13);
+  chunk("IDAT", z.data(), (uint32_t)zlen);
+  chunk("IEND", nullptr, 0);
+  const bool ok = std::fclose(f) == 0;
+  if (!ok) { set_error("short write"); return RM_ERR_IO; }
+  return RM_OK;
+}
+
+}  // extern "C"

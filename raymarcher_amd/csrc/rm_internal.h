@@ -1,0 +1,26 @@
+// rm_internal.h — helpers shared by the launcher (rm_kernels.hip) and the host side (rm_host.cpp).
+#pragma once
+#include <string>
+
+#ifndef __HIPCC__
+#define __host__
+#define __device__
+#endif
+
+namespace rm {
+
+// Records the text returned by rm_last_error() for the calling thread.
+void set_error(const std::string &msg);
+
+// Rows owned by `shard` when an H-row frame is cut into tiles of tileRows rows dealt round-robin.
+__host__ __device__ inline int shard_rows(int H, int tileRows, int shard, int numShards) {
+  const int tiles = (H + tileRows - 1) / tileRows;
+  if (shard >= tiles) return 0;
+  const int owned = (tiles - shard + numShards - 1) / numShards;
+  int rows = owned * tileRows;
+  const int lastRows = H - (tiles - 1) * tileRows;  // rows of the (possibly partial) last tile
+  if ((tiles - 1) % numShards == shard) rows -= tileRows - lastRows;
+  return rows;
+}
+
+}  // namespace rm

@@ -1,0 +1,384 @@
+// rm_kernels.hip — HIP kernels and the C-ABI launcher of the per-pixel raymarch (gfx950 only).
+//
+// Replaces Realtime::rayMarch() of the reference (src/realtimerender.cpp:53-87): instead of uploading
+// ~600 uniforms by name and drawing a full-screen quad through resources/raymarch.{vert,frag}, the
+// launcher copies one constant SceneBlock to the device and launches one lane per pixel.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rm_device.hip.h"
+#include "rm_internal.h"
+
+namespace rm {
+
+// Maps a packed output row to its frame row: rows are grouped in tiles of `tileRows`; this launch owns
+// tiles shard, shard+numShards, …  (rm_render: tileRows = rows, numShards = 1).
+struct RowMap {
+  int rowBegin, tileRows, shard, numShards;
+  __host__ __device__ int frameRow(int r) const {
+    return rowBegin + ((r / tileRows) * numShards + shard) * tileRows + (r % tileRows);
+  }
+};
+
+// Block = 4 waves side by side, each wave an 8×8 pixel tile → the block covers 32×8 pixels.
+constexpr int kBlockW = 32, kBlockH = 8;
+
+template <bool BULB, bool COUNT>
+__global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                      int nRows, float4 *__restrict__ out,
+                                                      float4 *__restrict__ bright,
+                                                      unsigned long long *__restrict__ counters) {
+  // LDS copy of the object table for per-lane (divergent) material lookups.
+  __shared__ RmObject s_objs[RM_MAX_OBJECTS];
+  {
+    const int nd = sb->numObjects * (int)(sizeof(RmObject) / 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sb->objs);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_objs);
+    for (int i = threadIdx.x; i < nd; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = blockIdx.x * kBlockW + wave * 8 + (lane & 7);
+  const int r = blockIdx.y * kBlockH + (lane >> 3);
+  if (x >= W || r >= nRows) return;
+  const int y = map.frameRow(r);
+  V4 col, br;
+  Counters cnt{0, 0};
+  bool hit;
+  shadePixel<BULB, COUNT>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  const size_t o = (size_t)r * W + x;
+  out[o] = make_float4(col.x, col.y, col.z, col.w);
+  if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
+  if (COUNT) {
+    atomicAdd(&counters[0], cnt.evals);
+    atomicAdd(&counters[1], cnt.iters);
+    if (hit) atomicAdd(&counters[2], 1ull);
+  }
+}
+
+__global__ void probe_math_kernel(int fn, const float *x, const float *y, const float *z, float *out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = x[i], b = y ? y[i] : 0.0f, c = z ? z[i] : 0.0f, r = 0.0f;
+  switch (fn) {
+    case RM_FN_SIN: r = sin_(a); break;
+    case RM_FN_COS: r = cos_(a); break;
+    case RM_FN_ACOS: r = acos_(a); break;
+    case RM_FN_ATAN2: r = atan2_(a, b); break;
+    case RM_FN_LOG2: r = log2_(a); break;
+    case RM_FN_EXP2: r = exp2_(a); break;
+    case RM_FN_POW: r = pow_(a, b); break;
+    case RM_FN_SQRT: r = sqrt_(a); break;
+    case RM_FN_DIV: r = a / b; break;
+    case RM_FN_PNOISE3: r = pnoise(v3(a, b, c)); break;
+  }
+  out[i] = r;
+}
+
+__global__ void probe_sdscene_kernel(const SceneBlock *__restrict__ sb, const float *pts, float *out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Counters cnt{0, 0};
+  SceneMin m = sdScene<false, false>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
+  out[4 * i] = m.d;
+  out[4 * i + 1] = (float)m.idx;
+  out[4 * i + 2] = m.trap.y;
+  out[4 * i + 3] = m.trap.z;
+}
+
+// clamp → ×255 → round-half-up, vertical flip (src/realtime.cpp:337-338 + GL's RGBA8 conversion).
+__global__ void to_rgba8_kernel(const float4 *__restrict__ in, uchar4 *__restrict__ out, int W, int H) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  float4 c = in[(size_t)y * W + x];
+  auto q = [](float v) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); return (unsigned char)(v * 255.0f + 0.5f); };
+  out[(size_t)(H - 1 - y) * W + x] = make_uchar4(q(c.x), q(c.y), q(c.z), q(c.w));
+}
+
+// gathered[shard-major packed rows] → frame rows
+__global__ void deinterleave_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int W, int H, int tileRows,
+                                    int numShards, int strideRows) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;  // y = frame row
+  if (x >= W) return;
+  int tile = y / tileRows, shard = tile % numShards;
+  // rows owned by shards < shard, plus this shard's rows before frame row y
+  int before = shard * strideRows;
+  if (strideRows == 0)
+    for (int s = 0; s < shard; s++) before += shard_rows(H, tileRows, s, numShards);
+  int local = (tile / numShards) * tileRows + (y % tileRows);
+  out[(size_t)y * W + x] = in[(size_t)(before + local) * W + x];
+}
+
+// ---- launcher state -------------------------------------------------------------------------------------
+namespace {
+constexpr int kSlots = 8;
+struct Slot {
+  SceneBlock *host = nullptr;  // pinned
+  SceneBlock *dev = nullptr;
+  hipEvent_t done = nullptr;
+  bool used = false;
+};
+struct DeviceState {
+  Slot slots[kSlots];
+  int next = 0;
+  unsigned long long *dCounters = nullptr;
+  bool init = false;
+};
+std::mutex g_mu;
+DeviceState g_dev[64];
+bool g_timing = false;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timed;
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                               \
+      return RM_ERR_DEVICE;                                                                       \
+    }                                                                                             \
+  } while (0)
+
+int acquire_slot(Slot **out) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { set_error("device index out of range"); return RM_ERR_DEVICE; }
+  DeviceState &ds = g_dev[dev];
+  if (!ds.init) {
+    for (auto &s : ds.slots) {
+      HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&s.host), sizeof(SceneBlock), hipHostMallocDefault));
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(SceneBlock)));
+      HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 3 * sizeof(unsigned long long)));
+    ds.init = true;
+  }
+  Slot &s = ds.slots[ds.next];
+  ds.next = (ds.next + 1) % kSlots;
+  if (s.used) HIP_OK(hipEventSynchronize(s.done));  // only blocks with > kSlots launches in flight
+  s.used = true;
+  *out = &s;
+  return RM_OK;
+}
+
+int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                   const RmGlobals *g, const RmSettings *s) {
+  if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights) || numObjects < 0 || numLights < 0) {
+    set_error("null scene pointer or negative count");
+    return RM_ERR_INVALID_ARGUMENT;
+  }
+  if (numObjects > RM_MAX_OBJECTS || numLights > RM_MAX_LIGHTS) {
+    set_error("scene exceeds RM_MAX_OBJECTS / RM_MAX_LIGHTS");
+    return RM_ERR_CAPACITY;
+  }
+  if (s->maxSteps < 0 || s->fractalIters < 0 || s->mengerLevels < 0 || s->numReflection < 0) {
+    set_error("negative loop bound in RmSettings");
+    return RM_ERR_INVALID_ARGUMENT;
+  }
+  const uint32_t unsupported = RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA | RM_FEAT_CLOUD | RM_FEAT_TERRAIN |
+                               RM_FEAT_SKY_BACKGROUND;
+  if ((s->features & unsupported) || s->enableSkyBox) {
+    set_error("feature mask / skybox outside the implemented hot-path scope");
+    return RM_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < numObjects; i++) {
+    if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM || objs[i].texLoc != -1 || objs[i].isEmissive) {
+      set_error("object " + std::to_string(i) + ": CUSTOM type, texture or emissive (area light) not supported");
+      return RM_ERR_UNSUPPORTED;
+    }
+  }
+  for (int i = 0; i < numLights; i++) {
+    if (lights[i].type < 0 || lights[i].type > RM_LIGHT_SPOT) {
+      set_error("light " + std::to_string(i) + ": area / unknown light type not supported");
+      return RM_ERR_UNSUPPORTED;
+    }
+  }
+  return RM_OK;
+}
+
+int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut) {
+  Slot *slot;
+  int st = acquire_slot(&slot);
+  if (st != RM_OK) return st;
+  SceneBlock *h = slot->host;
+  h->cam = *cam; h->g = *g; h->s = *s;
+  h->numObjects = numObjects; h->numLights = numLights;
+  for (int i = 0; i < numObjects; i++) h->objs[i] = objs[i];
+  for (int i = 0; i < numLights; i++) h->lights[i] = lights[i];
+  HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
+  *slotOut = slot;
+  return RM_OK;
+}
+
+int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                  const RmGlobals *g, const RmSettings *s, int W, int H, RowMap map, int nRows, float *d_rgba,
+                  float *d_bright, hipStream_t stream, bool count, RmCounters *countersOut) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s);
+  if (st != RM_OK) return st;
+  if (W <= 0 || H <= 0 || nRows < 0 || !d_rgba) { set_error("bad frame size or null output"); return RM_ERR_INVALID_ARGUMENT; }
+  if (nRows == 0) return RM_OK;
+  Slot *slot;
+  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot);
+  if (st != RM_OK) return st;
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  unsigned long long *dc = g_dev[dev].dCounters;
+  if (count) HIP_OK(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), stream));
+  dim3 grid((W + kBlockW - 1) / kBlockW, (nRows + kBlockH - 1) / kBlockH), block(256);
+  const bool bulb = (numObjects == 1 && objs[0].type == RM_MANDELBULB);
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (g_timing) {
+    HIP_OK(hipEventCreate(&t0));
+    HIP_OK(hipEventCreate(&t1));
+    HIP_OK(hipEventRecord(t0, stream));
+  }
+  float4 *o = reinterpret_cast<float4 *>(d_rgba), *b = reinterpret_cast<float4 *>(d_bright);
+  if (bulb) {
+    if (count) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+  } else {
+    if (count) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+  }
+  HIP_OK(hipGetLastError());
+  if (g_timing) {
+    HIP_OK(hipEventRecord(t1, stream));
+    g_timed.emplace_back(t0, t1);
+  }
+  HIP_OK(hipEventRecord(slot->done, stream));
+  if (count) {
+    unsigned long long hc[3];
+    HIP_OK(hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (countersOut) { countersOut->sceneEvals = hc[0]; countersOut->bulbIters = hc[1]; countersOut->hitPixels = hc[2]; }
+  }
+  return RM_OK;
+}
+}  // namespace
+}  // namespace rm
+
+using namespace rm;
+
+extern "C" {
+
+int rm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+int rm_set_device(int device) {
+  HIP_OK(hipSetDevice(device));
+  return RM_OK;
+}
+
+int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+              const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *d_rgba,
+              float *d_bright, void *stream) {
+  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
+  int n = rowEnd - rowBegin;
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
+                       static_cast<hipStream_t>(stream), false, nullptr);
+}
+
+int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                      const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *d_rgba,
+                      float *d_bright, RmCounters *out) {
+  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
+  int n = rowEnd - rowBegin;
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, true, out);
+}
+
+int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                    const RmGlobals *g, const RmSettings *s, int W, int H, int tileRows, int shard, int numShards,
+                    float *d_rgba, float *d_bright, void *stream) {
+  if (tileRows <= 0 || numShards <= 0 || shard < 0 || shard >= numShards) {
+    set_error("bad tile partition");
+    return RM_ERR_INVALID_ARGUMENT;
+  }
+  RowMap map{0, tileRows, shard, numShards};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards),
+                       d_rgba, d_bright, static_cast<hipStream_t>(stream), false, nullptr);
+}
+
+int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
+                    int shardStrideRows, void *stream) {
+  if (!d_gathered || !d_frame || W <= 0 || H <= 0 || tileRows <= 0 || numShards <= 0 || numShards > 64 ||
+      (shardStrideRows != 0 && shardStrideRows < shard_rows(H, tileRows, 0, numShards))) {
+    set_error("bad deinterleave arguments");
+    return RM_ERR_INVALID_ARGUMENT;
+  }
+  dim3 grid((W + 255) / 256, H), block(256);
+  hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4 *>(d_gathered), reinterpret_cast<float4 *>(d_frame), W, H, tileRows,
+                     numShards, shardStrideRows);
+  HIP_OK(hipGetLastError());
+  return RM_OK;
+}
+
+int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *stream) {
+  if (!d_rgba || !d_out || W <= 0 || H <= 0) { set_error("bad frame arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  dim3 grid((W + 255) / 256, H), block(256);
+  hipLaunchKernelGGL(to_rgba8_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4 *>(d_rgba), reinterpret_cast<uchar4 *>(d_out), W, H);
+  HIP_OK(hipGetLastError());
+  return RM_OK;
+}
+
+int rm_set_timing(int on) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_timing = on != 0;
+  for (auto &p : g_timed) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  g_timed.clear();
+  return RM_OK;
+}
+int rm_get_timing(double *avgKernelMs, int *launches) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  double total = 0.0;
+  for (auto &p : g_timed) {
+    HIP_OK(hipEventSynchronize(p.second));
+    float ms = 0.0f;
+    HIP_OK(hipEventElapsedTime(&ms, p.first, p.second));
+    total += ms;
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  if (launches) *launches = (int)g_timed.size();
+  if (avgKernelMs) *avgKernelMs = g_timed.empty() ? 0.0 : total / (double)g_timed.size();
+  g_timed.clear();
+  return RM_OK;
+}
+
+int rm_probe_math(int fn, const float *d_x, const float *d_y, const float *d_z, float *d_out, int n, void *stream) {
+  if (fn < 0 || fn >= RM_FN_COUNT || !d_x || !d_out || n < 0) { set_error("bad probe arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (n == 0) return RM_OK;
+  hipLaunchKernelGGL(probe_math_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), fn, d_x,
+                     d_y, d_z, d_out, n);
+  HIP_OK(hipGetLastError());
+  return RM_OK;
+}
+
+int rm_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s, const float *d_pts,
+                     float *d_out, int n, void *stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  RmCamera cam{};
+  int st = validate_scene(&cam, objs, numObjects, nullptr, 0, g, s);
+  if (st != RM_OK) return st;
+  if (!d_pts || !d_out || n < 0) { set_error("bad probe arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (n == 0) return RM_OK;
+  Slot *slot;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  st = stage_scene(&cam, objs, numObjects, nullptr, 0, g, s, hs, &slot);
+  if (st != RM_OK) return st;
+  hipLaunchKernelGGL(probe_sdscene_kernel, dim3((n + 255) / 256), dim3(256), 0, hs, slot->dev, d_pts, d_out, n);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(slot->done, hs));
+  return RM_OK;
+}
+
+}  // extern "C"

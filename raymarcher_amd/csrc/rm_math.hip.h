@@ -1,0 +1,150 @@
+// rm_math.hip.h — device implementation of the "rm_math" numeric contract for gfx950.
+//
+// GLSL leaves the precision of sin/cos/acos/atan/pow/exp2/log implementation-defined
+// (the reference calls them all over resources/raymarch.frag, e.g. frag:787-793).  This project fixes
+// one legal implementation built only from correctly rounded binary32 operations
+// (v_add/v_mul/v_fma, IEEE division and sqrt expansions, v_floor, v_rndne, integer bit moves) so that
+// a frame is reproducible bit for bit; the CPU oracle implements the same contract separately and the
+// GPU tests compare bits.  Compile with -ffp-contract=off and without fast-math: a fused multiply-add
+// exists only where fma() is written.  Branch-free select forms are used so a wave never diverges
+// inside a built-in.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rm {
+
+#define RM_DEV __device__ __forceinline__
+
+RM_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RM_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+RM_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+RM_DEV float fabs_(float x) { return __builtin_fabsf(x); }
+// GLSL min/max as compare-select: "y if y < x else x" / "y if x < y else x".
+RM_DEV float min_(float x, float y) { return (y < x) ? y : x; }
+RM_DEV float max_(float x, float y) { return (x < y) ? y : x; }
+RM_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
+RM_DEV float floor_(float x) { return __builtin_floorf(x); }
+RM_DEV float fract_(float x) { return x - __builtin_floorf(x); }
+RM_DEV float mod_(float x, float y) { return fma(-y, __builtin_floorf(x / y), x); }
+RM_DEV float step_(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }
+RM_DEV float mix_(float x, float y, float a) { return fma(y, a, x * (1.0f - a)); }
+RM_DEV float smoothstep_(float e0, float e1, float x) {
+  float t = clamp_((x - e0) / (e1 - e0), 0.0f, 1.0f);
+  return (t * t) * fma(-2.0f, t, 3.0f);
+}
+RM_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
+
+constexpr float kPi = 3.14159274f;          // 0x40490fdb
+constexpr float kPio2 = 1.57079637f;        // 0x3fc90fdb
+constexpr float k2oPi = 0.636619747f;       // 0x3f22f983
+constexpr float kPio2Mid = -4.37113883e-08f;  // 0xb33bbd2e
+constexpr float kPio2Lo = -1.71512451e-15f;   // 0xa6f72ced
+
+// sin and cos of one argument sharing the Cody–Waite reduction (bits equal the separate calls).
+RM_DEV void sincos_(float x, float &sn, float &cs) {
+  bool ok = fabs_(x) < 4194304.0f;
+  float k = __builtin_rintf(x * k2oPi);
+  float r = fma(-k, kPio2, x);
+  r = fma(-k, kPio2Mid, r);
+  r = fma(-k, kPio2Lo, r);
+  int q = ok ? (int)k : 0;
+  r = ok ? r : 0.0f;
+  float z = r * r;
+  float s = fma(z, -1.950213627e-04f, 8.332063444e-03f);
+  s = fma(z, s, -1.666665375e-01f);
+  float sp = fma(s * z, r, r);
+  float c = fma(z, 2.441812649e-05f, -1.388718490e-03f);
+  c = fma(z, c, 4.166664183e-02f);
+  float cp = fma(z, c * z, fma(z, -0.5f, 1.0f));
+  float sv = (q & 1) ? cp : sp;
+  float cv = (q & 1) ? sp : cp;
+  // sign flips as integer xor of the sign bit (exact negation, also of zero)
+  sn = u2f(f2u(sv) ^ ((uint32_t)(q & 2) << 30));
+  cs = u2f(f2u(cv) ^ ((uint32_t)((q + 1) & 2) << 30));
+}
+RM_DEV float sin_(float x) { float s, c; sincos_(x, s, c); return s; }
+RM_DEV float cos_(float x) { float s, c; sincos_(x, s, c); return c; }
+
+RM_DEV float asin_p(float z) {
+  float p = fma(z, 4.277068377e-02f, 2.384351753e-02f);
+  p = fma(z, p, 4.553402960e-02f);
+  p = fma(z, p, 7.494829595e-02f);
+  p = fma(z, p, 1.666676253e-01f);
+  return p;
+}
+RM_DEV float acos_(float x) {
+  float ax = fabs_(x);
+  bool small = ax <= 0.5f;
+  float z = small ? (x * x) : ((1.0f - ax) * 0.5f);
+  float s = small ? x : sqrt_(z);
+  float as = fma(s * z, asin_p(z), s);
+  float big = 2.0f * as;
+  big = (x < 0.0f) ? (kPi - big) : big;
+  float r = small ? (kPio2 - as) : big;
+  float edge = (x > 0.0f) ? 0.0f : kPi;
+  return (small || ax < 1.0f) ? r : edge;
+}
+
+RM_DEV float atan_p(float s) {
+  float p = fma(s, 2.920665313e-03f, -1.636782475e-02f);
+  p = fma(s, p, 4.321170226e-02f);
+  p = fma(s, p, -7.552202046e-02f);
+  p = fma(s, p, 1.066599935e-01f);
+  p = fma(s, p, -1.421105415e-01f);
+  p = fma(s, p, 1.999377310e-01f);
+  p = fma(s, p, -3.333315253e-01f);
+  return p;
+}
+RM_DEV float atan2_(float y, float x) {
+  float ax = fabs_(x), ay = fabs_(y);
+  bool sw = ax < ay;
+  float mx = sw ? ay : ax;
+  float mn = sw ? ax : ay;
+  float t = mn / mx;
+  t = (t == t) ? t : ((mx == 0.0f) ? 0.0f : 1.0f);
+  float s = t * t;
+  float a = fma(t * s, atan_p(s), t);
+  a = (ay > ax) ? (kPio2 - a) : a;
+  a = (x < 0.0f) ? (kPi - a) : a;
+  return u2f((f2u(a) & 0x7fffffffu) | (f2u(y) & 0x80000000u));
+}
+
+RM_DEV float log2_(float x) {
+  uint32_t ux = f2u(x) - 0x3f3504f3u;
+  int32_t e = (int32_t)ux >> 23;
+  float m = u2f((ux & 0x007fffffu) + 0x3f3504f3u);
+  float f = m - 1.0f;
+  float l = fma(f, 1.258333027e-01f, -2.072679251e-01f);
+  l = fma(f, l, 2.157161385e-01f);
+  l = fma(f, l, -2.389451116e-01f);
+  l = fma(f, l, 2.879162133e-01f);
+  l = fma(f, l, -3.607036769e-01f);
+  l = fma(f, l, 4.809106290e-01f);
+  l = fma(f, l, -7.213473320e-01f);
+  l = fma(f, l, 1.442695022e+00f);
+  float r = fma(f, l, (float)e);
+  return (x >= 1.17549435e-38f) ? r : -__builtin_inff();
+}
+RM_DEV float exp2_(float x) {
+  float n = __builtin_rintf(x);
+  float f = x - n;
+  float p = fma(f, 1.535335905e-04f, 1.339887502e-03f);
+  p = fma(f, p, 9.618436918e-03f);
+  p = fma(f, p, 5.550332367e-02f);
+  p = fma(f, p, 2.402264774e-01f);
+  p = fma(f, p, 6.931471825e-01f);
+  p = fma(f, p, 1.0f);
+  // clamp n only to keep the int conversion defined on lanes whose result is replaced below
+  int ni = (int)max_(min_(n, 200.0f), -200.0f);
+  float r = p * u2f((uint32_t)(ni + 127) << 23);
+  r = (x >= 128.0f) ? __builtin_inff() : r;
+  return (x > -125.0f) ? r : 0.0f;
+}
+RM_DEV float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+constexpr float kLn2 = 0.693147182f;   // 0x3f317218
+constexpr float kLog2e = 1.44269502f;  // 0x3fb8aa3b
+RM_DEV float log_(float x) { return log2_(x) * kLn2; }
+RM_DEV float exp_(float x) { return exp2_(x * kLog2e); }
+
+}  // namespace rm

@@ -1,0 +1,185 @@
+"""Host-side driver of the C-ABI: scene tables, camera, row-range / row-tile renders into torch tensors.
+
+Mirrors the reference's scene surface — RayMarchScene::initScene/getShapes/getLights/getCamera/
+getGlobalData (src/raymarch/raymarchscene.h:12-90) and Realtime::rayMarch / saveViewportImage
+(src/realtimerender.cpp:53-87, src/realtime.cpp:284-350) — on top of rm_scene_*, rm_camera_build,
+rm_render*, rm_frame_to_rgba8 and rm_write_png.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+from . import abi
+from ._lib import check, lib
+
+
+@dataclass
+class SceneTables:
+    """The uniform tables one frame needs (what configure*Uniforms upload, realtimerender.cpp:596-811)."""
+    camera: abi.RmCamera
+    objects: C.Array
+    num_objects: int
+    lights: C.Array
+    num_lights: int
+    globals_: abi.RmGlobals
+
+    def args(self, settings):
+        return (C.byref(self.camera), self.objects, self.num_objects, self.lights, self.num_lights,
+                C.byref(self.globals_), C.byref(settings))
+
+
+def build_camera(pos, look, up, height_angle_rad, W, H, near=0.1, far=100.0):
+    """Camera::initializeCamera + configureCameraUniforms via rm_camera_build (camera.cpp:8-133)."""
+    cd = abi.RmCameraData()
+    for i in range(3):
+        cd.pos[i], cd.look[i], cd.up[i] = pos[i], look[i], up[i]
+    cd.pos[3], cd.look[3], cd.up[3] = 1.0, 0.0, 0.0
+    cd.heightAngle = height_angle_rad
+    cam = abi.RmCamera()
+    view = (C.c_float * 16)()
+    proj = (C.c_float * 16)()
+    check(lib().rm_camera_build(C.byref(cd), W, H, near, far, view, proj, C.byref(cam)))
+    return cam, list(view), list(proj)
+
+
+class Scene:
+    """A parsed scenefile (SceneParser::parse + RayMarchScene::initScene)."""
+
+    def __init__(self, path=None, text=None):
+        self._h = C.c_void_p()
+        L = lib()
+        if path is not None:
+            check(L.rm_scene_load(str(path).encode(), C.byref(self._h)))
+        elif text is not None:
+            check(L.rm_scene_load_string(text.encode(), C.byref(self._h)))
+        else:
+            raise ValueError("path or text required")
+
+    def close(self):
+        if self._h:
+            lib().rm_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_objects(self):
+        return lib().rm_scene_num_objects(self._h)
+
+    @property
+    def num_lights(self):
+        return lib().rm_scene_num_lights(self._h)
+
+    def camera_data(self):
+        cd = abi.RmCameraData()
+        check(lib().rm_scene_camera_data(self._h, C.byref(cd)))
+        return cd
+
+    def texture_of(self, i):
+        t = lib().rm_scene_object_texture(self._h, i)
+        return t.decode() if t else None
+
+    def tables(self, W, H, near=0.1, far=100.0, host_settings=None):
+        """Copy the tables out (so they outlive the handle) and build the camera for a W×H frame."""
+        L = lib()
+        no, nl = self.num_objects, self.num_lights
+        objs = (abi.RmObject * max(no, 1))()
+        lights = (abi.RmLight * max(nl, 1))()
+        po, pl = L.rm_scene_objects(self._h), L.rm_scene_lights(self._h)
+        for i in range(no):
+            C.memmove(C.byref(objs[i]), C.byref(po[i]), C.sizeof(abi.RmObject))
+        for i in range(nl):
+            C.memmove(C.byref(lights[i]), C.byref(pl[i]), C.sizeof(abi.RmLight))
+        g = abi.RmGlobals()
+        hs = host_settings
+        check(L.rm_scene_globals(self._h, C.byref(hs) if hs is not None else None, C.byref(g)))
+        cd = self.camera_data()
+        cam = abi.RmCamera()
+        check(L.rm_camera_build(C.byref(cd), W, H, near, far, None, None, C.byref(cam)))
+        return SceneTables(cam, objs, no, lights, nl, g)
+
+
+class Renderer:
+    """Launches the HIP raymarch on one GPU; outputs are torch tensors on that device."""
+
+    def __init__(self, device=0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("raymarcher_amd.Renderer needs a HIP device; there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        check(lib().rm_set_device(device))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def render(self, tables, settings, W, H, row_begin=0, row_end=None, bright=False, out=None):
+        """rm_render: rows [row_begin,row_end) → float32 tensor (rows, W, 4), row 0 = bottom."""
+        t = self.torch
+        row_end = H if row_end is None else row_end
+        n = row_end - row_begin
+        if out is None:
+            out = t.empty((max(n, 0), W, 4), dtype=t.float32, device=self.device)
+        br = t.empty_like(out) if bright else None
+        check(lib().rm_render(*tables.args(settings), W, H, row_begin, row_end, C.c_void_p(out.data_ptr()),
+                              C.c_void_p(br.data_ptr()) if bright else None, self._stream()))
+        return (out, br) if bright else out
+
+    def render_counted(self, tables, settings, W, H):
+        t = self.torch
+        out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
+        cnt = abi.RmCounters()
+        t.cuda.synchronize(self.device)
+        check(lib().rm_render_counted(*tables.args(settings), W, H, 0, H, C.c_void_p(out.data_ptr()), None,
+                                      C.byref(cnt)))
+        return out, cnt
+
+    def render_tiles(self, tables, settings, W, H, tile_rows, shard, num_shards, out=None):
+        """rm_render_tiles: this shard's interleaved row tiles, packed → (rm_shard_rows, W, 4)."""
+        t = self.torch
+        n = lib().rm_shard_rows(H, tile_rows, shard, num_shards)
+        if out is None:
+            out = t.empty((max(n, 0), W, 4), dtype=t.float32, device=self.device)
+        check(lib().rm_render_tiles(*tables.args(settings), W, H, tile_rows, shard, num_shards,
+                                    C.c_void_p(out.data_ptr()), None, self._stream()))
+        return out
+
+    def deinterleave(self, gathered, W, H, tile_rows, num_shards, shard_stride_rows=0):
+        t = self.torch
+        frame = t.empty((H, W, 4), dtype=t.float32, device=self.device)
+        check(lib().rm_deinterleave(C.c_void_p(gathered.data_ptr()), C.c_void_p(frame.data_ptr()), W, H, tile_rows,
+                                    num_shards, shard_stride_rows, self._stream()))
+        return frame
+
+    def to_rgba8(self, frame):
+        """Clamp/quantise + vertical flip (saveViewportImage, realtime.cpp:284-350) → uint8 (H, W, 4)."""
+        t = self.torch
+        H, W = frame.shape[0], frame.shape[1]
+        out = t.empty((H, W, 4), dtype=t.uint8, device=self.device)
+        check(lib().rm_frame_to_rgba8(C.c_void_p(frame.data_ptr()), C.c_void_p(out.data_ptr()), W, H, self._stream()))
+        return out
+
+    def save_png(self, frame, path):
+        img = self.to_rgba8(frame).cpu().contiguous()
+        check(lib().rm_write_png(str(path).encode(), C.c_void_p(img.data_ptr()), img.shape[1], img.shape[0]))
+
+    def probe_math(self, fn, x, y=None, z=None):
+        t = self.torch
+        out = t.empty_like(x)
+        check(lib().rm_probe_math(fn, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()) if y is not None else None,
+                                  C.c_void_p(z.data_ptr()) if z is not None else None, C.c_void_p(out.data_ptr()),
+                                  x.numel(), self._stream()))
+        return out
+
+    def probe_sdscene(self, tables, settings, pts):
+        t = self.torch
+        n = pts.shape[0]
+        out = t.empty((n, 4), dtype=t.float32, device=self.device)
+        check(lib().rm_probe_sdscene(tables.objects, tables.num_objects, C.byref(tables.globals_), C.byref(settings),
+                                     C.c_void_p(pts.data_ptr()), C.c_void_p(out.data_ptr()), n, self._stream()))
+        return out

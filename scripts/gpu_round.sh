@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box session: parity tests, a bench line, and the rocprofv3 kernel summary.
+# Stops at the first step that times out (exit 124/137) so a hung GPU step is never followed by another.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+step() { # name, timeout, cmd...
+  local name=$1 t=$2; shift 2
+  echo "== $name" | tee -a gpurun_out/progress.log
+  timeout -k 10 "$t" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "== $name rc=$rc" | tee -a gpurun_out/progress.log
+  tail -n 15 "gpurun_out/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name, stopping"; exit $rc; fi
+  return $rc
+}
+step tests 900 python -m pytest tests -m gpu -q "${PYTEST_ARGS:--x}"
+TESTS_RC=$?
+step bench 600 python bench.py --steps "${STEPS:-10}" --warmup 2
+if [ "${PROFILE:-1}" = "1" ]; then
+  step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  find gpurun_out/prof -name '*kernel_stats*' | head -3
+fi
+exit $TESTS_RC

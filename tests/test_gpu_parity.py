@@ -1,0 +1,338 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle.
+
+The numeric contract makes every frame bit-reproducible, so the bar is BIT EQUALITY of
+the float32 outputs (tolerance 0), far inside the 1e-3 per-channel L∞ the north star states.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as h
+from raymarcher_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def tables_of(scene):
+    from raymarcher_amd.render import SceneTables
+    cam, objs, no, lights, nl, g = scene
+    return SceneTables(cam, objs, no, lights, nl, g)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(gpu, ref, what):
+    gb, rb = bits(gpu), bits(ref)
+    bad = gb != rb
+    if bad.any():
+        idx = np.argwhere(bad)[:5]
+        diff = np.abs(gpu.astype(np.float64) - ref.astype(np.float64))
+        raise AssertionError(f"{what}: {bad.sum()} of {bad.size} words differ; max |Δ| = {np.nanmax(diff):.3e}; "
+                             f"first at {idx.tolist()}")
+
+
+# ---------------------------------------------------------------- the numeric contract, function by function
+def _math_inputs(fn, n, rng):
+    f = np.float32
+    if fn in (abi.RM_FN_SIN, abi.RM_FN_COS):
+        x = np.concatenate([rng.uniform(-30, 30, n // 2), rng.uniform(-1e4, 1e4, n // 4), rng.normal(0, 1e-3, n // 4)])
+        x = np.concatenate([x, [0.0, -0.0, np.pi, 1e7, -1e7, np.inf, -np.inf, np.nan, 4194303.5, 4194304.0]])
+        return x.astype(f), None
+    if fn == abi.RM_FN_ACOS:
+        x = np.concatenate([rng.uniform(-1, 1, n), [0, 1, -1, 0.5, -0.5, 1.0000001, -1.0000001, 2, -2, np.nan, 0.49999997]])
+        return x.astype(f), None
+    if fn == abi.RM_FN_ATAN2:
+        y = np.concatenate([rng.normal(0, 2, n), [0, 0, -0.0, 1, -1, np.inf, np.inf, np.nan, 0.0, 1e-30]])
+        x = np.concatenate([rng.normal(0, 2, n), [0, -1, -1, 0, 0, np.inf, -np.inf, 1, -0.0, 1e-30]])
+        return y.astype(f), x.astype(f)
+    if fn == abi.RM_FN_LOG2:
+        x = np.concatenate([np.exp(rng.uniform(-80, 80, n)), rng.uniform(0.5, 2, n),
+                            [0, -0.0, 1, -1, 1e-45, 1.17549435e-38, 1.1754942e-38, np.inf, np.nan, 2, 0.70710677, 0.70710683]])
+        return x.astype(f), None
+    if fn == abi.RM_FN_EXP2:
+        x = np.concatenate([rng.uniform(-130, 130, n), rng.uniform(-1, 1, n),
+                            [0, -125, -125.00001, -124.99999, 127.5, 127.99999, 128, 1e30, -1e30, np.inf, -np.inf, np.nan, 0.5, -0.5, 1.5, 2.5]])
+        return x.astype(f), None
+    if fn == abi.RM_FN_POW:
+        x = np.concatenate([np.exp(rng.uniform(-5, 5, n)), [0, 0, 0, 1, 2, -1, np.inf, 0.9, 1e-40]])
+        y = np.concatenate([rng.uniform(-20, 100, n), [0, 1, -1, 5, 0.5, 2, 2, 1e5, 2]])
+        return x.astype(f), y.astype(f)
+    if fn == abi.RM_FN_SQRT:
+        x = np.concatenate([np.exp(rng.uniform(-87, 88, n)), [0, -0.0, 1e-45, 1e-40, 1.17549435e-38, np.inf, -1, np.nan, 2, 4]])
+        return x.astype(f), None
+    if fn == abi.RM_FN_DIV:
+        x = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-40, 40, n)), [0, 1, 1, -1, 0, np.inf, 1e-40, 1e38, 1]])
+        y = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-40, 40, n)), [1, 0, 3, 7, 0, np.inf, 1e3, 1e-5, 289]])
+        return x.astype(f), y.astype(f)
+    raise ValueError(fn)
+
+
+@pytest.mark.parametrize("fn", [abi.RM_FN_SIN, abi.RM_FN_COS, abi.RM_FN_ACOS, abi.RM_FN_ATAN2, abi.RM_FN_LOG2,
+                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV])
+def test_math_contract_bit_exact(renderer, fn):
+    import torch
+    rng = np.random.default_rng(1000 + fn)
+    x, y = _math_inputs(fn, 200000, rng)
+    ref = np.empty_like(x)
+    st = h.oracle().rmo_probe_math(fn, h.fptr(x), h.fptr(y) if y is not None else None, None, h.fptr(ref), x.size)
+    assert st == 0
+    tx = torch.from_numpy(x).cuda()
+    ty = torch.from_numpy(y).cuda() if y is not None else None
+    got = renderer.probe_math(fn, tx, ty).cpu().numpy()
+    # NaN payloads are compared as "both NaN"
+    both_nan = np.isnan(got) & np.isnan(ref)
+    gb, rb = bits(got), bits(ref)
+    bad = (gb != rb) & ~both_nan
+    assert not bad.any(), f"fn {fn}: {bad.sum()} mismatches, e.g. x={x[bad][:4]}, gpu={got[bad][:4]}, cpu={ref[bad][:4]}"
+
+
+def test_pnoise_bit_exact(renderer):
+    import torch
+    rng = np.random.default_rng(7)
+    n = 100000
+    p = rng.uniform(-40, 40, (3, n)).astype(np.float32)
+    p[:, :8] = np.array([[0, 0, 0], [1, 2, 3], [-1, -2, -3], [255.5, 0.25, -0.75], [256, 256, 256], [-0.0, 0.0, 5.5],
+                         [1e-8, -1e-8, 0.5], [12.999999, 3.0000002, -7.0]], dtype=np.float32).T
+    ref = np.empty(n, dtype=np.float32)
+    x, y, z = (np.ascontiguousarray(p[i]) for i in range(3))
+    assert h.oracle().rmo_probe_math(abi.RM_FN_PNOISE3, h.fptr(x), h.fptr(y), h.fptr(z), h.fptr(ref), n) == 0
+    got = renderer.probe_math(abi.RM_FN_PNOISE3, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(),
+                              torch.from_numpy(z).cuda()).cpu().numpy()
+    assert_bit_equal(got, ref, "pnoise")
+    assert np.abs(ref).max() <= 1.5 and np.abs(ref).max() > 0.3
+
+
+# ---------------------------------------------------------------- sdScene on random points, every primitive type
+def all_primitives_scene(W=64, H=64):
+    cam = h.make_camera((0, 0, 6), (0, 0, -1), (0, 1, 0), 45.0, W, H)
+    types = [abi.RM_CUBE, abi.RM_CONE, abi.RM_CYLINDER, abi.RM_SPHERE, abi.RM_OCTAHEDRON, abi.RM_TORUS, abi.RM_CAPSULE,
+             abi.RM_DEATHSTAR, abi.RM_RECTANGLE, abi.RM_SIERPINSKI, abi.RM_MENGERSPONGE, abi.RM_MANDELBULB]
+    objs = (abi.RmObject * len(types))()
+    for i, t in enumerate(types):
+        gx, gy = (i % 4) - 1.5, (i // 4) - 1.0
+        M = h.translate(1.6 * gx, 1.6 * gy, 0.0) @ h.scale(0.9, 0.8 + 0.05 * i, 0.9)
+        objs[i] = h.make_object(t, model=M, scale_factor=min(0.9, 0.8 + 0.05 * i), ambient=(.2, .2, .2),
+                                diffuse=(0.3 + 0.05 * i, 0.8, 1.0 - 0.05 * i), specular=(1, 1, 1), shininess=15.0 + i)
+    lights = (abi.RmLight * 3)(
+        h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.3, -1, -0.6)),
+        h.make_light(abi.RM_LIGHT_POINT, (1, 0.8, 0.6), pos=(3, 3, 4), func=(0.5, 0.1, 0.01)),
+        h.make_light(abi.RM_LIGHT_SPOT, (0.7, 0.8, 1), direction=(0, -1, -1), pos=(0, 5, 5), func=(0.8, 0.02, 0.0),
+                     angle=np.deg2rad(35.0), penumbra=np.deg2rad(12.0)))
+    return cam, objs, len(types), lights, 3, h.make_globals()
+
+
+def test_sdscene_bit_exact_all_primitives(renderer):
+    import torch
+    scene = all_primitives_scene()
+    s = abi.default_settings()
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-3.5, 3.5, (50000, 3)).astype(np.float32)
+    pts[:, 2] *= 0.4
+    ref = np.empty((pts.shape[0], 4), dtype=np.float32)
+    cam, objs, no, lights, nl, g = scene
+    assert h.oracle().rmo_probe_sdscene(objs, no, C.byref(g), C.byref(s), h.fptr(pts), h.fptr(ref), pts.shape[0]) == 0
+    got = renderer.probe_sdscene(tables_of(scene), s, torch.from_numpy(pts).cuda()).cpu().numpy()
+    assert_bit_equal(got, ref, "sdScene")
+    assert len(np.unique(ref[:, 1])) >= 10  # the points really exercise most object types
+
+
+# ---------------------------------------------------------------- whole frames
+FRAME_CASES = {
+    "bulb_reference_consts": (lambda W, H: h.scene_mandelbulb(W, H), {}, 96, 54),
+    "bulb_bench_consts_12iters": (lambda W, H: h.scene_mandelbulb(W, H), {"fractalIters": 12}, 96, 54),
+    "bulb_softshadow_ao": (lambda W, H: h.scene_mandelbulb(W, H), {"enableSoftShadow": 1, "enableAmbientOcclusion": 1}, 64, 36),
+    "primitives_phong": (lambda W, H: all_primitives_scene(W, H), {"maxSteps": 64}, 96, 64),
+    "primitives_softshadow_ao_nobump": (lambda W, H: all_primitives_scene(W, H),
+                                        {"enableSoftShadow": 1, "enableAmbientOcclusion": 1,
+                                         "features": abi.RM_FEAT_DARK_BACKGROUND}, 80, 48),
+}
+
+
+@pytest.mark.parametrize("name", list(FRAME_CASES))
+def test_frame_bit_exact(renderer, name):
+    build, over, W, H = FRAME_CASES[name]
+    scene = build(W, H)
+    s = abi.default_settings(**over)
+    ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+    out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+    assert_bit_equal(out.cpu().numpy(), ref, f"{name} fragColor")
+    assert_bit_equal(br.cpu().numpy(), ref_b, f"{name} BrightColor")
+    assert np.isfinite(ref).all()
+    hit = (ref[..., :3] != ref[0, 0, :3]).any(axis=-1).mean()
+    assert 0.05 < hit < 0.95, "frame should contain both object and background"
+
+
+def reflect_refract_scene(W, H):
+    cam = h.make_camera((0, 1.2, 5), (0, -0.2, -1), (0, 1, 0), 40.0, W, H)
+    objs = (abi.RmObject * 4)(
+        h.make_object(abi.RM_SPHERE, model=h.translate(-1.1, 0, 0) @ h.scale(1.6, 1.6, 1.6), scale_factor=1.6,
+                      ambient=(.1, .1, .1), diffuse=(.8, .2, .2), specular=(1, 1, 1), shininess=30, reflective=(.8, .8, .8)),
+        h.make_object(abi.RM_SPHERE, model=h.translate(1.1, 0, 0.3) @ h.scale(1.5, 1.5, 1.5), scale_factor=1.5,
+                      ambient=(.1, .1, .1), diffuse=(.2, .3, .8), specular=(1, 1, 1), shininess=50,
+                      transparent=(.9, .9, .9), ior=1.4),
+        h.make_object(abi.RM_CUBE, model=h.translate(0, -1.3, 0) @ h.scale(8, 1, 8), scale_factor=1.0,
+                      ambient=(.2, .2, .2), diffuse=(.6, .6, .5), specular=(.3, .3, .3), shininess=5, reflective=(.3, .3, .3)),
+        h.make_object(abi.RM_TORUS, model=h.translate(0.2, 0.4, -2.0) @ h.scale(2, 2, 2), scale_factor=2.0,
+                      ambient=(.1, .2, .1), diffuse=(.3, .9, .3), specular=(1, 1, 1), shininess=10))
+    lights = (abi.RmLight * 2)(
+        h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.5, -1, -0.4)),
+        h.make_light(abi.RM_LIGHT_POINT, (.8, .8, 1), pos=(-3, 4, 3), func=(0.6, 0.05, 0.0)))
+    return cam, objs, 4, lights, 2, h.make_globals(kt=0.8)
+
+
+@pytest.mark.parametrize("bounces", [1, 2])
+def test_reflection_refraction_bit_exact(renderer, bounces):
+    W, H = 96, 64
+    scene = reflect_refract_scene(W, H)
+    s = abi.default_settings(enableReflection=1, enableRefraction=1, numReflection=bounces)
+    ref = h.oracle_render(scene, s, W, H)
+    plain = h.oracle_render(scene, abi.default_settings(), W, H)
+    assert np.abs(ref - plain).max() > 0.05, "secondary rays must change the image"
+    out = renderer.render(tables_of(scene), s, W, H)
+    assert_bit_equal(out.cpu().numpy(), ref, "reflection+refraction")
+    assert ref[..., 3].max() >= 2.0  # alpha accumulates per bounce (frag:2520, 2568, 2572)
+
+
+def menger_scene(W, H):
+    cam = h.make_camera((2.6, 2.2, 3.0), (-2.6, -2.2, -3.0), (0, 1, 0), 30.0, W, H)
+    objs = (abi.RmObject * 1)(h.make_object(abi.RM_MENGERSPONGE, ambient=(.3, .3, .3), diffuse=(1, 1, 1),
+                                            specular=(1, 1, 1), shininess=25.0, reflective=(.4, .4, .4)))
+    lights = (abi.RmLight * 2)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-1, -1.5, -0.7)),
+                               h.make_light(abi.RM_LIGHT_DIRECTIONAL, (.5, .5, .6), (1, -0.5, 0.3)))
+    return cam, objs, 1, lights, 2, h.make_globals()
+
+
+@pytest.mark.parametrize("levels,bounces,itime", [(4, 1, 0.0), (5, 2, 0.0), (4, 1, 7.5)])
+def test_menger_bit_exact(renderer, levels, bounces, itime):
+    W, H = 80, 60
+    scene = menger_scene(W, H)
+    scene[5].iTime = itime
+    s = abi.default_settings(mengerLevels=levels, numReflection=bounces, enableReflection=1)
+    ref = h.oracle_render(scene, s, W, H)
+    out = renderer.render(tables_of(scene), s, W, H)
+    assert_bit_equal(out.cpu().numpy(), ref, "menger")
+
+
+def test_mandelbrot_2d_and_julia(renderer):
+    W, H = 64, 48
+    scene = list(h.scene_mandelbulb(W, H))
+    scene[5] = h.make_globals(two_d=1, itime=3.0)
+    s = abi.default_settings()
+    ref = h.oracle_render(tuple(scene), s, W, H)
+    assert_bit_equal(renderer.render(tables_of(tuple(scene)), s, W, H).cpu().numpy(), ref, "2-D mandelbrot")
+    assert ref[..., :3].std() > 0.01
+    scene[5] = h.make_globals(julia=(0.35, -0.2), power=6.0)
+    ref = h.oracle_render(tuple(scene), s, W, H)
+    assert_bit_equal(renderer.render(tables_of(tuple(scene)), s, W, H).cpu().numpy(), ref, "julia bulb power 6")
+
+
+# ---------------------------------------------------------------- edge cases of the boundary
+def test_row_ranges_and_ragged_sizes(renderer):
+    W, H = 37, 29  # not multiples of the 8×8 wave tile
+    scene = all_primitives_scene(W, H)
+    s = abi.default_settings(maxSteps=48)
+    ref = h.oracle_render(scene, s, W, H)
+    full = renderer.render(tables_of(scene), s, W, H).cpu().numpy()
+    assert_bit_equal(full, ref, "ragged frame")
+    part = renderer.render(tables_of(scene), s, W, H, 5, 18).cpu().numpy()
+    assert_bit_equal(part, ref[5:18], "row range")
+    empty = renderer.render(tables_of(scene), s, W, H, 7, 7)
+    assert empty.shape[0] == 0
+
+
+def test_empty_scene_is_background(renderer):
+    W, H = 16, 8
+    cam = h.make_camera((0, 0, 3), (0, 0, -1), (0, 1, 0), 45.0, W, H)
+    scene = (cam, (abi.RmObject * 1)(), 0, (abi.RmLight * 1)(), 0, h.make_globals())
+    out = renderer.render(tables_of(scene), abi.default_settings(), W, H).cpu().numpy()
+    assert (out == 1.0).all()  # WHITE_BACKGROUND, alpha 1
+    assert_bit_equal(out, h.oracle_render(scene, abi.default_settings(), W, H), "empty scene")
+
+
+def test_tiles_gather_roundtrip(renderer):
+    import torch
+    from raymarcher_amd import lib
+    W, H, T = 48, 50, 8  # last tile is partial (50 = 6·8 + 2)
+    scene = h.scene_mandelbulb(W, H)
+    s = abi.default_settings(fractalIters=12)
+    ref = h.oracle_render(scene, s, W, H)
+    for shards in (1, 2, 3, 4):
+        parts = [renderer.render_tiles(tables_of(scene), s, W, H, T, k, shards) for k in range(shards)]
+        assert sum(p.shape[0] for p in parts) == H
+        for k, p in enumerate(parts):
+            rows = [lib().rm_shard_row_to_frame(H, T, k, shards, r) for r in range(p.shape[0])]
+            assert_bit_equal(p.cpu().numpy(), ref[rows], f"shard {k}/{shards}")
+        frame = renderer.deinterleave(torch.cat(parts, 0).contiguous(), W, H, T, shards)
+        assert_bit_equal(frame.cpu().numpy(), ref, f"deinterleave {shards}")
+
+
+def test_unsupported_and_invalid_inputs(renderer):
+    from raymarcher_amd import RaymarcherError
+    W, H = 8, 8
+    scene = h.scene_mandelbulb(W, H)
+    t = tables_of(scene)
+    with pytest.raises(RaymarcherError) as e:
+        renderer.render(t, abi.default_settings(features=abi.RM_FEAT_SEA), W, H)
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
+    with pytest.raises(RaymarcherError) as e:
+        renderer.render(t, abi.default_settings(), W, H, 4, 12)
+    assert e.value.status == abi.RM_ERR_INVALID_ARGUMENT
+    t.objects[0].texLoc = 0
+    with pytest.raises(RaymarcherError) as e:
+        renderer.render(t, abi.default_settings(), W, H)
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
+    t.objects[0].texLoc = -1
+    t.num_objects = 31
+    with pytest.raises(RaymarcherError) as e:
+        renderer.render(t, abi.default_settings(), W, H)
+    assert e.value.status == abi.RM_ERR_CAPACITY
+
+
+def test_counters_match_oracle(renderer):
+    W, H = 64, 36
+    scene = h.scene_mandelbulb(W, H)
+    s = abi.default_settings()
+    _, cnt = h.oracle_render(scene, s, W, H, counters=True)
+    out, gcnt = renderer.render_counted(tables_of(scene), s, W, H)
+    assert (gcnt.sceneEvals, gcnt.bulbIters, gcnt.hitPixels) == (cnt.sceneEvals, cnt.bulbIters, cnt.hitPixels)
+
+
+def test_rgba8_flip_and_png(renderer, tmp_path):
+    W, H = 40, 24
+    scene = h.scene_mandelbulb(W, H)
+    s = abi.default_settings(fractalIters=12)
+    frame = renderer.render(tables_of(scene), s, W, H)
+    img = renderer.to_rgba8(frame).cpu().numpy()
+    ref = frame.cpu().numpy()[::-1]
+    exp = (np.clip(ref, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert (img == exp).all()
+    path = tmp_path / "bulb.png"
+    renderer.save_png(frame, path)
+    from PIL import Image
+    assert (np.asarray(Image.open(path)) == img).all()
+
+
+# ---------------------------------------------------------------- full-size, size-independent properties
+def test_full_size_properties_4k_bulb(renderer):
+    """BASELINE.json's size (3840×2160): the oracle cannot finish a 4K frame in seconds, so check
+    (i) determinism, (ii) the scene's mirror symmetry x → −x is NOT assumed (fp32 rounding of rays differs),
+    but row-range renders of arbitrary bands equal the same rows of the full frame bit for bit, and
+    (iii) sampled rows equal the oracle's rows bit for bit."""
+    W, H = 3840, 2160
+    from raymarcher_amd import scenes
+    t = scenes.mandelbulb(W, H)
+    s = abi.default_settings(fractalIters=12)
+    a = renderer.render(t, s, W, H)
+    b = renderer.render(t, s, W, H)
+    assert (a.view(dtype=__import__("torch").int32) == b.view(dtype=__import__("torch").int32)).all()
+    band = renderer.render(t, s, W, H, 1000, 1100)
+    assert (band.view(dtype=__import__("torch").int32) == a[1000:1100].view(dtype=__import__("torch").int32)).all()
+    cam, objs, no, lights, nl, g = t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_
+    for row in (3, 700, 1080, 1501):
+        ref = h.oracle_render((cam, objs, no, lights, nl, g), s, W, H, row, row + 1, threads=16)
+        assert_bit_equal(a[row:row + 1].cpu().numpy(), ref, f"4K row {row}")
+    hit = float((a[..., 0] != 1.0).float().mean())
+    assert 0.25 < hit < 0.40  # ≈0.33 of the pixels hit the bulb
