@@ -219,8 +219,9 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   std::lock_guard<std::mutex> lock(g_mu);
   int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s);
   if (st != RM_OK) return st;
-  if (W <= 0 || H <= 0 || nRows < 0 || !d_rgba) { set_error("bad frame size or null output"); return RM_ERR_INVALID_ARGUMENT; }
-  if (nRows == 0) return RM_OK;
+  if (W <= 0 || H <= 0 || nRows < 0) { set_error("bad frame size"); return RM_ERR_INVALID_ARGUMENT; }
+  if (nRows == 0) return RM_OK;  // empty row range: nothing to write, a null buffer is fine
+  if (!d_rgba) { set_error("null output buffer"); return RM_ERR_INVALID_ARGUMENT; }
   Slot *slot;
   st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot);
   if (st != RM_OK) return st;
