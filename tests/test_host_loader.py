@@ -1,0 +1,139 @@
+"""Host side (scenefile loader + camera) against golden uniform tables produced by the reference's own,
+unmodified loader/camera compiled in the build container (oracle/ref/, oracle/tools/gen_host_goldens.py).
+Inputs are the reference's scenefiles (data) under tests/golden/scenes/.  CPU only: these entry points of
+the C-ABI library do no GPU work."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as h
+from raymarcher_amd import RaymarcherError, abi, lib
+from raymarcher_amd.render import Scene
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLD, "host_tables.json")) as f:
+    TABLES = json.load(f)
+
+OK_SCENES = sorted(k for k, v in TABLES.items() if v.get("ok"))
+BAD_SCENES = sorted(k for k, v in TABLES.items() if not v.get("ok"))
+
+
+def close(a, b, rel=2e-6, abs_=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= abs_ + rel * np.maximum(np.abs(a), np.abs(b)))
+
+
+@pytest.mark.parametrize("rel", OK_SCENES)
+def test_loader_matches_reference_tables(rel):
+    g = TABLES[rel]
+    sc = Scene(path=os.path.join(GOLD, "scenes", rel))
+    ref_objs = g["objects"]
+    # the reference appends one emissive rectangle per area light at render-scene build time
+    # (raymarchscene.cpp:121-133); the golden dump lists parser shapes only
+    n_area = sum(1 for l in g["lights"] if l["type"] == abi.RM_LIGHT_AREA)
+    assert sc.num_objects == len(ref_objs) + n_area
+    assert sc.num_lights == len(g["lights"])
+    objs, lights = lib().rm_scene_objects(sc._h), lib().rm_scene_lights(sc._h)
+    for i, ro in enumerate(ref_objs):
+        o = objs[i]
+        assert o.type == ro["type"]
+        assert close(list(o.invModel), ro["invModel"], rel=2e-5, abs_=2e-6), (rel, i, list(o.invModel), ro["invModel"])
+        assert close(o.scaleFactor, ro["scaleFactor"])
+        for name in ("shininess", "blend", "ior"):
+            assert getattr(o, name) == np.float32(ro[name])
+        for name in ("cAmbient", "cDiffuse", "cSpecular", "cReflective", "cTransparent"):
+            assert list(getattr(o, name)) == [float(np.float32(v)) for v in ro[name]]
+        assert (o.texLoc != -1) == ro["textured"]
+        assert (sc.texture_of(i) is not None) == ro["textured"]
+        if ro["textured"]:
+            assert (o.repeatU, o.repeatV) == (ro["repeatU"], ro["repeatV"])
+        assert o.isEmissive == 0 and o.lightIdx == -1
+    for i in range(n_area):
+        o = objs[len(ref_objs) + i]
+        assert o.type == abi.RM_RECTANGLE and o.isEmissive == 1
+    for i, rl in enumerate(g["lights"]):
+        li = lights[i]
+        assert li.type == rl["type"]
+        assert list(li.color) == [float(np.float32(v)) for v in rl["color"]]
+        assert close(list(li.pos), rl["pos"]) and close(list(li.dir), rl["dir"])
+        assert list(li.func) == [float(np.float32(v)) for v in rl["func"]]
+        assert close(li.angle, rl["angle"], rel=1e-7) and close(li.penumbra, rl["penumbra"], rel=1e-7)
+    gl = abi.RmGlobals()
+    assert lib().rm_scene_globals(sc._h, None, C.byref(gl)) == 0
+    assert (gl.ka, gl.kd, gl.ks) == tuple(float(np.float32(g[k])) for k in ("ka", "kd", "ks"))
+    cd = sc.camera_data()
+    assert close(list(cd.pos), g["camPos"]) and close(list(cd.look), g["camLook"]) and close(list(cd.up), g["camUp"])
+    assert close(cd.heightAngle, g["heightAngle"], rel=1e-7)
+    # camera matrices at both golden sizes
+    for key, cam in g["camera"].items():
+        W, H = map(int, key.split("x"))
+        view, proj, out = (C.c_float * 16)(), (C.c_float * 16)(), abi.RmCamera()
+        assert lib().rm_camera_build(C.byref(cd), W, H, 0.1, 100.0, view, proj, C.byref(out)) == 0
+        assert close(list(view), cam["view"], rel=2e-6, abs_=1e-6)
+        assert close(list(proj), cam["proj"], rel=2e-6, abs_=1e-9)
+        assert close(list(out.invProjView), cam["invProjView"], rel=2e-5, abs_=2e-4), (rel, key)
+        assert out.initialFar == 100.0
+
+
+@pytest.mark.parametrize("rel", BAD_SCENES)
+def test_scenes_the_reference_rejects_are_rejected(rel):
+    with pytest.raises(RaymarcherError) as e:
+        Scene(path=os.path.join(GOLD, "scenes", rel))
+    assert e.value.status == abi.RM_ERR_PARSE
+
+
+def test_bitwise_agreement_rate_with_reference_math():
+    """The loader evaluates the same binary32 expression order as the reference's math library, so almost
+    every matrix word should be IDENTICAL, not just close.  Guard against silent drift."""
+    same = total = 0
+    for rel in OK_SCENES:
+        g = TABLES[rel]
+        sc = Scene(path=os.path.join(GOLD, "scenes", rel))
+        objs = lib().rm_scene_objects(sc._h)
+        for i, ro in enumerate(g["objects"]):
+            a = np.array(list(objs[i].invModel), dtype=np.float32)
+            b = np.array(ro["invModel"], dtype=np.float32)
+            same += int((a == b).sum())
+            total += 16
+    assert same / total > 0.97, f"only {same}/{total} invModel words identical"
+
+
+SCHEMA_ERRORS = {
+    "not json": "{",
+    "root not object": "[1,2]",
+    "missing globalData": '{"cameraData": {"position":[0,0,1],"up":[0,1,0],"heightAngle":30,"look":[0,0,-1]}}',
+    "unknown root key": '{"globalData":{"ambientCoeff":1,"diffuseCoeff":1,"specularCoeff":1},"cameraData":{"position":[0,0,1],"up":[0,1,0],"heightAngle":30,"look":[0,0,-1]},"bogus":1}',
+    "look and focus": '{"globalData":{"ambientCoeff":1,"diffuseCoeff":1,"specularCoeff":1},"cameraData":{"position":[0,0,1],"up":[0,1,0],"heightAngle":30,"look":[0,0,-1],"focus":[0,0,0]}}',
+    "bad primitive type": '{"globalData":{"ambientCoeff":1,"diffuseCoeff":1,"specularCoeff":1},"cameraData":{"position":[0,0,1],"up":[0,1,0],"heightAngle":30,"look":[0,0,-1]},"groups":[{"primitives":[{"type":"terrain"}]}]}',
+    "spot without angle": '{"globalData":{"ambientCoeff":1,"diffuseCoeff":1,"specularCoeff":1},"cameraData":{"position":[0,0,1],"up":[0,1,0],"heightAngle":30,"look":[0,0,-1]},"groups":[{"lights":[{"type":"spot","color":[1,1,1],"direction":[0,-1,0],"penumbra":10,"attenuationCoeff":[1,0,0]}]}]}',
+    "translate wrong arity": '{"globalData":{"ambientCoeff":1,"diffuseCoeff":1,"specularCoeff":1},"cameraData":{"position":[0,0,1],"up":[0,1,0],"heightAngle":30,"look":[0,0,-1]},"groups":[{"translate":[1,2]}]}',
+}
+
+
+@pytest.mark.parametrize("name", list(SCHEMA_ERRORS))
+def test_schema_errors(name):
+    with pytest.raises(RaymarcherError) as e:
+        Scene(text=SCHEMA_ERRORS[name])
+    assert e.value.status == abi.RM_ERR_PARSE
+    assert str(e.value)
+
+
+def test_missing_file_is_io_error():
+    with pytest.raises(RaymarcherError) as e:
+        Scene(path="/nonexistent/dir/scene.json")
+    assert e.value.status == abi.RM_ERR_IO
+
+
+def test_camera_against_independent_numpy_restatement():
+    for (pos, look, up, ang, W, H) in [((0, 0, 4.5), (0, 0, -4.5), (0, 1, 0), 30.0, 3840, 2160),
+                                       ((3, 2, 5), (-3, -1.5, -5), (0.1, 1, 0), 45.0, 1024, 768),
+                                       ((-2, 7, 1), (0.5, -1, 0.2), (0, 0, 1), 60.0, 640, 480)]:
+        from raymarcher_amd.render import build_camera
+        cam, view, proj = build_camera(pos, look, up, np.deg2rad(ang), W, H)
+        v, p, inv = h.camera_numpy(pos, look, up, np.deg2rad(ang), W, H)
+        assert close(view, v.T.reshape(-1), rel=1e-5, abs_=1e-6)
+        assert close(proj, p.T.reshape(-1), rel=1e-5, abs_=1e-8)
+        assert close(list(cam.invProjView), inv.T.reshape(-1), rel=1e-4, abs_=1e-3)
