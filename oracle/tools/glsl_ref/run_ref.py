@@ -1,0 +1,124 @@
+"""Run the (mechanically adapted) reference shader on SwiftShader for one set of uniform tables.
+TEST INFRASTRUCTURE, container-only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import essl_adapt
+import gles
+
+REF = "/root/reference/resources"
+_CTX = None
+
+
+def ctx():
+    global _CTX
+    if _CTX is None:
+        _CTX = gles.Context()
+    return _CTX
+
+
+def build_program(defines, consts, max_objects=6, max_lights=4):
+    c = ctx()
+    vert = open(os.path.join(REF, "raymarch.vert")).read().replace("#version 330 core", "#version 300 es\nprecision highp float;")
+    frag = essl_adapt.adapt(open(os.path.join(REF, "raymarch.frag")).read(), defines, consts, max_objects, max_lights)
+    for _ in range(8):
+        fs, ok, log = c.compile(gles.GL_FRAGMENT_SHADER, frag)
+        if ok:
+            break
+        new, _n = essl_adapt.fix_errors(frag, log)
+        if new == frag:
+            raise RuntimeError("cannot adapt fragment shader:\n" + log[:3000])
+        frag = new
+    else:
+        raise RuntimeError("fragment shader did not converge")
+    vs, ok, log = c.compile(gles.GL_VERTEX_SHADER, vert)
+    if not ok:
+        raise RuntimeError("vertex shader: " + log)
+    prog, ok, log = c.link(vs, fs)
+    if not ok:
+        raise RuntimeError("link: " + log)
+    return prog
+
+
+def set_uniforms(prog, cam, objs, no, lights, nl, g, s):
+    """What configure{Screen,Camera,Shapes,Lights,Settings}Uniforms upload (realtimerender.cpp:596-811)."""
+    gl = ctx().gl
+    gl.glUseProgram(prog)
+
+    def loc(name):
+        return gl.glGetUniformLocation(prog, name.encode())
+
+    def f1(name, v):
+        gl.glUniform1f(loc(name), float(v))
+
+    def i1(name, v):
+        gl.glUniform1i(loc(name), int(v))
+
+    def f3(name, v):
+        gl.glUniform3f(loc(name), float(v[0]), float(v[1]), float(v[2]))
+
+    m = (C.c_float * 16)(*list(cam.invProjView))
+    gl.glUniformMatrix4fv(loc("invProjViewMatrix"), 1, 0, m)
+    f1("initialFar", cam.initialFar)
+    i1("isTwoD", g.isTwoD)
+    f1("iTime", g.iTime)
+    for k in ("ka", "kd", "ks", "kt"):
+        f1(k, getattr(g, k))
+    f1("power", g.power)
+    gl.glUniform2f(loc("juliaSeed"), float(g.juliaSeed[0]), float(g.juliaSeed[1]))
+    i1("numObjects", no)
+    i1("numLights", nl)
+    for i in range(no):
+        o, b = objs[i], f"objects[{i}]."
+        i1(b + "type", o.type)
+        mm = (C.c_float * 16)(*list(o.invModel))
+        gl.glUniformMatrix4fv(loc(b + "invModelMatrix"), 1, 0, mm)
+        for k in ("scaleFactor", "shininess", "blend", "ior", "repeatU", "repeatV"):
+            f1(b + k, getattr(o, k))
+        for k in ("cAmbient", "cDiffuse", "cSpecular", "cReflective", "cTransparent", "color"):
+            f3(b + k, getattr(o, k))
+        i1(b + "texLoc", o.texLoc)
+        i1(b + "isEmissive", o.isEmissive)
+        i1(b + "lightIdx", o.lightIdx)
+    for i in range(nl):
+        li, b = lights[i], f"lights[{i}]."
+        i1(b + "type", li.type)
+        f3(b + "lightColor", li.color)
+        f3(b + "lightDir", li.dir)
+        f3(b + "lightPos", li.pos)
+        f3(b + "lightFunc", li.func)
+        f1(b + "lightAngle", li.angle)
+        f1(b + "lightPenumbra", li.penumbra)
+    i1("enableSoftShadow", s.enableSoftShadow)
+    i1("enableReflection", s.enableReflection)
+    i1("enableRefraction", s.enableRefraction)
+    i1("enableAmbientOcculusion", s.enableAmbientOcclusion)
+    i1("enableSkyBox", 0)
+    # samplers of different types may not share a texture unit: the cubemap goes to the reference's unit 10
+    # (src/realtime.h:17-27); nothing is bound (incomplete textures sample as 0, as in the reference when
+    # a texture file is missing, realtimerender.cpp:405-408).
+    i1("skybox", 10)
+
+
+def render(scene, settings, W, H):
+    """scene = (cam, objs, numObjects, lights, numLights, globals); returns (fragColor, BrightColor) float32 HxWx4,
+    row 0 = bottom (GL read-back order)."""
+    from raymarcher_amd import abi
+    cam, objs, no, lights, nl, g = scene
+    f = settings.features
+    defines = {"SKY_BACKGROUND": bool(f & abi.RM_FEAT_SKY_BACKGROUND), "NIGHTSKY_BACKGROUND": False,
+               "DARK_BACKGROUND": bool(f & abi.RM_FEAT_DARK_BACKGROUND), "WHITE_BACKGROUND": bool(f & abi.RM_FEAT_WHITE_BACKGROUND),
+               "CLOUD": bool(f & abi.RM_FEAT_CLOUD), "TERRAIN": bool(f & abi.RM_FEAT_TERRAIN), "SEA": False,
+               "PERLIN_BUMP": bool(f & abi.RM_FEAT_PERLIN_BUMP)}
+    consts = {"MAX_STEPS": settings.maxSteps, "MAX_STEPS_FRACTALS": settings.fractalIters,
+              "NUM_REFLECTION": settings.numReflection, "MENGER_LEVELS": settings.mengerLevels}
+    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1))
+    c = ctx()
+    c.target(W, H, 2)
+    set_uniforms(prog, cam, objs, no, lights, nl, g, settings)
+    c.draw_fullscreen(prog)
+    err = c.error()
+    assert err == 0, f"GL error {err:#x}"
+    return c.read(W, H, 0).copy(), c.read(W, H, 1).copy()

@@ -1,0 +1,197 @@
+"""Known-answer tests that pin the CPU oracle's restatement of the shader (no GPU).
+
+The reference has no tests or golden vectors, so these are analytic values of the distance
+functions it implements (iquilezles.org SDF definitions at the unit sizes of sdMatch, frag:1262-1293) and
+algebraic properties of the marchers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as h
+from raymarcher_amd import abi
+
+
+def sd(type_, pts, model=None, scale_factor=1.0, settings=None, g=None):
+    objs = (abi.RmObject * 1)(h.make_object(type_, model=model, scale_factor=scale_factor))
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((len(pts), 4), dtype=np.float32)
+    s = settings or abi.default_settings()
+    g = g or h.make_globals()
+    assert h.oracle().rmo_probe_sdscene(objs, 1, C.byref(g), C.byref(s), h.fptr(pts), h.fptr(out), len(pts)) == 0
+    return out
+
+
+def test_sphere_cube_analytic():
+    d = sd(abi.RM_SPHERE, [[1, 0, 0], [0, 0, 0], [0, 2, 0], [0.3, 0.4, 0]])[:, 0]
+    assert np.allclose(d, [0.5, -0.5, 1.5, 0.0], atol=1e-7)  # sdSphere((1,0,0), .5) = .5
+    d = sd(abi.RM_CUBE, [[1, 0, 0], [0, 0, 0], [1.5, 1.5, 0], [0.5, 0.5, 0.5], [1.5, 1.5, 1.5]])[:, 0]
+    assert np.allclose(d, [0.5, -0.5, np.sqrt(2.0), 0.0, np.sqrt(3.0)], atol=1e-6)
+    d = sd(abi.RM_RECTANGLE, [[0, 0, 1], [1, 0, 0], [0, 0, 0]])[:, 0]
+    assert np.allclose(d, [1.0, 0.5, 0.0], atol=1e-7)
+
+
+def test_cylinder_torus_capsule_octahedron_cone_analytic():
+    d = sd(abi.RM_CYLINDER, [[1, 0, 0], [0, 1, 0], [0, 0, 0], [1.5, 1.5, 0]])[:, 0]
+    assert np.allclose(d, [0.5, 0.5, -0.5, np.sqrt(2.0)], atol=1e-6)
+    d = sd(abi.RM_TORUS, [[0.5, 0, 0], [0, 0, 0], [0.5, 1, 0], [1.5, 0, 0]])[:, 0]
+    assert np.allclose(d, [-0.125, 0.375, 0.875, 0.875], atol=1e-6)
+    d = sd(abi.RM_CAPSULE, [[0, 0.25, 0], [0.5, 0.25, 0], [0, 1.0, 0], [0, -0.5, 0]])[:, 0]
+    assert np.allclose(d, [-0.1, 0.4, 0.4, 0.4], atol=1e-6)
+    d = sd(abi.RM_OCTAHEDRON, [[1, 0, 0], [0, 0, 0], [0, -2, 0]])[:, 0]
+    assert np.allclose(d, [0.5, -0.5 * 0.57735027, 1.5], atol=1e-6)
+    d = sd(abi.RM_CONE, [[0, 1.0, 0], [0, -1.0, 0], [2, -0.5, 0]])[:, 0]
+    assert np.allclose(d, [0.5, 0.5, 1.5], atol=1e-6)  # above the apex, below the base disc, beside the base rim
+
+
+def test_deathstar_is_sphere_minus_sphere():
+    # far from the carved side it is the r = .5 sphere
+    d = sd(abi.RM_DEATHSTAR, [[-2, 0, 0], [0, 2, 0]])[:, 0]
+    assert np.allclose(d, [1.5, 1.5], atol=1e-6)
+    # on the +x axis inside the carving sphere (centre x = .5, r = .35) the distance is to that sphere's surface
+    d = sd(abi.RM_DEATHSTAR, [[0.5, 0, 0]])[:, 0]
+    assert np.allclose(d, [0.35], atol=1e-6)
+
+
+def test_object_transform_and_scale_factor():
+    M = h.translate(1, 2, 3) @ h.scale(2, 2, 2)
+    d = sd(abi.RM_SPHERE, [[1, 2, 3], [4, 2, 3], [1, 2, 6]], model=M, scale_factor=2.0)[:, 0]
+    assert np.allclose(d, [-1.0, 2.0, 2.0], atol=1e-6)  # radius-1 sphere at (1,2,3): frag:1417-1419
+
+
+def test_mandelbulb_power8_against_float64_iteration():
+    """Distance estimator of frag:775-803 re-evaluated in float64 with libm trig."""
+    rng = np.random.default_rng(5)
+    pts = rng.normal(0, 0.9, (3000, 3)).astype(np.float32)
+    out = sd(abi.RM_MANDELBULB, pts)
+    P = pts.astype(np.float64)
+    ref = np.empty(len(P))
+    trapy = np.empty(len(P))
+    stable = np.ones(len(P), bool)
+    for n, pos in enumerate(P):
+        w = pos.copy()
+        m = w @ w
+        trap = np.array([abs(w[0]), abs(w[1]), abs(w[2]), m])
+        dz = 1.0
+        for i in range(20):
+            dz = 8.0 * m ** 3.5 * dz + 1.0
+            r = np.sqrt(w @ w)
+            b = 8.0 * np.arccos(w[1] / r)
+            a = 8.0 * np.arctan2(w[0], w[2])
+            w = pos + r ** 8 * np.array([np.sin(b) * np.sin(a), np.cos(b), np.sin(b) * np.cos(a)])
+            trap = np.minimum(trap, np.array([abs(w[0]), abs(w[1]), abs(w[2]), m]))
+            m = w @ w
+            if abs(m - 2.0) < 1e-3:
+                stable[n] = False  # bailout decision within rounding distance
+            if m > 2.0:
+                break
+        ref[n] = 0.25 * np.log(m) * np.sqrt(m) / dz
+        trapy[n] = trap[1]
+    # the orbit is chaotic: errors grow with dz, but the DE divides by dz, so absolute agreement is tight
+    err = np.abs(out[:, 0] - ref)[stable]
+    assert np.percentile(err, 99) < 2e-5 and np.median(err) < 2e-7, (np.percentile(err, 99), np.median(err))
+    assert np.percentile(np.abs(out[:, 2] - trapy)[stable], 95) < 1e-4
+    assert (out[:, 1] == 0).all()
+
+
+def test_menger_levels_and_trap():
+    s = abi.default_settings()
+    # centre of the unit sponge is inside the first cross hole; a corner region is solid
+    out = sd(abi.RM_MENGERSPONGE, [[0, 0, 0], [0.99, 0.99, 0.99], [3, 0, 0]], settings=s)
+    assert out[0, 0] > 0 and out[1, 0] < 0 and np.isclose(out[2, 0], 2.0, atol=1e-6)
+    assert np.isclose(out[0, 3], 0.25)  # trap.z = (1+m)/4 of the first level that carved (frag:1067)
+    deep = sd(abi.RM_MENGERSPONGE, [[0.99, 0.99, 0.99]], settings=abi.default_settings(mengerLevels=5))
+    assert deep[0, 0] >= out[1, 0]  # more levels only remove material
+
+
+def test_sierpinski_and_mandelbrot_prims_are_finite_and_signed():
+    rng = np.random.default_rng(6)
+    pts = rng.uniform(-2, 2, (500, 3)).astype(np.float32)
+    for t in (abi.RM_SIERPINSKI, abi.RM_MANDELBROT):
+        d = sd(t, pts)[:, 0]
+        assert np.isfinite(d).all()
+    assert (sd(abi.RM_SIERPINSKI, [[5, 5, 5]])[:, 0] > 0).all()
+
+
+def test_scene_union_picks_nearest_and_reports_last_fractal_trap():
+    objs = (abi.RmObject * 3)(
+        h.make_object(abi.RM_SPHERE, model=h.translate(-2, 0, 0)),
+        h.make_object(abi.RM_MANDELBULB, model=h.translate(2, 0, 0)),
+        h.make_object(abi.RM_CUBE, model=h.translate(0, 3, 0)))
+    pts = np.array([[-2, 0, 0], [2.0, 0.1, 0.2], [0, 3, 0], [-1.2, 0, 0]], dtype=np.float32)
+    out = np.empty((4, 4), dtype=np.float32)
+    g, s = h.make_globals(), abi.default_settings()
+    assert h.oracle().rmo_probe_sdscene(objs, 3, C.byref(g), C.byref(s), h.fptr(pts), h.fptr(out), 4) == 0
+    assert list(out[:, 1]) == [0, 1, 2, 0]
+    # UB3: the trap belongs to the last fractal evaluated (the bulb), whichever object is nearest
+    assert out[2, 1] == 2 and out[2, 2] > 0 and out[1, 2] > 0
+
+
+def test_march_properties_on_a_sphere():
+    """Primary hit depth (frag:1453-1484): |d| < 1e-3 at the reported point, miss → background."""
+    W = Hh = 33
+    cam = h.make_camera((0, 0, 3), (0, 0, -1), (0, 1, 0), 45.0, W, Hh)
+    objs = (abi.RmObject * 1)(h.make_object(abi.RM_SPHERE, ambient=(1, 1, 1)))
+    scene = (cam, objs, 1, (abi.RmLight * 1)(), 0, h.make_globals(ka=1.0))
+    s = abi.default_settings(features=abi.RM_FEAT_DARK_BACKGROUND)
+    img, br = h.oracle_render(scene, s, W, Hh, bright=True)
+    centre = img[Hh // 2, W // 2]
+    assert np.allclose(centre, [1, 1, 1, 1])  # ambient only: ka·cAmbient = 1
+    assert (img[0, 0] == [0, 0, 0, 1]).all()  # DARK_BACKGROUND miss
+    assert (br[..., :3] == 0).all() and (br[..., 3] == 1).all()  # luminance 1.0 is not > 1 (frag:1940)
+    hit = img[..., 0] > 0
+    # silhouette is a disc of angular radius asin(.5/3): pixel radius ≈ 33/2 · tan(9.59°)/tan(22.5°)
+    assert abs(hit.sum() - np.pi * (16.5 * np.tan(np.arcsin(0.5 / 3)) / np.tan(np.deg2rad(22.5))) ** 2) < 40
+
+
+def test_phong_directional_light_on_a_sphere_centre():
+    W = Hh = 31
+    cam = h.make_camera((0, 0, 3), (0, 0, -1), (0, 1, 0), 30.0, W, Hh)
+    objs = (abi.RmObject * 1)(h.make_object(abi.RM_SPHERE, ambient=(.2, .2, .2), diffuse=(.5, .6, .7), specular=(1, 1, 1), shininess=10))
+    lights = (abi.RmLight * 1)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (0, 0, -1)))
+    scene = (cam, objs, 1, lights, 1, h.make_globals(ka=0.5, kd=0.8, ks=0.3))
+    s = abi.default_settings(features=abi.RM_FEAT_WHITE_BACKGROUND)  # no bump: N = (0,0,1) at the centre
+    img = h.oracle_render(scene, s, W, Hh)
+    c = img[Hh // 2, W // 2, :3]
+    # N·L = 1, R·V = 1: ka·amb + kd·dif + ks·spec (frag:1860-1923)
+    assert np.allclose(c, [0.1 + 0.4 + 0.3, 0.1 + 0.48 + 0.3, 0.1 + 0.56 + 0.3], atol=2e-3)
+
+
+def test_shadow_reflection_refraction_change_the_image_in_the_expected_places():
+    W, Hh = 64, 48
+    import test_gpu_parity as tg
+    scene = tg.reflect_refract_scene(W, Hh)
+    base = h.oracle_render(scene, abi.default_settings(), W, Hh)
+    refl = h.oracle_render(scene, abi.default_settings(enableReflection=1), W, Hh)
+    refr = h.oracle_render(scene, abi.default_settings(enableRefraction=1), W, Hh)
+    assert (refl[..., :3] >= base[..., :3] - 1e-6).all()  # reflection only adds light (frag:2520-2521)
+    assert (refr[..., :3] >= base[..., :3] - 1e-6).all()
+    assert (refl[..., 3] - base[..., 3]).max() == 1.0 and (refr[..., 3] - base[..., 3]).max() == 1.0
+    soft = h.oracle_render(scene, abi.default_settings(enableSoftShadow=1), W, Hh)
+    assert (soft[..., :3] <= base[..., :3] + 1e-6).all()  # penumbra factor ≤ 1 (frag:1711, 1928; UB1)
+    assert np.abs(soft - base).max() > 0.01
+    ao = h.oracle_render(scene, abi.default_settings(enableAmbientOcclusion=1), W, Hh)
+    assert (ao[..., :3] <= base[..., :3] + 1e-6).all()
+
+
+def test_row_range_equals_full_frame_rows_and_is_thread_count_independent():
+    W, Hh = 40, 30
+    scene = h.scene_mandelbulb(W, Hh)
+    s = abi.default_settings(fractalIters=12)
+    full = h.oracle_render(scene, s, W, Hh, threads=8)
+    part = h.oracle_render(scene, s, W, Hh, 7, 19, threads=1)
+    assert (full[7:19].view(np.uint32) == part.view(np.uint32)).all()
+
+
+def test_invalid_inputs_are_rejected():
+    W, Hh = 8, 8
+    cam, objs, no, lights, nl, g = h.scene_mandelbulb(W, Hh)
+    out = np.zeros((Hh, W, 4), dtype=np.float32)
+    s = abi.default_settings(features=abi.RM_FEAT_SEA)
+    st = h.oracle().rmo_render(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(s), W, Hh, 0, Hh, h.fptr(out), None, None, 1)
+    assert st == abi.RM_ERR_UNSUPPORTED
+    s = abi.default_settings()
+    st = h.oracle().rmo_render(C.byref(cam), objs, 31, lights, nl, C.byref(g), C.byref(s), W, Hh, 0, Hh, h.fptr(out), None, None, 1)
+    assert st == abi.RM_ERR_CAPACITY
+    st = h.oracle().rmo_render(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(s), W, Hh, 4, 12, h.fptr(out), None, None, 1)
+    assert st == abi.RM_ERR_INVALID_ARGUMENT

@@ -1,0 +1,156 @@
+"""The rm_math numeric contract as implemented by the CPU oracle: accuracy against float64 libm (so it is a
+legitimate implementation of the GLSL built-ins) and the documented out-of-domain values."""
+import numpy as np
+import pytest
+
+import helpers as h
+from raymarcher_amd import abi
+
+
+def probe(fn, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = None if y is None else np.ascontiguousarray(y, dtype=np.float32)
+    out = np.empty_like(x)
+    assert h.oracle().rmo_probe_math(fn, h.fptr(x), h.fptr(y) if y is not None else None, None, h.fptr(out), x.size) == 0
+    return out
+
+
+def ulp_err(got, exact):
+    exact = np.asarray(exact, dtype=np.float64)
+    ulp = np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - exact) / ulp
+
+
+def test_constants_are_the_documented_bit_patterns():
+    bits = [h.oracle().rmo_const_bits(i) for i in range(7)]
+    assert bits == [0x40490fdb, 0x3fc90fdb, 0xb33bbd2e, 0xa6f72ced, 0x3f22f983, 0x3f317218, 0x3fb8aa3b]
+
+
+def test_sin_cos_accuracy():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-30, 30, 400000), rng.uniform(-0.01, 0.01, 10000)]).astype(np.float32)
+    xd = x.astype(np.float64)
+    for fn, f in ((abi.RM_FN_SIN, np.sin), (abi.RM_FN_COS, np.cos)):
+        got = probe(fn, x)
+        # absolute error near zeros of the function is bounded by the reduction (3-term Cody–Waite)
+        err = np.abs(got.astype(np.float64) - f(xd))
+        assert err.max() < 1.5e-7, err.max()
+        big = np.abs(f(xd)) > 0.1
+        assert ulp_err(got[big], f(xd[big])).max() < 2.0
+    # contract range: |x| >= 2^22 and non-finite inputs collapse to sin = 0, cos = 1
+    bad = np.array([4194304.0, -1e9, np.inf, -np.inf, np.nan], dtype=np.float32)
+    assert (probe(abi.RM_FN_SIN, bad) == 0).all() and (probe(abi.RM_FN_COS, bad) == 1).all()
+    assert abs(probe(abi.RM_FN_SIN, np.array([4194303.0], dtype=np.float32))[0] - np.sin(4194303.0)) < 1e-5
+
+
+def test_acos_accuracy_and_clamping():
+    x = np.linspace(-1, 1, 400001).astype(np.float32)
+    got = probe(abi.RM_FN_ACOS, x)
+    assert ulp_err(got, np.arccos(x.astype(np.float64))).max() < 3.0
+    edge = probe(abi.RM_FN_ACOS, np.array([1.0, -1.0, 1.5, -1.5, np.nan, np.inf], dtype=np.float32))
+    pi = np.float32(3.14159274)
+    assert list(edge) == [0.0, pi, 0.0, pi, pi, 0.0]
+
+
+def test_atan2_accuracy_and_special_cases():
+    rng = np.random.default_rng(1)
+    y, x = rng.normal(0, 1, 400000).astype(np.float32), rng.normal(0, 1, 400000).astype(np.float32)
+    got = probe(abi.RM_FN_ATAN2, y, x)
+    exact = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.abs(got - exact).max() < 4e-7
+    assert ulp_err(got, exact).max() < 4.0
+    sp = probe(abi.RM_FN_ATAN2, np.array([0, 0, -0.0, 1, -1, np.inf], dtype=np.float32),
+               np.array([0, -1, -1, 0, 0, np.inf], dtype=np.float32))
+    pi, h2 = np.float32(3.14159274), np.float32(1.57079637)
+    assert sp[0] == 0 and sp[1] == pi and sp[2] == -pi and sp[3] == h2 and sp[4] == -h2
+    assert abs(sp[5] - np.pi / 4) < 1e-6
+
+
+def test_log2_exp2_pow_accuracy():
+    rng = np.random.default_rng(2)
+    x = np.exp(rng.uniform(-60, 60, 300000)).astype(np.float32)
+    got = probe(abi.RM_FN_LOG2, x)
+    exact = np.log2(x.astype(np.float64))
+    assert np.abs(got - exact).max() < 2e-5  # |log2| up to ~87: absolute error of a few ulp of the result
+    near1 = np.abs(exact) < 0.6
+    assert (np.abs(got[near1] - exact[near1]) < 1.3e-7).all()
+    e = rng.uniform(-120, 120, 300000).astype(np.float32)
+    assert ulp_err(probe(abi.RM_FN_EXP2, e), np.exp2(e.astype(np.float64))).max() < 2.0
+    # pow on the ranges the shader uses: m^3.5, r^8, RdotV^shininess
+    b = rng.uniform(0.01, 4.0, 200000).astype(np.float32)
+    p = rng.choice([3.5, 8.0, 6.0, 2.0, 3.0, 0.9, 1.1, 1.4], 200000).astype(np.float32)
+    gp = probe(abi.RM_FN_POW, b, p)
+    ep = np.power(b.astype(np.float64), p.astype(np.float64))
+    assert (np.abs(gp - ep) / ep).max() < 3e-6
+    c = rng.uniform(0.0, 1.0, 100000).astype(np.float32)
+    gs = probe(abi.RM_FN_POW, c, np.full_like(c, 100.0))
+    assert np.abs(gs - np.power(c.astype(np.float64), 100.0)).max() < 2e-5
+    # documented edges
+    z = probe(abi.RM_FN_LOG2, np.array([0.0, -1.0, 1e-45, np.nan, np.inf, 1.0], dtype=np.float32))
+    assert np.isneginf(z[:4]).all() and z[4] == 128.0 and z[5] == 0.0
+    ez = probe(abi.RM_FN_EXP2, np.array([-125.0, -200.0, np.nan, 128.0, np.inf, 0.0, 127.5], dtype=np.float32))
+    assert list(ez[:3]) == [0, 0, 0] and np.isposinf(ez[3]) and np.isposinf(ez[4]) and ez[5] == 1.0 and np.isposinf(ez[6])
+    assert probe(abi.RM_FN_POW, np.array([0.0], dtype=np.float32), np.array([3.0], dtype=np.float32))[0] == 0.0
+
+
+def test_sqrt_and_division_are_ieee():
+    rng = np.random.default_rng(3)
+    x = np.exp(rng.uniform(-80, 80, 100000)).astype(np.float32)
+    assert (probe(abi.RM_FN_SQRT, x) == np.sqrt(x)).all()
+    y = rng.normal(0, 10, 100000).astype(np.float32)
+    assert (probe(abi.RM_FN_DIV, x, y) == (x / y)).all()
+
+
+def test_pnoise_matches_an_independent_float64_restatement():
+    """Classic Perlin 3-D (frag:1610-1676) re-derived in float64 numpy; the binary32 oracle must agree to 1e-5."""
+    rng = np.random.default_rng(4)
+    P = rng.uniform(-20, 20, (2000, 3))
+    x, y, z = (np.ascontiguousarray(P[:, i], dtype=np.float32) for i in range(3))
+    out = np.empty(2000, dtype=np.float32)
+    assert h.oracle().rmo_probe_math(abi.RM_FN_PNOISE3, h.fptr(x), h.fptr(y), h.fptr(z), h.fptr(out), 2000) == 0
+    P = np.stack([x, y, z], 1).astype(np.float64)
+
+    def permute(v):
+        return np.mod((v * 34.0 + 1.0) * v, 289.0)
+
+    Pi0 = np.floor(P)
+    Pi1 = np.mod(Pi0 + 1.0, 256.0)
+    Pi0 = np.mod(Pi0, 256.0)
+    Pf0 = P - np.floor(P)
+    Pf1 = Pf0 - 1.0
+    res = np.zeros(len(P))
+    fade = lambda t: t * t * t * (t * (t * 6 - 15) + 10)
+    f = fade(Pf0)
+    acc = {}
+    min_gz = np.full(len(P), np.inf)
+    for cx in (0, 1):
+        for cy in (0, 1):
+            for cz in (0, 1):
+                ix = (Pi1 if cx else Pi0)[:, 0]
+                iy = (Pi1 if cy else Pi0)[:, 1]
+                iz = (Pi1 if cz else Pi0)[:, 2]
+                v = permute(permute(permute(ix) + iy) + iz)
+                gx = v / 7.0
+                gy = np.modf(np.floor(gx) / 7.0)[0] - 0.5
+                gx = gx - np.floor(gx)
+                gz = 0.5 - np.abs(gx) - np.abs(gy)
+                sz = (gz <= 0).astype(float)
+                min_gz = np.minimum(min_gz, np.abs(gz))
+                gx = gx - sz * ((gx >= 0).astype(float) - 0.5)
+                gy = gy - sz * ((gy >= 0).astype(float) - 0.5)
+                g = np.stack([gx, gy, gz], 1)
+                g = g * (1.79284291400159 - 0.85373472095314 * (g * g).sum(1))[:, None]
+                off = np.stack([(Pf1 if cx else Pf0)[:, 0], (Pf1 if cy else Pf0)[:, 1], (Pf1 if cz else Pf0)[:, 2]], 1)
+                acc[(cx, cy, cz)] = (g * off).sum(1)
+    mix = lambda a, b, t: a * (1 - t) + b * t
+    nz = {(cx, cy): mix(acc[(cx, cy, 0)], acc[(cx, cy, 1)], f[:, 2]) for cx in (0, 1) for cy in (0, 1)}
+    ny = {cx: mix(nz[(cx, 0)], nz[(cx, 1)], f[:, 1]) for cx in (0, 1)}
+    res = 2.2 * mix(ny[0], ny[1], f[:, 0])
+    # The hash-to-gradient map of this noise (frag:1626-1640) has lattice points where gz = 0.5−|gx|−|gy| is
+    # EXACTLY zero in real arithmetic (k = v mod 7, j = (v div 7) mod 7 with j = k ≤ 3 or j + k = 7, j ≥ 4): there `step(gz, 0)` is decided by
+    # rounding noise and picks one of two entirely different gradients, so the reference itself is
+    # implementation-dependent at those points (≈71 % of evaluations touch one).  The contract makes them
+    # deterministic; an independent float64 restatement can only be compared where every corner is stable.
+    stable = min_gz > 1e-6
+    assert 0.2 < stable.mean() < 0.4  # (42/49)^8 = 0.29: 7 of the 49 (k, j) classes have gz == 0
+    assert np.abs(out - res)[stable].max() < 2e-5
