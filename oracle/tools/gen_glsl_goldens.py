@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/glsl/*.npz: outputs of the REFERENCE SHADER ITSELF (resources/raymarch.frag, adapted
+mechanically to GLSL ES 3.00 in memory — oracle/tools/glsl_ref/essl_adapt.py) executed on the SwiftShader
+software rasteriser of this container.  TEST INFRASTRUCTURE, container-only; the fixtures (inputs = ABI table
+bytes, outputs = float32 arrays) are what travels.  Run:  python oracle/tools/gen_glsl_goldens.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "tools", "glsl_ref"))
+
+import helpers as h  # noqa: E402
+import run_ref  # noqa: E402
+import test_gpu_parity as tg  # noqa: E402
+from raymarcher_amd import abi  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "glsl")
+
+
+def subset(sc, idx):
+    cam, objs, no, lights, nl, g = sc
+    o = (abi.RmObject * len(idx))(*[objs[i] for i in idx])
+    return cam, o, len(idx), lights, nl, g
+
+
+def pack(scene, settings):
+    cam, objs, no, lights, nl, g = scene
+    raw = lambda x: np.frombuffer(bytes(x), dtype=np.uint8)
+    return dict(cam=raw(cam), objs=raw(objs), num_objects=no, lights=raw(lights), num_lights=nl, globals=raw(g),
+                settings=raw(settings))
+
+
+def frame_case(name, scene, settings, W, H):
+    rgba, bright = run_ref.render(scene, settings, W, H)
+    np.savez_compressed(os.path.join(OUT, f"frame_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, **pack(scene, settings))
+    print("frame", name, rgba.shape, float(np.nanmax(rgba)))
+
+
+def probe_case(name, kind, scene, settings, pts):
+    out = run_ref.probe(kind, scene, settings, pts)
+    np.savez_compressed(os.path.join(OUT, f"probe_{name}.npz"), kind=kind, pts=np.asarray(pts, dtype=np.float32), out=out,
+                        **pack(scene, settings))
+    print("probe", name, out.shape)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    W, H = 64, 48
+    WB, DB = abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND
+    prims = tg.all_primitives_scene(W, H)
+    frame_case("prims_a_phong", subset(prims, range(0, 6)), abi.default_settings(features=WB), W, H)
+    frame_case("prims_b_phong", subset(prims, [6, 7, 8, 9]), abi.default_settings(features=WB, maxSteps=128), W, H)
+    frame_case("prims_a_bump", subset(prims, range(0, 6)), abi.default_settings(), W, H)
+    frame_case("prims_ao", subset(prims, [0, 2, 4, 6, 8, 9]), abi.default_settings(features=DB, enableAmbientOcclusion=1), W, H)
+    frame_case("reflect_refract", tg.reflect_refract_scene(W, H),
+               abi.default_settings(features=WB, enableReflection=1, enableRefraction=1), W, H)
+    frame_case("menger_reflect", tg.menger_scene(W, H), abi.default_settings(features=WB, enableReflection=1), W, H)
+    frame_case("bulb_reference_consts", h.scene_mandelbulb(96, 54), abi.default_settings(), 96, 54)
+    frame_case("bulb_12iters_nobump", h.scene_mandelbulb(96, 54), abi.default_settings(features=WB, fractalIters=12), 96, 54)
+    two_d = h.scene_mandelbulb(W, H)[:5] + (h.make_globals(two_d=1, itime=3.0),)
+    frame_case("mandelbrot_2d", two_d, abi.default_settings(), W, H)
+    # function-level probes
+    rng = np.random.default_rng(42)
+    s = abi.default_settings()
+    bulb = h.scene_mandelbulb(8, 8)
+    probe_case("sd_bulb_p8", "sdscene", bulb, s, rng.normal(0, 0.8, (4096, 3)))
+    probe_case("sd_bulb_p8_12iters", "sdscene", bulb, abi.default_settings(fractalIters=12), rng.normal(0, 0.8, (2048, 3)))
+    julia = bulb[:5] + (h.make_globals(julia=(0.35, -0.2), power=6.0),)
+    probe_case("sd_julia_p6", "sdscene", julia, s, rng.normal(0, 0.8, (2048, 3)))
+    probe_case("sd_menger", "sdscene", tg.menger_scene(8, 8), s, rng.uniform(-1.5, 1.5, (4096, 3)))
+    pts = rng.uniform(-3.5, 3.5, (4096, 3))
+    pts[:, 2] *= 0.4
+    probe_case("sd_prims_a", "sdscene", subset(prims, range(0, 6)), s, pts)
+    probe_case("sd_prims_b", "sdscene", subset(prims, [6, 7, 8, 9]), s, pts)
+    probe_case("pnoise", "pnoise", bulb, s, rng.uniform(-40, 40, (8192, 3)))
+    probe_case("normal_prims_a", "normal", subset(prims, range(0, 6)), s, pts[:2048])
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,12 @@ Edits (all mechanical):
   E5 struct array sizes reduced to fit SwiftShader's 261 fragment uniform vectors
   E6 outputs routed through floatBitsToUint into RGBA32UI attachments for exact read-back
   E7 `#define` feature lines switched on/off per test case; loop-bound constants set per test case
+  E8 partial evaluation against the test case's uniform values, so that SwiftShader (which inlines every call
+     into one function and needs tens of minutes for the full shader) only compiles code that can execute:
+     option uniforms that are false in the case (`enableReflection`, `enableRefraction`,
+     `enableAmbientOcculusion`, `enableSkyBox`, `isTwoD`) become the literal `false` in `if` conditions; the
+     area-light test `li.type == AREA` becomes `false` when the scene has no area light; `sdMatch` branches
+     of primitive types that do not occur in the scene are removed.  Executed arithmetic is unchanged.
 """
 import re
 
@@ -38,7 +44,43 @@ def floatify(line):
     return out + sep + comment
 
 
-def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4):
+def specialise(text, false_uniforms=(), present_types=None, has_area_light=False):
+    """E8 — see module docstring."""
+    for u in false_uniforms:
+        text = re.sub(r"\bif\s*\(\s*" + u + r"\b", "if (false", text)
+    if not has_area_light:
+        text = re.sub(r"li\.type\s*==\s*AREA", "false", text)
+    if present_types is not None:
+        # sdMatch: `if (type == NAME) {` / `} else if (type == NAME) {` + one `return …;` line each (frag:1262-1293)
+        lines = text.split("\n")
+        out, i = [], 0
+        names = ["CUBE", "CONE", "CYLINDER", "SPHERE", "OCTAHEDRON", "TORUS", "CAPSULE", "DEATHSTAR", "RECTANGLE",
+                 "MANDELBROT", "MANDELBULB", "MENGERSPONGE", "SIERPINSKI", "CUSTOM"]
+        while i < len(lines):
+            m = re.match(r"^(\s*)(\}\s*else\s+)?if\s*\(\s*type\s*==\s*(\w+)\s*\)\s*\{\s*$", lines[i])
+            if m and m.group(3) in names and names.index(m.group(3)) not in present_types \
+                    and i + 1 < len(lines) and re.match(r"^\s*return\s+sd\w+\(", lines[i + 1]):
+                out.append(f"{m.group(1)}{m.group(2) or ''}if (false) {{")
+                out.append(f"{m.group(1)}    return 0.0;")
+                i += 2
+                continue
+            out.append(lines[i])
+            i += 1
+        text = "\n".join(out)
+    return text
+
+
+PROBE_MAIN = {
+    # harness-only entry points appended after the reference's functions: evaluate ONE reference function at
+    # points fetched from a float texture, so function-level values can be cross-checked (the reference's
+    # own main() only exposes final colours).
+    "sdscene": "SceneMin m = sdScene(q.xyz); fragColor = vec4(m.minD, float(m.minObjIdx), m.trap.y, m.trap.z);",
+    "pnoise": "fragColor = vec4(pnoise(q.xyz), 0.0, 0.0, 0.0);",
+    "normal": "fragColor = vec4(getNormal(q.xyz), 0.0);",
+}
+
+
+def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4, probe=None):
     """Return ESSL 3.00 source.  `defines`: {name: bool} for the #define block (frag:4-15);
     `consts`: {MAX_STEPS: n, MAX_STEPS_FRACTALS: n, NUM_REFLECTION: n, MENGER_LEVELS: n}."""
     defines = defines or {}
@@ -71,7 +113,12 @@ def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4):
     text = re.sub(r"layout\s*\(location\s*=\s*0\)\s*out\s+vec4\s+fragColor;", "vec4 fragColor;\nlayout(location = 0) out uvec4 fragBits;", text)
     text = re.sub(r"layout\s*\(location\s*=\s*1\)\s*out\s+vec4\s+BrightColor;", "vec4 BrightColor;\nlayout(location = 1) out uvec4 brightBits;", text)
     text = re.sub(r"void\s+main\s*\(\s*\)", "void main_ref()", text)
-    text += ("\nvoid main() {\n  fragColor = vec4(0.0); BrightColor = vec4(0.0, 0.0, 0.0, 1.0);\n  main_ref();\n"
+    if probe is None:
+        body = "  main_ref();\n"
+    else:
+        text += "\nuniform highp sampler2D probePts;\n"
+        body = "  vec4 q = texelFetch(probePts, ivec2(gl_FragCoord.xy), 0);\n  " + PROBE_MAIN[probe] + "\n"
+    text += ("\nvoid main() {\n  fragColor = vec4(0.0); BrightColor = vec4(0.0, 0.0, 0.0, 1.0);\n" + body +
              "  fragBits = floatBitsToUint(fragColor);\n  brightBits = floatBitsToUint(BrightColor);\n}\n")
     return text
 

@@ -19,10 +19,12 @@ def ctx():
     return _CTX
 
 
-def build_program(defines, consts, max_objects=6, max_lights=4):
+def build_program(defines, consts, max_objects=6, max_lights=4, spec=None, probe=None):
     c = ctx()
     vert = open(os.path.join(REF, "raymarch.vert")).read().replace("#version 330 core", "#version 300 es\nprecision highp float;")
-    frag = essl_adapt.adapt(open(os.path.join(REF, "raymarch.frag")).read(), defines, consts, max_objects, max_lights)
+    frag = essl_adapt.adapt(open(os.path.join(REF, "raymarch.frag")).read(), defines, consts, max_objects, max_lights, probe)
+    if spec is not None:
+        frag = essl_adapt.specialise(frag, **spec)
     for _ in range(8):
         fs, ok, log = c.compile(gles.GL_FRAGMENT_SHADER, frag)
         if ok:
@@ -114,7 +116,18 @@ def render(scene, settings, W, H):
                "PERLIN_BUMP": bool(f & abi.RM_FEAT_PERLIN_BUMP)}
     consts = {"MAX_STEPS": settings.maxSteps, "MAX_STEPS_FRACTALS": settings.fractalIters,
               "NUM_REFLECTION": settings.numReflection, "MENGER_LEVELS": settings.mengerLevels}
-    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1))
+    false_u = ["enableSkyBox"]
+    if not settings.enableReflection:
+        false_u.append("enableReflection")
+    if not settings.enableRefraction:
+        false_u.append("enableRefraction")
+    if not settings.enableAmbientOcclusion:
+        false_u.append("enableAmbientOcculusion")
+    if not g.isTwoD:
+        false_u.append("isTwoD")
+    spec = {"false_uniforms": false_u, "present_types": sorted({objs[i].type for i in range(no)}),
+            "has_area_light": any(lights[i].type == abi.RM_LIGHT_AREA for i in range(nl))}
+    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec)
     c = ctx()
     c.target(W, H, 2)
     set_uniforms(prog, cam, objs, no, lights, nl, g, settings)
@@ -122,3 +135,38 @@ def render(scene, settings, W, H):
     err = c.error()
     assert err == 0, f"GL error {err:#x}"
     return c.read(W, H, 0).copy(), c.read(W, H, 1).copy()
+
+
+def probe(kind, scene, settings, pts):
+    """Evaluate one reference function ('sdscene' | 'pnoise' | 'normal') at pts (N,3) → (N,4) float32."""
+    from raymarcher_amd import abi
+    cam, objs, no, lights, nl, g = scene
+    pts = np.asarray(pts, dtype=np.float32)
+    n = len(pts)
+    W = 64
+    H = (n + W - 1) // W
+    tex_data = np.zeros((H * W, 4), dtype=np.float32)
+    tex_data[:n, :3] = pts
+    consts = {"MAX_STEPS": settings.maxSteps, "MAX_STEPS_FRACTALS": settings.fractalIters,
+              "NUM_REFLECTION": settings.numReflection, "MENGER_LEVELS": settings.mengerLevels}
+    spec = {"false_uniforms": ["enableSkyBox", "enableReflection", "enableRefraction", "enableAmbientOcculusion", "isTwoD"],
+            "present_types": sorted({objs[i].type for i in range(no)}), "has_area_light": False}
+    prog = build_program({}, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec, probe=kind)
+    c = ctx()
+    gl = c.gl
+    c.target(W, H, 2)
+    set_uniforms(prog, cam, objs, no, lights, nl, g, settings)
+    tex = C.c_uint()
+    gl.glGenTextures(1, C.byref(tex))
+    gl.glActiveTexture(0x84C0 + 1)
+    gl.glBindTexture(gles.GL_TEXTURE_2D, tex)
+    gl.glTexImage2D(gles.GL_TEXTURE_2D, 0, 0x8814, W, H, 0, 0x1908, gles.GL_FLOAT, tex_data.ctypes.data_as(C.c_void_p))
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, gles.GL_TEXTURE_MIN_FILTER, gles.GL_NEAREST)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, gles.GL_TEXTURE_MAG_FILTER, gles.GL_NEAREST)
+    gl.glUniform1i(gl.glGetUniformLocation(prog, b"probePts"), 1)
+    c.draw_fullscreen(prog)
+    err = c.error()
+    assert err == 0, f"GL error {err:#x}"
+    out = c.read(W, H, 0).reshape(-1, 4)[:n].copy()
+    gl.glActiveTexture(0x84C0)
+    return out
