@@ -130,7 +130,8 @@ def main():
     dt = time.perf_counter() - t0
     import ctypes as C
     kms, kn = C.c_double(), C.c_int()
-    L.rm_get_timing(C.byref(kms), C.byref(kn))
+    stages = (C.c_double * 4)()
+    L.rm_get_stage_timing(C.byref(kms), stages, C.byref(kn))
     L.rm_set_timing(0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=r.device)
     kmax = torch.tensor([kms.value], dtype=torch.float64, device=r.device)
@@ -162,7 +163,11 @@ def main():
                        "parity": "bit-exact vs CPU oracle (rm_math contract)"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "kernel": "rm::render_kernel<bulb>", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "Mandelbulb pipeline: rm::bulb_primary_kernel + bulb_surface_kernel + "
+                                   "bulb_shadow_kernel + bulb_shade_kernel (one rm_render launch)",
+                         "kernel_ms": round(kernel_ms, 4),
+                         "stage_ms": {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
+                                      "shadow": round(stages[2], 4), "shade": round(stages[3], 4)},
                          "algorithmic": {"flop_per_launch": flops_launch, "sceneEvals": cnt.sceneEvals,
                                          "bulbIters": cnt.bulbIters, "hitPixels": cnt.hitPixels},
                          "hbm": {"achieved": round(bytes_launch / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,

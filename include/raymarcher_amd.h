@@ -13,8 +13,10 @@
  *  - output frames are row-major float RGBA, **row 0 = bottom of the image** (GL convention,
  *    frag:2572-2574); rm_frame_to_rgba8() applies the vertical flip of Realtime::saveViewportImage
  *    (src/realtime.cpp:337-338);
- *  - d_* pointers are DEVICE pointers owned by the caller (hipMalloc / torch tensor storage); the
- *    launcher never allocates or frees in the render call and never synchronises the stream;
+ *  - d_* pointers are DEVICE pointers owned by the caller (hipMalloc / torch tensor storage); render calls are
+ *    asynchronous on the caller's stream.  The library keeps a small per-device scene ring and, for the
+ *    Mandelbulb pipeline, a grow-only workspace (≤ 52 B/pixel + 8 B per pixel·light) that is (re)allocated —
+ *    with a stream synchronise — only when a larger frame than any before is rendered;
  *  - every function returns an rm_status; no exception crosses this boundary (the reference throws
  *    std::runtime_error on shader failure, src/utils/shaderloader.h:39,83, and prints + returns on
  *    scene errors, src/raymarch/raymarchscene.cpp:111).
@@ -198,6 +200,12 @@ int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects,
  * stream when profiling is switched on with rm_set_timing(1); resets the accumulator. */
 int rm_set_timing(int on);
 int rm_get_timing(double *avgKernelMs, int *launches);
+/* Same, split by pipeline stage.  The single-Mandelbulb scene class renders as four kernels (primary march,
+ * surface/normals, shadow marches, shading: stage 0..3); every other scene is one kernel (stage 0). */
+int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches);
+/* 1 = always use the one-lane-per-pixel kernel, 0 = pick the fastest path for the scene class (default).
+ * Both paths produce identical bits; the switch exists for A/B measurement and tests. */
+int rm_set_kernel_path(int forceGeneric);
 
 /*
  * rm_frame_to_rgba8 — clamp→×255→round and vertical flip, the read-back of

@@ -1,0 +1,343 @@
+// rm_bulb_pipeline.hip.h — the single-Mandelbulb scene class as a wavefront pipeline of four kernels.
+//
+// Why: in the one-lane-per-pixel kernel (rm::render_kernel) a wave runs max-over-lanes of every nested loop
+// (march steps × Mandelbulb iterations, then normals, then one shadow march per light); on the north-star
+// frame only ≈27 % of the issued lane-slots did useful work.  Here the same per-pixel arithmetic (bit for
+// bit — every formula is shared with rm_device.hip.h) is regrouped so that each kernel has one kind of work:
+//
+//   K1 bulb_primary_kernel  primary rays.  Persistent waves; each lane is a small state machine whose loop
+//                           body is ONE Mandelbulb iteration (frag:786-798), so lanes at different march
+//                           steps / iteration counts never wait for each other.  Lanes whose ray ended park;
+//                           when ≥16 are parked (__ballot/popcount) the wave flushes them — misses store the
+//                           background, hits are appended to a compact hit list (one wave-aggregated atomic) —
+//                           and refills them with the next pixels (one atomic on the pixel cursor).
+//   K2 bulb_surface_kernel  one lane per HIT (dense waves): hit point, 4-tap normal, Perlin bump, AO.
+//   K3 bulb_shadow_kernel   one lane per (hit, light) shadow ray, same iteration-level state machine and
+//                           refill as K1.  Rays of lights with N·L <= 0.005 are not marched: getPhong
+//                           discards their result (frag:1908-1912), so the frame is unchanged.
+//   K4 bulb_shade_kernel    one lane per hit: Phong sum in light order, orbit-trap colour, float4 store.
+//
+// Intermediate records live in a per-device workspace in HBM (≤ 52 B per pixel + 8 B per shadow ray; a few
+// hundred MB of traffic per 4K frame ≈ 0.1 ms at HBM speed).  Wave-coherent 8×8 pixel tiles are still the unit
+// in which pixels are handed out (tile-major pixel cursor), so neighbouring lanes start on neighbouring rays.
+#pragma once
+#include "rm_device.hip.h"
+
+namespace rm {
+
+struct RowMap {
+  int rowBegin, tileRows, shard, numShards;
+  __host__ __device__ int frameRow(int r) const {
+    return rowBegin + ((r / tileRows) * numShards + shard) * tileRows + (r % tileRows);
+  }
+};
+
+// Device workspace of the pipeline (pointers into one allocation owned by the launcher).
+struct BulbWs {
+  uint32_t *counters;  // [0] pixel cursor, [1] number of hits, [2] shadow-ray cursor
+  int *hitPix;         // packed output index r·W + x of each hit
+  float4 *hitRec;      // (depth res.d, trap.y, trap.z, trap.w)           frag:1477, 800
+  float4 *surfP;       // (p.xyz, ao)
+  float4 *surfN;       // (bumped normal, unused)
+  int2 *shadow;        // per ray [light·nHits + hit]: (intersectObj or -1, bits of the penumbra factor)
+};
+
+constexpr int kFlushThreshold = 16;
+
+RM_DEV unsigned long long laneMaskLt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// ---- Mandelbulb distance estimator as a resumable state (frag:775-803) ---------------------------------------
+struct BulbDE {
+  V3 w, c;
+  float dz, m, ty, tz, tw;
+  int it;
+};
+struct BulbParams {  // wave-uniform
+  float power, pexp, jx, jy, scale;
+  int iters;
+  bool julia;
+};
+RM_DEV BulbParams bulbParams(const SceneBlock *sb) {
+  BulbParams k;
+  k.power = sb->g.power;
+  k.pexp = (k.power - 1.0f) / 2.0f;
+  k.jx = sb->g.juliaSeed[0];
+  k.jy = sb->g.juliaSeed[1];
+  k.julia = len2(k.jx, k.jy) != 0.0f;
+  k.iters = sb->s.fractalIters;
+  k.scale = sb->objs[0].scaleFactor;
+  return k;
+}
+RM_DEV void deStart(BulbDE &s, const SceneBlock *sb, const BulbParams &k, V3 p) {
+  const float *M = sb->objs[0].invModel;
+  V3 po = v3(fma(M[8], p.z, fma(M[4], p.y, fma(M[0], p.x, M[12]))), fma(M[9], p.z, fma(M[5], p.y, fma(M[1], p.x, M[13]))),
+             fma(M[10], p.z, fma(M[6], p.y, fma(M[2], p.x, M[14]))));  // frag:1417
+  s.w = po;
+  s.m = dot(po, po);
+  s.ty = fabs_(po.y); s.tz = fabs_(po.z); s.tw = s.m;  // trap = vec4(abs(w), m), frag:778 (trap.x is never read)
+  s.dz = 1.0f;
+  s.c = k.julia ? v3(k.jx, k.jy, 0.0f) : po;
+  s.it = 0;
+}
+// One iteration of frag:786-798; true when the loop ends (bailout or iteration cap).
+RM_DEV bool deStep(BulbDE &s, const BulbParams &k) {
+  s.dz = fma(k.power * pow_(s.m, k.pexp), s.dz, 1.0f);
+  float r = sqrt_(s.m);
+  float b = k.power * acos_(s.w.y / r);
+  float a = k.power * atan2_(s.w.x, s.w.z);
+  float pr = pow_(r, k.power);
+  float sb_, cb_, sa_, ca_;
+  sincos_(b, sb_, cb_);
+  sincos_(a, sa_, ca_);
+  s.w = v3(fma(pr, sb_ * sa_, s.c.x), fma(pr, cb_, s.c.y), fma(pr, sb_ * ca_, s.c.z));
+  s.ty = min_(s.ty, fabs_(s.w.y));
+  s.tz = min_(s.tz, fabs_(s.w.z));
+  s.tw = min_(s.tw, s.m);
+  s.m = dot(s.w, s.w);
+  s.it++;
+  return (s.m > 2.0f) || (s.it >= k.iters);
+}
+// frag:802 then sdScene's scale and nearest-object select (frag:1419-1423) for a one-object table.
+RM_DEV float deDistance(const BulbDE &s, const BulbParams &k) {
+  float d = ((0.25f * log_(s.m)) * sqrt_(s.m)) / s.dz;
+  float cur = d * k.scale;
+  return (cur < 1000000.0f) ? cur : 1000000.0f;
+}
+
+// Pixel handed out by the tile-major cursor: 64 consecutive indices = one 8×8 tile.
+RM_DEV bool decodePixel(uint32_t idx, int tilesX, int W, int nRows, int &x, int &r) {
+  uint32_t tile = idx >> 6, l = idx & 63u;
+  x = (int)(tile % (uint32_t)tilesX) * 8 + (int)(l & 7u);
+  r = (int)(tile / (uint32_t)tilesX) * 8 + (int)(l >> 3);
+  return x < W && r < nRows;
+}
+
+enum { ST_NEED = 0, ST_MARCH = 1, ST_HIT = 2, ST_MISS = 3, ST_DONE = 4 };
+
+// ---- K1 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                            int nRows, float4 *__restrict__ out,
+                                                            float4 *__restrict__ bright, BulbWs ws) {
+  const int tilesX = (W + 7) >> 3, tilesY = (nRows + 7) >> 3;
+  const uint32_t totalIdx = (uint32_t)tilesX * (uint32_t)tilesY * 64u;
+  const BulbParams k = bulbParams(sb);
+  const int maxSteps = sb->s.maxSteps;
+  const float far = sb->cam.initialFar;
+  const V3 bg = backgroundColor(sb);
+  const unsigned long long lt = laneMaskLt();
+
+  int st = ST_NEED, pix = -1, steps = 0;
+  V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
+  float t = 0.0f, hitD = 0.0f;
+  BulbDE de{};
+
+  for (;;) {
+    const unsigned long long mMarch = __ballot(st == ST_MARCH);
+    const unsigned long long mWait = __ballot(st == ST_NEED || st == ST_HIT || st == ST_MISS);
+    if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= kFlushThreshold)) {
+      // ---- flush: write results of parked lanes, then refill every waiting lane ----
+      if (st == ST_MISS) {  // frag:2325, 2465
+        out[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
+        if (bright) bright[pix] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+      }
+      const unsigned long long mHit = __ballot(st == ST_HIT);
+      if (mHit) {
+        const int first = __ffsll((long long)mHit) - 1;
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ws.counters[1], (uint32_t)__popcll(mHit));
+        base = __shfl(base, first);
+        if (st == ST_HIT) {
+          const uint32_t slot = base + (uint32_t)__popcll(mHit & lt);
+          ws.hitPix[slot] = pix;
+          ws.hitRec[slot] = make_float4(hitD, de.ty, de.tz, de.tw);
+        }
+      }
+      {
+        const int first = __ffsll((long long)mWait) - 1;
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ws.counters[0], (uint32_t)__popcll(mWait));
+        base = __shfl(base, first);
+        if (st != ST_MARCH && st != ST_DONE) {
+          const uint32_t idx = base + (uint32_t)__popcll(mWait & lt);
+          int x, r;
+          if (idx >= totalIdx) {
+            st = ST_DONE;
+          } else if (!decodePixel(idx, tilesX, W, nRows, x, r)) {
+            st = ST_NEED;  // padding lane of an edge tile: ask again at the next flush
+          } else {
+            pix = r * W + x;
+            float ndcx, ndcy;
+            pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+            primaryRay(sb, ndcx, ndcy, ro, rd);
+            t = 0.0f;
+            steps = 0;
+            deStart(de, sb, k, madd(rd, t, ro));
+            st = ST_MARCH;
+          }
+        }
+      }
+      continue;
+    }
+    if (mMarch == 0) break;  // nothing marching, nothing waiting: every lane is DONE
+    if (st == ST_MARCH) {
+      if (deStep(de, k)) {  // this lane's sdScene evaluation is complete → one step of frag:1459-1470
+        const float d = deDistance(de, k);
+        const bool hit = fabs_(d) < kSurfaceDist;
+        if (hit || t > far) {
+          hitD = t - d;  // frag:1477
+          st = hit ? ST_HIT : ST_MISS;
+        } else {
+          t = fma(d, 1.0f, t);
+          steps++;
+          if (steps >= maxSteps) st = ST_MISS;
+          else deStart(de, sb, k, madd(rd, t, ro));
+        }
+      }
+    }
+  }
+}
+
+// ---- K2 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bulb_surface_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                            BulbWs ws) {
+  const uint32_t nHits = ws.counters[1];
+  Counters cnt{0, 0};
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
+    const int pix = ws.hitPix[h];
+    const float4 rec = ws.hitRec[h];
+    const int r = pix / W, x = pix - r * W;
+    float ndcx, ndcy;
+    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+    V3 ro, rd;
+    primaryRay(sb, ndcx, ndcy, ro, rd);
+    const V3 p = madd(rd, rec.x, ro);                    // frag:2333
+    V3 n = getNormal<true, false>(sb, p, cnt);           // frag:1436-1444
+    if (sb->s.features & RM_FEAT_PERLIN_BUMP) n = bumpNormal(n, p);  // frag:2334-2336
+    float ao = 1.0f;
+    if (sb->s.enableAmbientOcclusion) ao = calcAO<true, false>(sb, p, n, cnt);  // frag:1859
+    ws.surfP[h] = make_float4(p.x, p.y, p.z, ao);
+    ws.surfN[h] = make_float4(n.x, n.y, n.z, 0.0f);
+  }
+}
+
+// ---- K3 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__restrict__ sb, BulbWs ws) {
+  const uint32_t nHits = ws.counters[1];
+  const uint32_t nl = (uint32_t)sb->numLights;
+  const uint32_t totalRays = nHits * nl;
+  const BulbParams k = bulbParams(sb);
+  const int maxSteps = sb->s.maxSteps;
+  const float far = sb->cam.initialFar;
+  const unsigned long long lt = laneMaskLt();
+
+  int st = ST_NEED, steps = 0;
+  uint32_t ray = 0;
+  V3 so = v3(0, 0, 0), L = v3(0, 0, 0);
+  float t = 0.0f, maxT = 0.0f, pen = 1.0f;
+  BulbDE de{};
+
+  for (;;) {
+    const unsigned long long mMarch = __ballot(st == ST_MARCH);
+    const unsigned long long mWait = __ballot(st == ST_NEED);
+    if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= kFlushThreshold)) {
+      const int first = __ffsll((long long)mWait) - 1;
+      uint32_t base = 0;
+      if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ws.counters[2], (uint32_t)__popcll(mWait));
+      base = __shfl(base, first);
+      if (st == ST_NEED) {
+        ray = base + (uint32_t)__popcll(mWait & lt);
+        if (ray >= totalRays) {
+          st = ST_DONE;
+        } else {
+          const uint32_t li = ray / nHits, h = ray - li * nHits;  // light-major: a wave marches toward one light
+          const float4 P = ws.surfP[h], Nn = ws.surfN[h];
+          const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
+          // li differs across a wave only at the boundary between two lights' ray ranges → per-lane table read
+          const LightGeom g = lightSetup(sb->lights[li], p, far);
+          if (dot(N, g.L) <= 0.005f) {
+            // getPhong skips this light whatever the shadow march returns (frag:1912): do not march.
+            ws.shadow[ray] = make_int2(-1, (int)f2u(1.0f));
+            st = ST_NEED;
+          } else {
+            so = shadowOrigin(p, N);
+            L = g.L;
+            maxT = g.maxT;
+            t = 0.0f;
+            pen = 1.0f;
+            steps = 0;
+            deStart(de, sb, k, madd(L, t, so));
+            st = ST_MARCH;
+          }
+        }
+      }
+      continue;
+    }
+    if (mMarch == 0) break;
+    if (st == ST_MARCH) {
+      if (deStep(de, k)) {  // one step of softshadow, frag:1708-1714
+        const float d = deDistance(de, k);
+        const bool hit = fabs_(d) < kSurfaceDist;
+        bool end = hit || t > maxT;
+        if (!end) {
+          pen = min_(pen, (8.0f * d) / t);
+          t = t + fabs_(d);
+          steps++;
+          if (steps >= maxSteps) end = true;
+          else deStart(de, sb, k, madd(L, t, so));
+        }
+        if (end) {
+          ws.shadow[ray] = make_int2(hit ? 0 : -1, (int)f2u(pen));
+          st = ST_NEED;
+        }
+      }
+    }
+  }
+}
+
+// ---- K4 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bulb_shade_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                          float4 *__restrict__ out, float4 *__restrict__ bright,
+                                                          BulbWs ws) {
+  const uint32_t nHits = ws.counters[1];
+  const int nl = sb->numLights;
+  const float ka = sb->g.ka, kd = sb->g.kd, ks = sb->g.ks;
+  const float far = sb->cam.initialFar;
+  const bool soft = sb->s.enableSoftShadow != 0;
+  const RmObject &o = sb->objs[0];
+  Material mat;
+  mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
+  mat.dif = v3(o.cDiffuse[0], o.cDiffuse[1], o.cDiffuse[2]);
+  mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
+  mat.shininess = o.shininess;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
+    const int pix = ws.hitPix[h];
+    const float4 rec = ws.hitRec[h], P = ws.surfP[h], Nn = ws.surfN[h];
+    const int r = pix / W, x = pix - r * W;
+    float ndcx, ndcy;
+    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+    V3 ro, rd;
+    primaryRay(sb, ndcx, ndcy, ro, rd);
+    const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
+    const float ao = P.w;
+    V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);  // frag:1860
+    const V3 V = normalize(neg(rd));
+    for (int i = 0; i < nl; i++) {
+      const RmLight &li = sb->lights[i];
+      const LightGeom g = lightSetup(li, p, far);
+      const int2 sh = ws.shadow[(uint32_t)i * nHits + h];
+      V3 cur;
+      if (lightTerm(li, g, mat, N, V, kd, ks, sh.x, u2f((uint32_t)sh.y), soft, cur)) total = add(total, cur);
+    }
+    const V3 c = bulbTrapColor(rec.y, rec.z, rec.w);  // frag:2356-2360
+    const V3 col = v3(c.x * (total.x * 8.0f), c.y * (total.y * 8.0f), c.z * (total.z * 8.0f));  // frag:2361
+    // frag:2572: phong + refl + refr with refl = refr = 0
+    const V3 fc = v3((col.x + 0.0f) + 0.0f, (col.y + 0.0f) + 0.0f, (col.z + 0.0f) + 0.0f);
+    out[pix] = make_float4(fc.x, fc.y, fc.z, (1.0f + 0.0f) + 0.0f);
+    if (bright) {
+      const float lum = dot(fc, v3(0.2126f, 0.7152f, 0.0722f));  // frag:1938-1946
+      bright[pix] = (lum > 1.0f) ? make_float4(fc.x, fc.y, fc.z, 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    }
+  }
+}
+
+}  // namespace rm

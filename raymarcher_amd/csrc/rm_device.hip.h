@@ -384,6 +384,48 @@ RM_DEV float angularFalloff(const RmLight &li, V3 L) {
 // Material of the hit object, fetched per lane (the index may differ across the wave).
 struct Material { V3 amb, dif, spec; float shininess; };
 
+// Per-light geometry of getPhong (frag:1864-1880): direction to the light, shadow-march range, attenuation,
+// spot falloff.  `li` is read with a wave-uniform index (scalar loads).
+struct LightGeom { V3 L; float maxT, fAtt, aFall; };
+RM_DEV LightGeom lightSetup(const RmLight &li, V3 p, float far) {
+  LightGeom g;
+  g.fAtt = 1.0f; g.aFall = 1.0f;
+  if (li.type == RM_LIGHT_DIRECTIONAL) {
+    g.L = normalize(v3(-li.dir[0], -li.dir[1], -li.dir[2]));
+    g.maxT = far;
+  } else {
+    V3 lpos = v3(li.pos[0], li.pos[1], li.pos[2]);
+    float d = len(sub(p, lpos));
+    V3 toL = sub(lpos, p);
+    g.L = normalize(toL);
+    g.fAtt = attenuation(d, li.func[0], li.func[1], li.func[2]);
+    g.maxT = len(toL);
+    if (li.type == RM_LIGHT_SPOT) g.aFall = angularFalloff(li, g.L);
+  }
+  return g;
+}
+// Shadow-ray origin p + N·SURFACE_DIST·5 (frag:1908).
+RM_DEV V3 shadowOrigin(V3 p, V3 N) {
+  return v3(fma(N.x * kSurfaceDist, 5.0f, p.x), fma(N.y * kSurfaceDist, 5.0f, p.y), fma(N.z * kSurfaceDist, 5.0f, p.z));
+}
+// One light's contribution (frag:1910-1928) given the shadow-march result; returns false if the light is
+// skipped (occluded, or N·L <= 0.005).
+RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat, V3 N, V3 V, float kd, float ks,
+                      int shadowObj, float pen, bool soft, V3 &cur) {
+  float NdotL = dot(N, g.L);
+  bool lit = (shadowObj == -1) && !(NdotL <= 0.005f);
+  NdotL = clamp_(NdotL, 0.0f, 1.0f);
+  V3 lc = v3(li.color[0], li.color[1], li.color[2]);
+  cur = v3(((kd * mat.dif.x) * NdotL) * lc.x, ((kd * mat.dif.y) * NdotL) * lc.y, ((kd * mat.dif.z) * NdotL) * lc.z);
+  V3 R = reflect(neg(g.L), N);
+  float RdotV = clamp_(dot(R, V), 0.0f, 1.0f);
+  float sp = (mat.shininess == 0.0f) ? (ks * RdotV) : (ks * pow_(RdotV, mat.shininess));
+  cur = v3(fma(sp * mat.spec.x, lc.x, cur.x), fma(sp * mat.spec.y, lc.y, cur.y), fma(sp * mat.spec.z, lc.z, cur.z));
+  cur = scale(cur, g.fAtt * g.aFall);
+  if (soft) cur = scale(cur, pen);
+  return lit;
+}
+
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
 template <bool BULB, bool COUNT>
 RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
@@ -392,41 +434,26 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd,
   if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT>(sb, p, N, cnt);
   V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);
   const V3 V = normalize(neg(rd));
-  const V3 so = v3(fma(N.x * kSurfaceDist, 5.0f, p.x), fma(N.y * kSurfaceDist, 5.0f, p.y),
-                   fma(N.z * kSurfaceDist, 5.0f, p.z));  // frag:1908
+  const V3 so = shadowOrigin(p, N);
   const int nl = sb->numLights;
   const bool soft = sb->s.enableSoftShadow != 0;
   for (int i = 0; i < nl; i++) {
     const RmLight &li = sb->lights[i];  // uniform index → scalar loads
-    float fAtt = 1.0f, aFall = 1.0f, maxT;
-    V3 L;
-    if (li.type == RM_LIGHT_DIRECTIONAL) {
-      L = normalize(v3(-li.dir[0], -li.dir[1], -li.dir[2]));
-      maxT = far;
-    } else {
-      V3 lpos = v3(li.pos[0], li.pos[1], li.pos[2]);
-      float d = len(sub(p, lpos));
-      V3 toL = sub(lpos, p);
-      L = normalize(toL);
-      fAtt = attenuation(d, li.func[0], li.func[1], li.func[2]);
-      maxT = len(toL);
-      if (li.type == RM_LIGHT_SPOT) aFall = angularFalloff(li, L);
-    }
-    MarchRes sh = march<BULB, COUNT, true>(sb, so, L, maxT, 1.0f, cnt);
-    float NdotL = dot(N, L);
-    bool lit = (sh.obj == -1) && !(NdotL <= 0.005f);
-    NdotL = clamp_(NdotL, 0.0f, 1.0f);
-    V3 lc = v3(li.color[0], li.color[1], li.color[2]);
-    V3 cur = v3(((kd * mat.dif.x) * NdotL) * lc.x, ((kd * mat.dif.y) * NdotL) * lc.y, ((kd * mat.dif.z) * NdotL) * lc.z);
-    V3 R = reflect(neg(L), N);
-    float RdotV = clamp_(dot(R, V), 0.0f, 1.0f);
-    float sp = (mat.shininess == 0.0f) ? (ks * RdotV) : (ks * pow_(RdotV, mat.shininess));
-    cur = v3(fma(sp * mat.spec.x, lc.x, cur.x), fma(sp * mat.spec.y, lc.y, cur.y), fma(sp * mat.spec.z, lc.z, cur.z));
-    cur = scale(cur, fAtt * aFall);
-    if (soft) cur = scale(cur, sh.d);
-    if (lit) total = add(total, cur);
+    LightGeom g = lightSetup(li, p, far);
+    MarchRes sh = march<BULB, COUNT, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
+    V3 cur;
+    if (lightTerm(li, g, mat, N, V, kd, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
   return total;
+}
+
+// Orbit-trap palette of the Mandelbulb (frag:2356-2360), before the ·(phong·8).
+RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
+  V3 c = v3(0.2f, 0.2f, 0.2f);
+  c = mix(c, v3(0.10f, 0.20f, 0.30f), clamp_(ty, 0.0f, 1.0f));
+  c = mix(c, v3(0.02f, 0.10f, 0.30f), clamp_(tz * tz, 0.0f, 1.0f));
+  c = mix(c, v3(0.30f, 0.10f, 0.02f), clamp_(pow_(tw, 6.0f), 0.0f, 1.0f));
+  return scale(c, 0.5f);
 }
 
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
@@ -455,11 +482,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   V3 ph = getPhong<BULB, COUNT>(sb, mat, pn, p, rd, maxT, cnt);
   V3 col = ph;
   if (type == RM_MANDELBULB) {  // frag:2354-2361
-    V3 c = v3(0.2f, 0.2f, 0.2f);
-    c = mix(c, v3(0.10f, 0.20f, 0.30f), clamp_(res.trap.y, 0.0f, 1.0f));
-    c = mix(c, v3(0.02f, 0.10f, 0.30f), clamp_(res.trap.z * res.trap.z, 0.0f, 1.0f));
-    c = mix(c, v3(0.30f, 0.10f, 0.02f), clamp_(pow_(res.trap.w, 6.0f), 0.0f, 1.0f));
-    c = scale(c, 0.5f);
+    V3 c = bulbTrapColor(res.trap.y, res.trap.z, res.trap.w);
     col = v3(c.x * (ph.x * 8.0f), c.y * (ph.y * 8.0f), c.z * (ph.z * 8.0f));
   } else if (type == RM_MENGERSPONGE) {  // frag:2362-2365
     V3 c = v3(fma(0.5f, cos_(fma(2.0f, res.trap.z, 0.0f)), 0.5f), fma(0.5f, cos_(fma(2.0f, res.trap.z, 1.0f)), 0.5f),
@@ -471,12 +494,36 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   return out;
 }
 
+// NDC of a pixel centre, then raymarch.vert:23-24 + frag:2388-2392: ro on the near plane, rd toward the far plane.
+RM_DEV void pixelNdc(int px, int py, int W, int H, float &ndcx, float &ndcy) {
+  ndcx = fma(((float)px + 0.5f) / (float)W, 2.0f, -1.0f);
+  ndcy = fma(((float)py + 0.5f) / (float)H, 2.0f, -1.0f);
+}
+RM_DEV void primaryRay(const SceneBlock *sb, float ndcx, float ndcy, V3 &ro, V3 &rd) {
+  const float *M = sb->cam.invProjView;
+  // invProjView · (x, y, ∓1, 1): ((M0·x + M1·y) + M2·z) + M3·w
+  float bx = fma(M[4], ndcy, M[0] * ndcx), by = fma(M[5], ndcy, M[1] * ndcx), bz = fma(M[6], ndcy, M[2] * ndcx),
+        bw = fma(M[7], ndcy, M[3] * ndcx);
+  float nw = fma(M[15], 1.0f, fma(M[11], -1.0f, bw)), fw = fma(M[15], 1.0f, fma(M[11], 1.0f, bw));
+  ro = v3(fma(M[12], 1.0f, fma(M[8], -1.0f, bx)) / nw, fma(M[13], 1.0f, fma(M[9], -1.0f, by)) / nw,
+          fma(M[14], 1.0f, fma(M[10], -1.0f, bz)) / nw);  // frag:2388
+  V3 fc = v3(fma(M[12], 1.0f, fma(M[8], 1.0f, bx)) / fw, fma(M[13], 1.0f, fma(M[9], 1.0f, by)) / fw,
+             fma(M[14], 1.0f, fma(M[10], 1.0f, bz)) / fw);  // frag:2389
+  rd = normalize(sub(fc, ro));                              // frag:2392
+}
+RM_DEV V3 backgroundColor(const SceneBlock *sb) {  // frag:2405-2419, later #ifdefs override earlier ones
+  V3 bg = v3(0.0f, 0.0f, 0.0f);
+  if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
+  if (sb->s.features & RM_FEAT_DARK_BACKGROUND) bg = v3(0.0f, 0.0f, 0.0f);
+  return bg;
+}
+
 // raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
 template <bool BULB, bool COUNT>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
                        V4 &bright, Counters &cnt, bool &hitFlag) {
-  float ndcx = fma(((float)px + 0.5f) / (float)W, 2.0f, -1.0f);
-  float ndcy = fma(((float)py + 0.5f) / (float)H, 2.0f, -1.0f);
+  float ndcx, ndcy;
+  pixelNdc(px, py, W, H, ndcx, ndcy);
   bright = v4(0.0f, 0.0f, 0.0f, 1.0f);
   hitFlag = false;
   if (sb->g.isTwoD) {  // frag:2431, 2377-2380
@@ -484,19 +531,9 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
     fragColor = v4(pow_(s, 0.9f), pow_(s, 1.1f), pow_(s, 1.4f), 1.0f);
     return;
   }
-  const float *M = sb->cam.invProjView;
-  // invProjView · (x, y, ∓1, 1): ((M0·x + M1·y) + M2·z) + M3·w
-  float bx = fma(M[4], ndcy, M[0] * ndcx), by = fma(M[5], ndcy, M[1] * ndcx), bz = fma(M[6], ndcy, M[2] * ndcx),
-        bw = fma(M[7], ndcy, M[3] * ndcx);
-  float nw = fma(M[15], 1.0f, fma(M[11], -1.0f, bw)), fw = fma(M[15], 1.0f, fma(M[11], 1.0f, bw));
-  V3 ro = v3(fma(M[12], 1.0f, fma(M[8], -1.0f, bx)) / nw, fma(M[13], 1.0f, fma(M[9], -1.0f, by)) / nw,
-             fma(M[14], 1.0f, fma(M[10], -1.0f, bz)) / nw);  // frag:2388
-  V3 fc = v3(fma(M[12], 1.0f, fma(M[8], 1.0f, bx)) / fw, fma(M[13], 1.0f, fma(M[9], 1.0f, by)) / fw,
-             fma(M[14], 1.0f, fma(M[10], 1.0f, bz)) / fw);   // frag:2389
-  V3 rd = normalize(sub(fc, ro));                             // frag:2392
-  V3 bg = v3(0.0f, 0.0f, 0.0f);
-  if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
-  if (sb->s.features & RM_FEAT_DARK_BACKGROUND) bg = v3(0.0f, 0.0f, 0.0f);
+  V3 ro, rd;
+  primaryRay(sb, ndcx, ndcy, ro, rd);
+  const V3 bg = backgroundColor(sb);
   const float far = sb->cam.initialFar;
 
   Hit info;

@@ -9,19 +9,11 @@
 #include <string>
 #include <vector>
 
+#include "rm_bulb_pipeline.hip.h"
 #include "rm_device.hip.h"
 #include "rm_internal.h"
 
 namespace rm {
-
-// Maps a packed output row to its frame row: rows are grouped in tiles of `tileRows`; this launch owns
-// tiles shard, shard+numShards, …  (rm_render: tileRows = rows, numShards = 1).
-struct RowMap {
-  int rowBegin, tileRows, shard, numShards;
-  __host__ __device__ int frameRow(int r) const {
-    return rowBegin + ((r / tileRows) * numShards + shard) * tileRows + (r % tileRows);
-  }
-};
 
 // Block = 4 waves side by side, each wave an 8×8 pixel tile → the block covers 32×8 pixels.
 constexpr int kBlockW = 32, kBlockH = 8;
@@ -126,11 +118,17 @@ struct DeviceState {
   int next = 0;
   unsigned long long *dCounters = nullptr;
   bool init = false;
+  // wavefront-pipeline workspace (grow-only; allocated outside any capture, on first use / growth)
+  void *wsMem = nullptr;
+  size_t wsBytes = 0;
+  int numCUs = 0;
 };
 std::mutex g_mu;
 DeviceState g_dev[64];
 bool g_timing = false;
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timed;
+bool g_forceGeneric = false;  // rm_set_kernel_path(1): always use the one-lane-per-pixel kernel
+struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (single kernel) or 5 (pipeline K1..K4 boundaries)
+std::vector<TimedLaunch> g_timed;
 
 #define HIP_OK(expr)                                                                              \
   do {                                                                                            \
@@ -160,6 +158,29 @@ int acquire_slot(Slot **out) {
   if (s.used) HIP_OK(hipEventSynchronize(s.done));  // only blocks with > kSlots launches in flight
   s.used = true;
   *out = &s;
+  return RM_OK;
+}
+
+// Carve the pipeline workspace for `pixels` pixels and `nl` lights out of the device allocation.
+int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, BulbWs *ws) {
+  auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t oCnt = 0, oPix = align(16), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
+               oN = oP + align(pixels * 16), oSh = oN + align(pixels * 16),
+               total = oSh + align(pixels * (size_t)(nl > 0 ? nl : 1) * 8);
+  if (total > ds.wsBytes) {
+    HIP_OK(hipStreamSynchronize(stream));
+    if (ds.wsMem) HIP_OK(hipFree(ds.wsMem));
+    ds.wsMem = nullptr; ds.wsBytes = 0;
+    HIP_OK(hipMalloc(&ds.wsMem, total));
+    ds.wsBytes = total;
+  }
+  char *b = static_cast<char *>(ds.wsMem);
+  ws->counters = reinterpret_cast<uint32_t *>(b + oCnt);
+  ws->hitPix = reinterpret_cast<int *>(b + oPix);
+  ws->hitRec = reinterpret_cast<float4 *>(b + oRec);
+  ws->surfP = reinterpret_cast<float4 *>(b + oP);
+  ws->surfN = reinterpret_cast<float4 *>(b + oN);
+  ws->shadow = reinterpret_cast<int2 *>(b + oSh);
   return RM_OK;
 }
 
@@ -231,25 +252,55 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (count) HIP_OK(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), stream));
   dim3 grid((W + kBlockW - 1) / kBlockW, (nRows + kBlockH - 1) / kBlockH), block(256);
   const bool bulb = (numObjects == 1 && objs[0].type == RM_MANDELBULB);
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  if (g_timing) {
-    HIP_OK(hipEventCreate(&t0));
-    HIP_OK(hipEventCreate(&t1));
-    HIP_OK(hipEventRecord(t0, stream));
-  }
+  auto nonzero3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
+  // The wavefront pipeline covers the single-Mandelbulb class without secondary rays; everything else (and the
+  // counted variant) runs the one-lane-per-pixel kernel.  Both produce the same bits.
+  const bool pipeline = bulb && !count && !g_forceGeneric && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
+                        !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
+                        !(s->enableRefraction && nonzero3(objs[0].cTransparent));
+  TimedLaunch tl{};
+  auto stamp = [&](int i) -> int {
+    if (!g_timing) return RM_OK;
+    HIP_OK(hipEventCreate(&tl.ev[i]));
+    HIP_OK(hipEventRecord(tl.ev[i], stream));
+    tl.n = i + 1;
+    return RM_OK;
+  };
   float4 *o = reinterpret_cast<float4 *>(d_rgba), *b = reinterpret_cast<float4 *>(d_bright);
-  if (bulb) {
-    if (count) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+  if (pipeline) {
+    DeviceState &ds = g_dev[dev];
+    if (ds.numCUs == 0) {
+      hipDeviceProp_t prop;
+      HIP_OK(hipGetDeviceProperties(&prop, dev));
+      ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    BulbWs ws;
+    st = bulb_workspace(ds, (size_t)nRows * W, numLights, stream, &ws);
+    if (st != RM_OK) return st;
+    HIP_OK(hipMemsetAsync(ws.counters, 0, 16, stream));
+    const dim3 persistent(ds.numCUs * 8), dense(ds.numCUs * 16);
+    if ((st = stamp(0)) != RM_OK) return st;
+    hipLaunchKernelGGL(bulb_primary_kernel, persistent, block, 0, stream, slot->dev, map, W, H, nRows, o, b, ws);
+    if ((st = stamp(1)) != RM_OK) return st;
+    hipLaunchKernelGGL(bulb_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws);
+    if ((st = stamp(2)) != RM_OK) return st;
+    hipLaunchKernelGGL(bulb_shadow_kernel, persistent, block, 0, stream, slot->dev, ws);
+    if ((st = stamp(3)) != RM_OK) return st;
+    hipLaunchKernelGGL(bulb_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws);
+    if ((st = stamp(4)) != RM_OK) return st;
   } else {
-    if (count) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    if ((st = stamp(0)) != RM_OK) return st;
+    if (bulb) {
+      if (count) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    } else {
+      if (count) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    }
+    if ((st = stamp(1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
-  if (g_timing) {
-    HIP_OK(hipEventRecord(t1, stream));
-    g_timed.emplace_back(t0, t1);
-  }
+  if (g_timing) g_timed.push_back(tl);
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
     unsigned long long hc[3];
@@ -334,24 +385,41 @@ int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *s
 int rm_set_timing(int on) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_timing = on != 0;
-  for (auto &p : g_timed) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto &t : g_timed)
+    for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
   g_timed.clear();
   return RM_OK;
 }
 int rm_get_timing(double *avgKernelMs, int *launches) {
+  double stages[4];
+  return rm_get_stage_timing(avgKernelMs, stages, launches);
+}
+int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches) {
   std::lock_guard<std::mutex> lock(g_mu);
-  double total = 0.0;
-  for (auto &p : g_timed) {
-    HIP_OK(hipEventSynchronize(p.second));
+  double total = 0.0, stage[4] = {0, 0, 0, 0};
+  for (auto &t : g_timed) {
+    if (t.n < 2) continue;
+    HIP_OK(hipEventSynchronize(t.ev[t.n - 1]));
     float ms = 0.0f;
-    HIP_OK(hipEventElapsedTime(&ms, p.first, p.second));
+    HIP_OK(hipEventElapsedTime(&ms, t.ev[0], t.ev[t.n - 1]));
     total += ms;
-    (void)hipEventDestroy(p.first);
-    (void)hipEventDestroy(p.second);
+    for (int i = 0; i + 1 < t.n && i < 4; i++) {
+      HIP_OK(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+      stage[i] += ms;
+    }
   }
+  const double n = g_timed.empty() ? 1.0 : (double)g_timed.size();
   if (launches) *launches = (int)g_timed.size();
-  if (avgKernelMs) *avgKernelMs = g_timed.empty() ? 0.0 : total / (double)g_timed.size();
+  if (avgTotalMs) *avgTotalMs = total / n;
+  if (avgStageMs) for (int i = 0; i < 4; i++) avgStageMs[i] = stage[i] / n;
+  for (auto &t : g_timed)
+    for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
   g_timed.clear();
+  return RM_OK;
+}
+int rm_set_kernel_path(int forceGeneric) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_forceGeneric = forceGeneric != 0;
   return RM_OK;
 }
 

@@ -229,6 +229,35 @@ def test_mandelbrot_2d_and_julia(renderer):
     assert_bit_equal(renderer.render(tables_of(tuple(scene)), s, W, H).cpu().numpy(), ref, "julia bulb power 6")
 
 
+def test_bulb_pipeline_equals_one_lane_per_pixel_kernel(renderer):
+    """The wavefront pipeline (4 kernels) and the one-lane-per-pixel kernel are two schedules of the same
+    arithmetic: identical bits, including with a transformed bulb, a point + spot light, AO and soft shadows."""
+    from raymarcher_amd import lib
+    W, H = 150, 83
+    cam = h.make_camera((0.5, 0.8, 4.0), (-0.5, -0.8, -4.0), (0, 1, 0), 35.0, W, H)
+    M = h.translate(0.2, -0.1, 0.3) @ h.scale(1.3, 1.3, 1.3)
+    objs = (abi.RmObject * 1)(h.make_object(abi.RM_MANDELBULB, model=M, scale_factor=1.3, ambient=(.3, .2, .3),
+                                            diffuse=(.9, 1, .8), specular=(1, 1, 1), shininess=40.0))
+    lights = (abi.RmLight * 3)(
+        h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.4, -1, -0.5)),
+        h.make_light(abi.RM_LIGHT_POINT, (1, .9, .7), pos=(3, 2, 4), func=(0.7, 0.05, 0.01)),
+        h.make_light(abi.RM_LIGHT_SPOT, (.6, .8, 1), direction=(0, -1, -0.3), pos=(0, 5, 1.5), func=(1, 0, 0),
+                     angle=np.deg2rad(30.0), penumbra=np.deg2rad(10.0)))
+    scene = (cam, objs, 1, lights, 3, h.make_globals())
+    for over in ({}, {"enableSoftShadow": 1, "enableAmbientOcclusion": 1, "fractalIters": 9, "maxSteps": 100},
+                 {"features": abi.RM_FEAT_DARK_BACKGROUND, "fractalIters": 1}):
+        s = abi.default_settings(**over)
+        try:
+            lib().rm_set_kernel_path(1)
+            a, ab = renderer.render(tables_of(scene), s, W, H, bright=True)
+        finally:
+            lib().rm_set_kernel_path(0)
+        b, bb = renderer.render(tables_of(scene), s, W, H, bright=True)
+        assert_bit_equal(b.cpu().numpy(), a.cpu().numpy(), f"pipeline vs generic {over}")
+        assert_bit_equal(bb.cpu().numpy(), ab.cpu().numpy(), f"pipeline vs generic bright {over}")
+        assert_bit_equal(b.cpu().numpy(), h.oracle_render(scene, s, W, H), f"pipeline vs oracle {over}")
+
+
 # ---------------------------------------------------------------- edge cases of the boundary
 def test_row_ranges_and_ragged_sizes(renderer):
     W, H = 37, 29  # not multiples of the 8×8 wave tile
