@@ -9,8 +9,12 @@
 //                           body is ONE Mandelbulb iteration (frag:786-798), so lanes at different march
 //                           steps / iteration counts never wait for each other.  Lanes whose ray ended park;
 //                           when ≥16 are parked (__ballot/popcount) the wave flushes them — misses store the
-//                           background, hits are appended to a compact hit list (one wave-aggregated atomic) —
-//                           and refills them with the next pixels (one atomic on the pixel cursor).
+//                           background, hits are appended to the hit list — and refills them with the next
+//                           pixels.  Pixel indices and hit-list slots are reserved per wave in chunks (512
+//                           indices / 64 slots per atomic): a single device-scope counter sustains only ≈88
+//                           atomics/µs, and one atomic per flush (≈10⁶ per 4K frame) made the first version
+//                           of this kernel atomic-bound (7.2 ms).  Unused slots of a wave's last chunk are
+//                           marked invalid (pix = −1) and skipped downstream.
 //   K2 bulb_surface_kernel  one lane per HIT (dense waves): hit point, 4-tap normal, Perlin bump, AO.
 //   K3 bulb_shadow_kernel   one lane per (hit, light) shadow ray, same iteration-level state machine and
 //                           refill as K1.  Rays of lights with N·L <= 0.005 are not marched: getPhong
@@ -43,6 +47,18 @@ struct BulbWs {
 };
 
 constexpr int kFlushThreshold = 16;
+constexpr uint32_t kPixelChunk = 512;  // pixel indices (= 8 tiles) reserved per atomic on the pixel cursor
+constexpr uint32_t kSlotChunk = 64;    // hit-list slots reserved per atomic
+constexpr uint32_t kRayChunk = 1024;   // shadow rays reserved per atomic
+
+// Wave-uniform broadcast of lane `src`'s value.
+RM_DEV uint32_t bcast(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
+// Reserve `n` units from a device counter, once per wave (lane 0 issues the atomic).
+RM_DEV uint32_t waveReserve(uint32_t *counter, uint32_t n) {
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, n);
+  return bcast(base, 0);
+}
 
 RM_DEV unsigned long long laneMaskLt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
@@ -130,51 +146,64 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
   V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
   float t = 0.0f, hitD = 0.0f;
   BulbDE de{};
+  // wave-uniform cursors into the reserved chunks
+  uint32_t pixCur = 0, pixEnd = 0, slotCur = 0, slotEnd = 0;
+  bool exhausted = false;
 
   for (;;) {
     const unsigned long long mMarch = __ballot(st == ST_MARCH);
     const unsigned long long mWait = __ballot(st == ST_NEED || st == ST_HIT || st == ST_MISS);
     if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= kFlushThreshold)) {
-      // ---- flush: write results of parked lanes, then refill every waiting lane ----
+      // ---- flush: write results of parked lanes, then refill waiting lanes ----
       if (st == ST_MISS) {  // frag:2325, 2465
         out[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
         if (bright) bright[pix] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        st = ST_NEED;
       }
       const unsigned long long mHit = __ballot(st == ST_HIT);
       if (mHit) {
-        const int first = __ffsll((long long)mHit) - 1;
-        uint32_t base = 0;
-        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ws.counters[1], (uint32_t)__popcll(mHit));
-        base = __shfl(base, first);
+        const uint32_t n = (uint32_t)__popcll(mHit), avail = slotEnd - slotCur;
+        uint32_t fresh = 0;
+        if (n > avail) fresh = waveReserve(&ws.counters[1], kSlotChunk);  // old chunk gets exactly filled
         if (st == ST_HIT) {
-          const uint32_t slot = base + (uint32_t)__popcll(mHit & lt);
+          const uint32_t rank = (uint32_t)__popcll(mHit & lt);
+          const uint32_t slot = (rank < avail) ? (slotCur + rank) : (fresh + (rank - avail));
           ws.hitPix[slot] = pix;
           ws.hitRec[slot] = make_float4(hitD, de.ty, de.tz, de.tw);
+          st = ST_NEED;
         }
+        if (n > avail) { slotCur = fresh + (n - avail); slotEnd = fresh + kSlotChunk; }
+        else slotCur += n;
+      }
+      // refill from the wave's pixel chunk
+      if (pixCur == pixEnd && !exhausted) {
+        pixCur = waveReserve(&ws.counters[0], kPixelChunk);
+        pixEnd = pixCur + kPixelChunk;
+        if (pixCur >= totalIdx) { exhausted = true; pixEnd = pixCur; }
+        else if (pixEnd > totalIdx) pixEnd = totalIdx;
       }
       {
-        const int first = __ffsll((long long)mWait) - 1;
-        uint32_t base = 0;
-        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ws.counters[0], (uint32_t)__popcll(mWait));
-        base = __shfl(base, first);
-        if (st != ST_MARCH && st != ST_DONE) {
-          const uint32_t idx = base + (uint32_t)__popcll(mWait & lt);
-          int x, r;
-          if (idx >= totalIdx) {
+        const unsigned long long mNeed = __ballot(st == ST_NEED);
+        const uint32_t avail = pixEnd - pixCur, n = (uint32_t)__popcll(mNeed);
+        if (st == ST_NEED) {
+          const uint32_t rank = (uint32_t)__popcll(mNeed & lt);
+          if (rank < avail) {
+            int x, r;
+            if (decodePixel(pixCur + rank, tilesX, W, nRows, x, r)) {
+              pix = r * W + x;
+              float ndcx, ndcy;
+              pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+              primaryRay(sb, ndcx, ndcy, ro, rd);
+              t = 0.0f;
+              steps = 0;
+              deStart(de, sb, k, madd(rd, t, ro));
+              st = ST_MARCH;
+            }  // else: padding lane of an edge tile, stays NEED
+          } else if (exhausted) {
             st = ST_DONE;
-          } else if (!decodePixel(idx, tilesX, W, nRows, x, r)) {
-            st = ST_NEED;  // padding lane of an edge tile: ask again at the next flush
-          } else {
-            pix = r * W + x;
-            float ndcx, ndcy;
-            pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
-            primaryRay(sb, ndcx, ndcy, ro, rd);
-            t = 0.0f;
-            steps = 0;
-            deStart(de, sb, k, madd(rd, t, ro));
-            st = ST_MARCH;
           }
         }
+        pixCur += (n < avail) ? n : avail;
       }
       continue;
     }
@@ -195,15 +224,18 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
       }
     }
   }
+  // unused slots of this wave's last chunk are holes
+  for (uint32_t sl = slotCur + (threadIdx.x & 63); sl < slotEnd; sl += 64) ws.hitPix[sl] = -1;
 }
 
 // ---- K2 ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bulb_surface_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                             BulbWs ws) {
-  const uint32_t nHits = ws.counters[1];
+  const uint32_t nHits = ws.counters[1];  // reserved slots (multiple of kSlotChunk); holes have pix < 0
   Counters cnt{0, 0};
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
     const int pix = ws.hitPix[h];
+    if (pix < 0) continue;
     const float4 rec = ws.hitRec[h];
     const int r = pix / W, x = pix - r * W;
     float ndcx, ndcy;
@@ -235,41 +267,49 @@ __global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__re
   V3 so = v3(0, 0, 0), L = v3(0, 0, 0);
   float t = 0.0f, maxT = 0.0f, pen = 1.0f;
   BulbDE de{};
+  uint32_t rayCur = 0, rayEnd = 0;
+  bool exhausted = false;
 
   for (;;) {
     const unsigned long long mMarch = __ballot(st == ST_MARCH);
     const unsigned long long mWait = __ballot(st == ST_NEED);
     if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= kFlushThreshold)) {
-      const int first = __ffsll((long long)mWait) - 1;
-      uint32_t base = 0;
-      if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ws.counters[2], (uint32_t)__popcll(mWait));
-      base = __shfl(base, first);
+      if (rayCur == rayEnd && !exhausted) {
+        rayCur = waveReserve(&ws.counters[2], kRayChunk);
+        rayEnd = rayCur + kRayChunk;
+        if (rayCur >= totalRays) { exhausted = true; rayEnd = rayCur; }
+        else if (rayEnd > totalRays) rayEnd = totalRays;
+      }
+      const uint32_t avail = rayEnd - rayCur, n = (uint32_t)__popcll(mWait);
       if (st == ST_NEED) {
-        ray = base + (uint32_t)__popcll(mWait & lt);
-        if (ray >= totalRays) {
-          st = ST_DONE;
-        } else {
+        const uint32_t rank = (uint32_t)__popcll(mWait & lt);
+        if (rank < avail) {
+          ray = rayCur + rank;
           const uint32_t li = ray / nHits, h = ray - li * nHits;  // light-major: a wave marches toward one light
-          const float4 P = ws.surfP[h], Nn = ws.surfN[h];
-          const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
-          // li differs across a wave only at the boundary between two lights' ray ranges → per-lane table read
-          const LightGeom g = lightSetup(sb->lights[li], p, far);
-          if (dot(N, g.L) <= 0.005f) {
-            // getPhong skips this light whatever the shadow march returns (frag:1912): do not march.
-            ws.shadow[ray] = make_int2(-1, (int)f2u(1.0f));
-            st = ST_NEED;
-          } else {
-            so = shadowOrigin(p, N);
-            L = g.L;
-            maxT = g.maxT;
-            t = 0.0f;
-            pen = 1.0f;
-            steps = 0;
-            deStart(de, sb, k, madd(L, t, so));
-            st = ST_MARCH;
-          }
+          if (ws.hitPix[h] >= 0) {
+            const float4 P = ws.surfP[h], Nn = ws.surfN[h];
+            const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
+            // li differs across a wave only at the boundary between two lights' ray ranges → per-lane table read
+            const LightGeom g = lightSetup(sb->lights[li], p, far);
+            if (dot(N, g.L) <= 0.005f) {
+              // getPhong skips this light whatever the shadow march returns (frag:1912): do not march.
+              ws.shadow[ray] = make_int2(-1, (int)f2u(1.0f));
+            } else {
+              so = shadowOrigin(p, N);
+              L = g.L;
+              maxT = g.maxT;
+              t = 0.0f;
+              pen = 1.0f;
+              steps = 0;
+              deStart(de, sb, k, madd(L, t, so));
+              st = ST_MARCH;
+            }
+          }  // hole: nothing to do, stays NEED
+        } else if (exhausted) {
+          st = ST_DONE;
         }
       }
+      rayCur += (n < avail) ? n : avail;
       continue;
     }
     if (mMarch == 0) break;
@@ -311,6 +351,7 @@ __global__ __launch_bounds__(256) void bulb_shade_kernel(const SceneBlock *__res
   mat.shininess = o.shininess;
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
     const int pix = ws.hitPix[h];
+    if (pix < 0) continue;
     const float4 rec = ws.hitRec[h], P = ws.surfP[h], Nn = ws.surfN[h];
     const int r = pix / W, x = pix - r * W;
     float ndcx, ndcy;

@@ -275,7 +275,9 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     BulbWs ws;
-    st = bulb_workspace(ds, (size_t)nRows * W, numLights, stream, &ws);
+    // hit-list capacity: every pixel may hit, plus one partly used 64-slot chunk per persistent wave
+    const size_t slots = (size_t)nRows * W + (size_t)kSlotChunk * ds.numCUs * 8 * 4;
+    st = bulb_workspace(ds, slots, numLights, stream, &ws);
     if (st != RM_OK) return st;
     HIP_OK(hipMemsetAsync(ws.counters, 0, 16, stream));
     const dim3 persistent(ds.numCUs * 8), dense(ds.numCUs * 16);
