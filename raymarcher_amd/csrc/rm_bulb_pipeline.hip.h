@@ -68,8 +68,9 @@ struct BulbDE {
   float dz, m, ty, tz, tw;
   int it;
 };
-struct BulbParams {  // wave-uniform
+struct BulbParams {  // wave-uniform; read ONCE before the persistent loop so the loop body has no scalar loads
   float power, pexp, jx, jy, scale;
+  float m00, m01, m02, m10, m11, m12, m20, m21, m22, m30, m31, m32;  // rows 0-2 of invModel, by column
   int iters;
   bool julia;
 };
@@ -82,12 +83,16 @@ RM_DEV BulbParams bulbParams(const SceneBlock *sb) {
   k.julia = len2(k.jx, k.jy) != 0.0f;
   k.iters = sb->s.fractalIters;
   k.scale = sb->objs[0].scaleFactor;
+  const float *M = sb->objs[0].invModel;
+  k.m00 = M[0]; k.m01 = M[1]; k.m02 = M[2];
+  k.m10 = M[4]; k.m11 = M[5]; k.m12 = M[6];
+  k.m20 = M[8]; k.m21 = M[9]; k.m22 = M[10];
+  k.m30 = M[12]; k.m31 = M[13]; k.m32 = M[14];
   return k;
 }
-RM_DEV void deStart(BulbDE &s, const SceneBlock *sb, const BulbParams &k, V3 p) {
-  const float *M = sb->objs[0].invModel;
-  V3 po = v3(fma(M[8], p.z, fma(M[4], p.y, fma(M[0], p.x, M[12]))), fma(M[9], p.z, fma(M[5], p.y, fma(M[1], p.x, M[13]))),
-             fma(M[10], p.z, fma(M[6], p.y, fma(M[2], p.x, M[14]))));  // frag:1417
+RM_DEV void deStart(BulbDE &s, const BulbParams &k, V3 p) {
+  V3 po = v3(fma(k.m20, p.z, fma(k.m10, p.y, fma(k.m00, p.x, k.m30))), fma(k.m21, p.z, fma(k.m11, p.y, fma(k.m01, p.x, k.m31))),
+             fma(k.m22, p.z, fma(k.m12, p.y, fma(k.m02, p.x, k.m32))));  // frag:1417
   s.w = po;
   s.m = dot(po, po);
   s.ty = fabs_(po.y); s.tz = fabs_(po.z); s.tw = s.m;  // trap = vec4(abs(w), m), frag:778 (trap.x is never read)
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
               primaryRay(sb, ndcx, ndcy, ro, rd);
               t = 0.0f;
               steps = 0;
-              deStart(de, sb, k, madd(rd, t, ro));
+              deStart(de, k, madd(rd, t, ro));
               st = ST_MARCH;
             }  // else: padding lane of an edge tile, stays NEED
           } else if (exhausted) {
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
           t = fma(d, 1.0f, t);
           steps++;
           if (steps >= maxSteps) st = ST_MISS;
-          else deStart(de, sb, k, madd(rd, t, ro));
+          else deStart(de, k, madd(rd, t, ro));
         }
       }
     }
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__re
               t = 0.0f;
               pen = 1.0f;
               steps = 0;
-              deStart(de, sb, k, madd(L, t, so));
+              deStart(de, k, madd(L, t, so));
               st = ST_MARCH;
             }
           }  // hole: nothing to do, stays NEED
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__re
           t = t + fabs_(d);
           steps++;
           if (steps >= maxSteps) end = true;
-          else deStart(de, sb, k, madd(L, t, so));
+          else deStart(de, k, madd(L, t, so));
         }
         if (end) {
           ws.shadow[ray] = make_int2(hit ? 0 : -1, (int)f2u(pen));
