@@ -146,6 +146,11 @@ def main():
     if rank == 0:
         _, cnt = r.render_counted(tables, settings, W, H)
     if rank == 0:
+        path = int(os.environ.get("RM_KERNEL_PATH", "0"))
+        kernel_name = {0: "rm::render_kernel<true,false> (one lane per pixel, 8x8 tile per wave)",
+                       1: "rm::render_kernel<true,false> (one lane per pixel, 8x8 tile per wave)",
+                       2: "pipeline A: bulb_primary+surface+shadow+shade kernels (state machines + lane refill)",
+                       3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)"}[path]
         mpix = W * H * args.steps / dt / 1e6
         flops_frame = cnt.bulbIters * FLOP_PER_ITER + cnt.sceneEvals * FLOP_PER_EVAL + cnt.hitPixels * FLOP_PER_HIT
         # the dominant kernel of one launch processes 1/world of the frame (interleaved tiles ≈ equal work)
@@ -163,9 +168,7 @@ def main():
                        "parity": "bit-exact vs CPU oracle (rm_math contract)"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "kernel": "Mandelbulb pipeline: rm::bulb_primary_kernel + bulb_surface_kernel + "
-                                   "bulb_shadow_kernel + bulb_shade_kernel (one rm_render launch)",
-                         "kernel_ms": round(kernel_ms, 4),
+                         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "stage_ms": {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
                                       "shadow": round(stages[2], 4), "shade": round(stages[3], 4)},
                          "algorithmic": {"flop_per_launch": flops_launch, "sceneEvals": cnt.sceneEvals,

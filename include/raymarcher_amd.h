@@ -203,9 +203,11 @@ int rm_get_timing(double *avgKernelMs, int *launches);
 /* Same, split by pipeline stage.  The single-Mandelbulb scene class renders as four kernels (primary march,
  * surface/normals, shadow marches, shading: stage 0..3); every other scene is one kernel (stage 0). */
 int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches);
-/* 1 = always use the one-lane-per-pixel kernel, 0 = pick the fastest path for the scene class (default).
- * Both paths produce identical bits; the switch exists for A/B measurement and tests. */
-int rm_set_kernel_path(int forceGeneric);
+/* Which schedule renders the single-Mandelbulb scene class: 0 = the measured-fastest one (default),
+ * 1 = one lane per pixel (rm::render_kernel, the only path for every other scene), 2 = four-kernel pipeline with
+ * per-lane state machines and ballot-based lane refill, 3 = four-kernel pipeline with plain loops on compacted
+ * hit / shadow-ray lists.  All paths produce identical bits; the switch exists for A/B measurement and tests. */
+int rm_set_kernel_path(int path);
 
 /*
  * rm_frame_to_rgba8 — clamp→×255→round and vertical flip, the read-back of

@@ -46,7 +46,7 @@ struct BulbWs {
   int2 *shadow;        // per ray [light·nHits + hit]: (intersectObj or -1, bits of the penumbra factor)
 };
 
-constexpr int kFlushThreshold = 16;
+constexpr int kDefaultFlushThreshold = 16;
 constexpr uint32_t kPixelChunk = 512;  // pixel indices (= 8 tiles) reserved per atomic on the pixel cursor
 constexpr uint32_t kSlotChunk = 64;    // hit-list slots reserved per atomic
 constexpr uint32_t kRayChunk = 1024;   // shadow rays reserved per atomic
@@ -138,7 +138,7 @@ enum { ST_NEED = 0, ST_MARCH = 1, ST_HIT = 2, ST_MISS = 3, ST_DONE = 4 };
 // ---- K1 ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                             int nRows, float4 *__restrict__ out,
-                                                            float4 *__restrict__ bright, BulbWs ws) {
+                                                            float4 *__restrict__ bright, BulbWs ws, int flushThreshold) {
   const int tilesX = (W + 7) >> 3, tilesY = (nRows + 7) >> 3;
   const uint32_t totalIdx = (uint32_t)tilesX * (uint32_t)tilesY * 64u;
   const BulbParams k = bulbParams(sb);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
   for (;;) {
     const unsigned long long mMarch = __ballot(st == ST_MARCH);
     const unsigned long long mWait = __ballot(st == ST_NEED || st == ST_HIT || st == ST_MISS);
-    if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= kFlushThreshold)) {
+    if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= flushThreshold)) {
       // ---- flush: write results of parked lanes, then refill waiting lanes ----
       if (st == ST_MISS) {  // frag:2325, 2465
         out[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void bulb_surface_kernel(const SceneBlock *__r
 }
 
 // ---- K3 ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__restrict__ sb, BulbWs ws) {
+__global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__restrict__ sb, BulbWs ws, int flushThreshold) {
   const uint32_t nHits = ws.counters[1];
   const uint32_t nl = (uint32_t)sb->numLights;
   const uint32_t totalRays = nHits * nl;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__re
   for (;;) {
     const unsigned long long mMarch = __ballot(st == ST_MARCH);
     const unsigned long long mWait = __ballot(st == ST_NEED);
-    if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= kFlushThreshold)) {
+    if (mMarch == 0 ? (mWait != 0) : (__popcll(mWait) >= flushThreshold)) {
       if (rayCur == rayEnd && !exhausted) {
         rayCur = waveReserve(&ws.counters[2], kRayChunk);
         rayEnd = rayCur + kRayChunk;
@@ -378,6 +378,177 @@ __global__ __launch_bounds__(256) void bulb_shade_kernel(const SceneBlock *__res
     const V3 col = v3(c.x * (total.x * 8.0f), c.y * (total.y * 8.0f), c.z * (total.z * 8.0f));  // frag:2361
     // frag:2572: phong + refl + refr with refl = refr = 0
     const V3 fc = v3((col.x + 0.0f) + 0.0f, (col.y + 0.0f) + 0.0f, (col.z + 0.0f) + 0.0f);
+    out[pix] = make_float4(fc.x, fc.y, fc.z, (1.0f + 0.0f) + 0.0f);
+    if (bright) {
+      const float lum = dot(fc, v3(0.2126f, 0.7152f, 0.0722f));  // frag:1938-1946
+      bright[pix] = (lum > 1.0f) ? make_float4(fc.x, fc.y, fc.z, 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    }
+  }
+}
+
+// =====================================================================================================
+// Variant B: the same four stages with plain nested loops (no per-lane state machine).  Stage 1 keeps the
+// one-lane-per-pixel 8×8 tile mapping of rm::render_kernel but only marches the primary ray; hits are
+// compacted (block-aggregated atomic), so stages 2-4 run on dense waves, and stage 2 also compacts, per
+// light, the shadow rays that can matter (N·L > 0.005).
+// =====================================================================================================
+struct BulbWsB {
+  uint32_t *counters;  // [1] hits, [4+i] shadow rays of light i
+  int *hitPix;
+  float4 *hitRec, *surfP, *surfN;
+  int2 *shadow;        // [light·cap + hit]
+  uint32_t *rayHit;    // [light·cap + k] → hit index of the k-th marched ray of that light
+  uint32_t cap;        // hit capacity (pixels of the launch)
+};
+
+// Block-aggregated append: returns this lane's slot (valid only where `want`), one atomic per block.
+RM_DEV uint32_t blockAppend(bool want, uint32_t *counter, uint32_t *ldsScratch /* >= 5 words */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(want);
+  if (lane == 0) ldsScratch[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = ldsScratch[0] + ldsScratch[1] + ldsScratch[2] + ldsScratch[3];
+    ldsScratch[4] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = ldsScratch[4];
+  for (int w = 0; w < wave; w++) base += ldsScratch[w];
+  const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();  // scratch may be reused by the next call
+  return slot;
+}
+
+__global__ __launch_bounds__(256) void bulbB_primary_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                             int nRows, float4 *__restrict__ out,
+                                                             float4 *__restrict__ bright, BulbWsB ws) {
+  __shared__ uint32_t scratch[8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = blockIdx.x * 32 + wave * 8 + (lane & 7);
+  const int r = blockIdx.y * 8 + (lane >> 3);
+  const bool inside = x < W && r < nRows;
+  bool hit = false;
+  MarchRes res;
+  res.obj = -1; res.d = 0.0f; res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (inside) {
+    float ndcx, ndcy;
+    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+    V3 ro, rd;
+    primaryRay(sb, ndcx, ndcy, ro, rd);
+    Counters cnt{0, 0};
+    res = march<true, false, false>(sb, ro, rd, sb->cam.initialFar, 1.0f, cnt);  // frag:2322
+    hit = res.obj != -1;
+    if (!hit) {
+      const V3 bg = backgroundColor(sb);
+      const size_t o = (size_t)r * W + x;
+      out[o] = make_float4(bg.x, bg.y, bg.z, 1.0f);
+      if (bright) bright[o] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    }
+  }
+  const uint32_t slot = blockAppend(hit, &ws.counters[1], scratch);
+  if (hit) {
+    ws.hitPix[slot] = r * W + x;
+    ws.hitRec[slot] = make_float4(res.d, res.trap.y, res.trap.z, res.trap.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void bulbB_surface_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                             BulbWsB ws) {
+  __shared__ uint32_t scratch[8];
+  const uint32_t nHits = ws.counters[1];
+  const int nl = sb->numLights;
+  const float far = sb->cam.initialFar;
+  Counters cnt{0, 0};
+  const uint32_t stride = gridDim.x * blockDim.x;
+  // every thread of a block runs the same number of trips so that the block-level appends stay collective
+  for (uint32_t h0 = blockIdx.x * blockDim.x; h0 < nHits; h0 += stride) {
+    const uint32_t h = h0 + threadIdx.x;
+    const bool live = h < nHits;
+    V3 p = v3(0, 0, 0), n = v3(0, 1, 0);
+    if (live) {
+      const int pix = ws.hitPix[h];
+      const float4 rec = ws.hitRec[h];
+      const int r = pix / W, x = pix - r * W;
+      float ndcx, ndcy;
+      pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+      V3 ro, rd;
+      primaryRay(sb, ndcx, ndcy, ro, rd);
+      p = madd(rd, rec.x, ro);                                             // frag:2333
+      n = getNormal<true, false>(sb, p, cnt);                              // frag:1436-1444
+      if (sb->s.features & RM_FEAT_PERLIN_BUMP) n = bumpNormal(n, p);      // frag:2334-2336
+      float ao = 1.0f;
+      if (sb->s.enableAmbientOcclusion) ao = calcAO<true, false>(sb, p, n, cnt);  // frag:1859
+      ws.surfP[h] = make_float4(p.x, p.y, p.z, ao);
+      ws.surfN[h] = make_float4(n.x, n.y, n.z, 0.0f);
+    }
+    for (int i = 0; i < nl; i++) {
+      bool want = false;
+      if (live) {
+        const LightGeom g = lightSetup(sb->lights[i], p, far);
+        want = !(dot(n, g.L) <= 0.005f);  // otherwise getPhong drops the light whatever the march finds (frag:1912)
+        if (!want) ws.shadow[(uint32_t)i * ws.cap + h] = make_int2(-1, (int)f2u(1.0f));
+      }
+      const uint32_t slot = blockAppend(want, &ws.counters[4 + i], scratch);
+      if (want) ws.rayHit[(uint32_t)i * ws.cap + slot] = h;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bulbB_shadow_kernel(const SceneBlock *__restrict__ sb, BulbWsB ws) {
+  const int nl = sb->numLights;
+  const float far = sb->cam.initialFar;
+  Counters cnt{0, 0};
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (int i = 0; i < nl; i++) {
+    const uint32_t nRays = ws.counters[4 + i];
+    const RmLight &li = sb->lights[i];  // wave-uniform
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nRays; j += stride) {
+      const uint32_t h = ws.rayHit[(uint32_t)i * ws.cap + j];
+      const float4 P = ws.surfP[h], Nn = ws.surfN[h];
+      const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
+      const LightGeom g = lightSetup(li, p, far);
+      const MarchRes sh = march<true, false, true>(sb, shadowOrigin(p, N), g.L, g.maxT, 1.0f, cnt);  // frag:1908
+      ws.shadow[(uint32_t)i * ws.cap + h] = make_int2(sh.obj, (int)f2u(sh.d));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bulbB_shade_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                           float4 *__restrict__ out, float4 *__restrict__ bright,
+                                                           BulbWsB ws) {
+  const uint32_t nHits = ws.counters[1];
+  const int nl = sb->numLights;
+  const float ka = sb->g.ka, kd = sb->g.kd, ks = sb->g.ks;
+  const float far = sb->cam.initialFar;
+  const bool soft = sb->s.enableSoftShadow != 0;
+  const RmObject &o = sb->objs[0];
+  Material mat;
+  mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
+  mat.dif = v3(o.cDiffuse[0], o.cDiffuse[1], o.cDiffuse[2]);
+  mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
+  mat.shininess = o.shininess;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
+    const int pix = ws.hitPix[h];
+    const float4 rec = ws.hitRec[h], P = ws.surfP[h], Nn = ws.surfN[h];
+    const int r = pix / W, x = pix - r * W;
+    float ndcx, ndcy;
+    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+    V3 ro, rd;
+    primaryRay(sb, ndcx, ndcy, ro, rd);
+    const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
+    const float ao = P.w;
+    V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);  // frag:1860
+    const V3 V = normalize(neg(rd));
+    for (int i = 0; i < nl; i++) {
+      const RmLight &li = sb->lights[i];
+      const LightGeom g = lightSetup(li, p, far);
+      const int2 sh = ws.shadow[(uint32_t)i * ws.cap + h];
+      V3 cur;
+      if (lightTerm(li, g, mat, N, V, kd, ks, sh.x, u2f((uint32_t)sh.y), soft, cur)) total = add(total, cur);
+    }
+    const V3 c = bulbTrapColor(rec.y, rec.z, rec.w);  // frag:2356-2360
+    const V3 col = v3(c.x * (total.x * 8.0f), c.y * (total.y * 8.0f), c.z * (total.z * 8.0f));  // frag:2361
+    const V3 fc = v3((col.x + 0.0f) + 0.0f, (col.y + 0.0f) + 0.0f, (col.z + 0.0f) + 0.0f);      // frag:2572
     out[pix] = make_float4(fc.x, fc.y, fc.z, (1.0f + 0.0f) + 0.0f);
     if (bright) {
       const float lum = dot(fc, v3(0.2126f, 0.7152f, 0.0722f));  // frag:1938-1946

@@ -440,7 +440,12 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd,
   for (int i = 0; i < nl; i++) {
     const RmLight &li = sb->lights[i];  // uniform index → scalar loads
     LightGeom g = lightSetup(li, p, far);
-    MarchRes sh = march<BULB, COUNT, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
+    // The reference marches the shadow ray first and only then drops lights with N·L <= 0.005 (frag:1908-1912);
+    // the march result of such a light is never read, so it is not marched here (COUNT keeps the reference's
+    // work so that the counters stay the algorithmic ones).
+    MarchRes sh;
+    sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
     V3 cur;
     if (lightTerm(li, g, mat, N, V, kd, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }

@@ -5,6 +5,7 @@
 // launcher copies one constant SceneBlock to the device and launches one lane per pixel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -107,6 +108,7 @@ __global__ void deinterleave_kernel(const float4 *__restrict__ in, float4 *__res
 // ---- launcher state -------------------------------------------------------------------------------------
 namespace {
 constexpr int kSlots = 8;
+constexpr int kAutoBulbPath = 1;  // what rm_set_kernel_path(0) picks for the single-Mandelbulb class (measured best)
 struct Slot {
   SceneBlock *host = nullptr;  // pinned
   SceneBlock *dev = nullptr;
@@ -126,7 +128,7 @@ struct DeviceState {
 std::mutex g_mu;
 DeviceState g_dev[64];
 bool g_timing = false;
-bool g_forceGeneric = false;  // rm_set_kernel_path(1): always use the one-lane-per-pixel kernel
+int g_kernelPath = 0;  // rm_set_kernel_path: 0 auto, 1 one-lane-per-pixel, 2 pipeline A (state machine), 3 pipeline B (plain loops)
 struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (single kernel) or 5 (pipeline K1..K4 boundaries)
 std::vector<TimedLaunch> g_timed;
 
@@ -162,11 +164,12 @@ int acquire_slot(Slot **out) {
 }
 
 // Carve the pipeline workspace for `pixels` pixels and `nl` lights out of the device allocation.
-int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, BulbWs *ws) {
+int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWsB *wsB) {
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
-  const size_t oCnt = 0, oPix = align(16), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
-               oN = oP + align(pixels * 16), oSh = oN + align(pixels * 16),
-               total = oSh + align(pixels * (size_t)(nl > 0 ? nl : 1) * 8);
+  const size_t nlq = (size_t)(nl > 0 ? nl : 1);
+  const size_t oCnt = 0, oPix = align(64), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
+               oN = oP + align(pixels * 16), oSh = oN + align(pixels * 16), oRay = oSh + align(pixels * nlq * 8),
+               total = oRay + align(pixels * nlq * 4);
   if (total > ds.wsBytes) {
     HIP_OK(hipStreamSynchronize(stream));
     if (ds.wsMem) HIP_OK(hipFree(ds.wsMem));
@@ -181,6 +184,10 @@ int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, B
   ws->surfP = reinterpret_cast<float4 *>(b + oP);
   ws->surfN = reinterpret_cast<float4 *>(b + oN);
   ws->shadow = reinterpret_cast<int2 *>(b + oSh);
+  wsB->counters = ws->counters; wsB->hitPix = ws->hitPix; wsB->hitRec = ws->hitRec; wsB->surfP = ws->surfP;
+  wsB->surfN = ws->surfN; wsB->shadow = ws->shadow;
+  wsB->rayHit = reinterpret_cast<uint32_t *>(b + oRay);
+  wsB->cap = (uint32_t)pixels;
   return RM_OK;
 }
 
@@ -255,7 +262,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   auto nonzero3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
   // The wavefront pipeline covers the single-Mandelbulb class without secondary rays; everything else (and the
   // counted variant) runs the one-lane-per-pixel kernel.  Both produce the same bits.
-  const bool pipeline = bulb && !count && !g_forceGeneric && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
+  static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
+  int path = g_kernelPath ? g_kernelPath : envPath;
+  if (path == 0) path = kAutoBulbPath;
+  const bool pipeline = bulb && !count && path != 1 && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
   TimedLaunch tl{};
@@ -275,20 +285,34 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     BulbWs ws;
+    BulbWsB wsB;
     // hit-list capacity: every pixel may hit, plus one partly used 64-slot chunk per persistent wave
     const size_t slots = (size_t)nRows * W + (size_t)kSlotChunk * ds.numCUs * 8 * 4;
-    st = bulb_workspace(ds, slots, numLights, stream, &ws);
+    st = bulb_workspace(ds, slots, numLights, stream, &ws, &wsB);
     if (st != RM_OK) return st;
-    HIP_OK(hipMemsetAsync(ws.counters, 0, 16, stream));
-    const dim3 persistent(ds.numCUs * 8), dense(ds.numCUs * 16);
+    HIP_OK(hipMemsetAsync(ws.counters, 0, 64, stream));
+    // tuning knobs for A/B runs (defaults are the measured best)
+    static const int blocksPerCU = std::getenv("RM_PIPE_BLOCKS_PER_CU") ? std::atoi(std::getenv("RM_PIPE_BLOCKS_PER_CU")) : 8;
+    static const int flushThr = std::getenv("RM_PIPE_FLUSH") ? std::atoi(std::getenv("RM_PIPE_FLUSH")) : kDefaultFlushThreshold;
+    const dim3 persistent(ds.numCUs * (blocksPerCU > 0 ? blocksPerCU : 8)), dense(ds.numCUs * 16);
     if ((st = stamp(0)) != RM_OK) return st;
-    hipLaunchKernelGGL(bulb_primary_kernel, persistent, block, 0, stream, slot->dev, map, W, H, nRows, o, b, ws);
-    if ((st = stamp(1)) != RM_OK) return st;
-    hipLaunchKernelGGL(bulb_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws);
-    if ((st = stamp(2)) != RM_OK) return st;
-    hipLaunchKernelGGL(bulb_shadow_kernel, persistent, block, 0, stream, slot->dev, ws);
-    if ((st = stamp(3)) != RM_OK) return st;
-    hipLaunchKernelGGL(bulb_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws);
+    if (path == 2) {
+      hipLaunchKernelGGL(bulb_primary_kernel, persistent, block, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, flushThr);
+      if ((st = stamp(1)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulb_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws);
+      if ((st = stamp(2)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulb_shadow_kernel, persistent, block, 0, stream, slot->dev, ws, flushThr);
+      if ((st = stamp(3)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulb_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws);
+    } else {
+      hipLaunchKernelGGL(bulbB_primary_kernel, grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsB);
+      if ((st = stamp(1)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulbB_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, wsB);
+      if ((st = stamp(2)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulbB_shadow_kernel, dense, block, 0, stream, slot->dev, wsB);
+      if ((st = stamp(3)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulbB_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, wsB);
+    }
     if ((st = stamp(4)) != RM_OK) return st;
   } else {
     if ((st = stamp(0)) != RM_OK) return st;
@@ -419,9 +443,10 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
   g_timed.clear();
   return RM_OK;
 }
-int rm_set_kernel_path(int forceGeneric) {
+int rm_set_kernel_path(int path) {
   std::lock_guard<std::mutex> lock(g_mu);
-  g_forceGeneric = forceGeneric != 0;
+  if (path < 0 || path > 3) { set_error("kernel path must be 0..3"); return RM_ERR_INVALID_ARGUMENT; }
+  g_kernelPath = path;
   return RM_OK;
 }
 

@@ -229,9 +229,10 @@ def test_mandelbrot_2d_and_julia(renderer):
     assert_bit_equal(renderer.render(tables_of(tuple(scene)), s, W, H).cpu().numpy(), ref, "julia bulb power 6")
 
 
-def test_bulb_pipeline_equals_one_lane_per_pixel_kernel(renderer):
-    """The wavefront pipeline (4 kernels) and the one-lane-per-pixel kernel are two schedules of the same
-    arithmetic: identical bits, including with a transformed bulb, a point + spot light, AO and soft shadows."""
+def test_bulb_schedules_are_bit_identical(renderer):
+    """One lane per pixel (path 1), the state-machine pipeline (2) and the plain-loop pipeline (3) are three
+    schedules of the same arithmetic: identical bits, including with a transformed bulb, a point + spot light,
+    AO and soft shadows."""
     from raymarcher_amd import lib
     W, H = 150, 83
     cam = h.make_camera((0.5, 0.8, 4.0), (-0.5, -0.8, -4.0), (0, 1, 0), 35.0, W, H)
@@ -247,15 +248,15 @@ def test_bulb_pipeline_equals_one_lane_per_pixel_kernel(renderer):
     for over in ({}, {"enableSoftShadow": 1, "enableAmbientOcclusion": 1, "fractalIters": 9, "maxSteps": 100},
                  {"features": abi.RM_FEAT_DARK_BACKGROUND, "fractalIters": 1}):
         s = abi.default_settings(**over)
-        try:
-            lib().rm_set_kernel_path(1)
-            a, ab = renderer.render(tables_of(scene), s, W, H, bright=True)
-        finally:
-            lib().rm_set_kernel_path(0)
-        b, bb = renderer.render(tables_of(scene), s, W, H, bright=True)
-        assert_bit_equal(b.cpu().numpy(), a.cpu().numpy(), f"pipeline vs generic {over}")
-        assert_bit_equal(bb.cpu().numpy(), ab.cpu().numpy(), f"pipeline vs generic bright {over}")
-        assert_bit_equal(b.cpu().numpy(), h.oracle_render(scene, s, W, H), f"pipeline vs oracle {over}")
+        ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+        for path in (1, 2, 3, 0):
+            try:
+                lib().rm_set_kernel_path(path)
+                a, ab = renderer.render(tables_of(scene), s, W, H, bright=True)
+            finally:
+                lib().rm_set_kernel_path(0)
+            assert_bit_equal(a.cpu().numpy(), ref, f"path {path} vs oracle {over}")
+            assert_bit_equal(ab.cpu().numpy(), ref_b, f"path {path} bright vs oracle {over}")
 
 
 # ---------------------------------------------------------------- edge cases of the boundary
