@@ -21,6 +21,7 @@
  *   UB4 unknown / CUSTOM type: object is skipped (never nearest)
  *   UB5 emissive objects / area lights: rejected by the host (out of scope)
  *   UB9 2-D mode BrightColor: (0,0,0,1)
+ *   UB10 cloudsMap leaves `nnd` unset outside the cloud: nnd = -d always (iq's original order)
  */
 #include "rm_oracle.h"
 #include "rm_math.h"
@@ -510,6 +511,304 @@ static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
   return total;
 }
 
+
+/* ---------------------------------------------------------------- procedural layers (frag:464-746, 1519-1584, 1950-2158)
+ * Compile-time #defines TERRAIN / CLOUD / SKY_BACKGROUND of the shader (frag:4-15) are runtime feature bits.
+ * GLSL evaluates `f*m2*x` left to right: (f*m2)*x — the scaled constant matrices are formed first. */
+typedef struct { float c[3][3]; } m3;   /* c[col][row] */
+static inline v3 m3_mul_v3(const m3 *M, v3 v) {
+  return V3(rm_fma(M->c[2][0], v.z, rm_fma(M->c[1][0], v.y, M->c[0][0] * v.x)),
+            rm_fma(M->c[2][1], v.z, rm_fma(M->c[1][1], v.y, M->c[0][1] * v.x)),
+            rm_fma(M->c[2][2], v.z, rm_fma(M->c[1][2], v.y, M->c[0][2] * v.x)));
+}
+static inline m3 m3_mul_m3(const m3 *A, const m3 *B) {
+  m3 R;
+  for (int c = 0; c < 3; c++) {
+    v3 col = m3_mul_v3(A, V3(B->c[c][0], B->c[c][1], B->c[c][2]));
+    R.c[c][0] = col.x; R.c[c][1] = col.y; R.c[c][2] = col.z;
+  }
+  return R;
+}
+static inline m3 m3_scale(const m3 *A, float f) {
+  m3 R;
+  for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) R.c[c][r] = f * A->c[c][r];
+  return R;
+}
+static const m3 kM3 = {{{0.00f, 0.80f, 0.60f}, {-0.80f, 0.36f, -0.48f}, {-0.60f, -0.48f, 0.64f}}};   /* frag:118-120 */
+static const m3 kM3i = {{{0.00f, -0.80f, -0.60f}, {0.80f, 0.36f, -0.48f}, {0.60f, -0.48f, 0.64f}}};  /* frag:121-123 */
+
+static inline float hash1f(float n) { return rm_fract((n * 17.0f) * rm_fract(n * 0.3183099f)); }  /* frag:467-469 */
+static inline float hash1v2(float px, float py) {                                                     /* frag:472-475 */
+  px = 50.0f * rm_fract(px * 0.3183099f);
+  py = 50.0f * rm_fract(py * 0.3183099f);
+  return rm_fract((px * py) * (px + py));
+}
+static inline float quintic(float w) { return ((w * w) * w) * rm_fma(w, rm_fma(w, 6.0f, -15.0f), 10.0f); }
+/* frag:493-502 */
+static float noiseT(float x, float y) {
+  float px = rm_floor(x), py = rm_floor(y);
+  float ux = quintic(rm_fract(x)), uy = quintic(rm_fract(y));
+  float a = hash1v2(px + 0.0f, py + 0.0f), b = hash1v2(px + 1.0f, py + 0.0f);
+  float c = hash1v2(px + 0.0f, py + 1.0f), d = hash1v2(px + 1.0f, py + 1.0f);
+  float t = rm_fma(b - a, ux, a);
+  t = rm_fma(c - a, uy, t);
+  t = rm_fma((((a - b) - c) + d) * ux, uy, t);
+  return rm_fma(2.0f, t, -1.0f);
+}
+/* frag:536-567: value noise (x) and analytic gradient (yzw) */
+static v4 noised3(v3 x) {
+  v3 p = V3(rm_floor(x.x), rm_floor(x.y), rm_floor(x.z));
+  v3 w = V3(rm_fract(x.x), rm_fract(x.y), rm_fract(x.z));
+  v3 u = V3(quintic(w.x), quintic(w.y), quintic(w.z));
+  v3 du = V3(((30.0f * w.x) * w.x) * rm_fma(w.x, w.x - 2.0f, 1.0f), ((30.0f * w.y) * w.y) * rm_fma(w.y, w.y - 2.0f, 1.0f),
+             ((30.0f * w.z) * w.z) * rm_fma(w.z, w.z - 2.0f, 1.0f));
+  float n = rm_fma(157.0f, p.z, rm_fma(317.0f, p.y, p.x));
+  float a = hash1f(n + 0.0f), b = hash1f(n + 1.0f), c = hash1f(n + 317.0f), d = hash1f(n + 318.0f);
+  float e = hash1f(n + 157.0f), f = hash1f(n + 158.0f), g = hash1f(n + 474.0f), h = hash1f(n + 475.0f);
+  float k0 = a, k1 = b - a, k2 = c - a, k3 = e - a;
+  float k4 = ((a - b) - c) + d, k5 = ((a - c) - e) + g, k6 = ((a - b) - e) + f;
+  float k7 = ((((((-a + b) + c) - d) + e) - f) - g) + h;
+  float v = rm_fma(k1, u.x, k0);
+  v = rm_fma(k2, u.y, v);
+  v = rm_fma(k3, u.z, v);
+  v = rm_fma(k4 * u.x, u.y, v);
+  v = rm_fma(k5 * u.y, u.z, v);
+  v = rm_fma(k6 * u.z, u.x, v);
+  v = rm_fma((k7 * u.x) * u.y, u.z, v);
+  float dx = rm_fma(k7 * u.y, u.z, rm_fma(k6, u.z, rm_fma(k4, u.y, k1)));
+  float dy = rm_fma(k7 * u.z, u.x, rm_fma(k4, u.x, rm_fma(k5, u.z, k2)));
+  float dz = rm_fma(k7 * u.x, u.y, rm_fma(k5, u.y, rm_fma(k6, u.x, k3)));
+  return V4(rm_fma(2.0f, v, -1.0f), (2.0f * du.x) * dx, (2.0f * du.y) * dy, (2.0f * du.z) * dz);
+}
+/* frag:630-644: f = 1.9, m2 = (0.8,0.6 | -0.6,0.8), gain .55 */
+static float fbm_9(float x, float y) {
+  const float m00 = 1.9f * 0.80f, m01 = 1.9f * 0.60f, m10 = 1.9f * -0.60f, m11 = 1.9f * 0.80f;  /* (f*m2), c[col][row] */
+  float a = 0.0f, b = 0.5f;
+  for (int i = 0; i < 9; i++) {
+    float n = noiseT(x, y);
+    a = rm_fma(b, n, a);
+    b = b * 0.55f;
+    float nx = rm_fma(m10, y, m00 * x), ny = rm_fma(m11, y, m01 * x);
+    x = nx; y = ny;
+  }
+  return a;
+}
+/* frag:647-667 */
+static v4 fbmd_8(v3 x) {
+  const m3 fm3 = m3_scale(&kM3, 2.0f), fm3i = m3_scale(&kM3i, 2.0f);
+  float a = 0.0f, b = 0.5f;
+  v3 d = V3(0.0f, 0.0f, 0.0f);
+  m3 m = {{{1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, 0.0f, 1.0f}}};
+  for (int i = 0; i < 8; i++) {
+    v4 n = noised3(x);
+    a = rm_fma(b, n.x, a);
+    if (i < 4) {
+      m3 bm = m3_scale(&m, b);
+      d = v3_add(d, m3_mul_v3(&bm, V3(n.y, n.z, n.w)));
+    }
+    b = b * 0.65f;
+    x = m3_mul_v3(&fm3, x);
+    m = m3_mul_m3(&fm3i, &m);
+  }
+  return V4(a, d.x, d.y, d.z);
+}
+/* frag:737-746 */
+static v2 sdTerrain(float px, float pz) {
+  float e = fbm_9(px / 2000.0f + 1.0f, pz / 2000.0f + -2.0f);
+  float a = 1.0f - rm_smoothstep(0.12f, 0.13f, rm_abs(e + 0.12f));
+  e = rm_fma(600.0f, e, 600.0f);
+  e = rm_fma(90.0f, rm_smoothstep(552.0f, 594.0f, e), e);
+  v2 r = {e, a};
+  return r;
+}
+/* frag:1529-1584, timeOfDay = 0.1 */
+static v3 getSunDir(void) {
+  float ang = rm_mix(0.0f, 3.14f, 0.1f);
+  return normalize3(V3(rm_cos(ang), rm_sin(ang), -0.577f));
+}
+static v3 getSkyColor(void) {
+  v3 c = mix3(V3(1.0f, 0.5f, 0.2f), V3(0.8f, 0.9f, 1.1f), rm_smoothstep(0.0f, 0.2f, 0.1f));
+  return mix3(c, V3(1.0f, 0.8f, 0.5f), rm_smoothstep(0.8f, 1.0f, 0.1f));
+}
+static v3 getSunColor(void) {
+  v3 c = mix3(V3(1.0f, 0.5f, 0.2f), V3(1.0f, 1.0f, 0.8f), rm_smoothstep(0.0f, 0.2f, 0.1f));
+  return mix3(c, V3(1.0f, 0.8f, 0.5f), rm_smoothstep(0.8f, 1.0f, 0.1f));
+}
+static v3 getSky(v3 rd) {
+  v3 col = v3_scale(getSkyColor(), rm_fma(0.4f, rd.y, 0.6f));
+  float s = rm_pow(rm_clamp(dot3(rd, getSunDir()), 0.0f, 1.0f), 32.0f);
+  return v3_madd(getSunColor(), s, col);
+}
+/* frag:1519-1523 */
+static v3 fog(v3 col, float t) {
+  float k = (-t) * 0.00025f;
+  v3 ext = V3(rm_exp2(k * 1.0f), rm_exp2(k * 1.5f), rm_exp2(k * 4.0f));
+  return V3(rm_fma(1.0f - ext.x, 0.55f, col.x * ext.x), rm_fma(1.0f - ext.y, 0.55f, col.y * ext.y),
+            rm_fma(1.0f - ext.z, 0.58f, col.z * ext.z));
+}
+/* frag:1950-1959 */
+static v4 cloudsFbm(const Ctx *c, v3 pos) {
+  const float it = c->g.iTime;
+  v3 q = V3(rm_fma(0.07f, it, rm_fma(pos.x, 0.0015f, 2.0f)), rm_fma(0.07f, 0.5f * it, rm_fma(pos.y, 0.0015f, 1.1f)),
+            rm_fma(0.07f, -0.15f * it, rm_fma(pos.z, 0.0015f, 1.0f)));
+  return fbmd_8(q);
+}
+static float cloudsShadowFlat(const Ctx *c, v3 ro, v3 rd) {
+  float t = (900.0f - ro.y) / rd.y;
+  if (t < 0.0f) return 1.0f;
+  return cloudsFbm(c, v3_madd(rd, t, ro)).x;
+}
+/* frag:1961-1974.  UB10: the reference leaves `nnd` unset when d > 0 although cloudMarch reads it for the sun
+ * sample (frag:1994-1995); iq's original sets nnd = -d before the early return, which is what is done here. */
+static v4 cloudsMap(const Ctx *c, v3 pos, float *nnd) {
+  float d = rm_abs(pos.y - 900.0f) - 4.0f;
+  float gy = rm_sign(pos.y - 900.0f);
+  v4 n = cloudsFbm(c, pos);
+  d = rm_fma(400.0f * n.x, rm_fma(0.3f, gy, 0.7f), d);
+  *nnd = -d;
+  if (d > 0.0f) return V4(-d, 0.0f, 0.0f, 0.0f);
+  d = rm_min(-d / 100.0f, 0.25f);
+  return V4(d, 0.0f, gy, 0.0f);
+}
+/* frag:1976-2026 */
+static int cloudMarch(const Ctx *c, int steps, v3 ro, v3 rd, float minT, float maxT, v4 *sum) {
+  int hasHit = 0;
+  float t = minT, lastT = -1.0f, thickness = 0.0f;
+  const v3 sunColor = getSunColor(), sunDir = getSunDir();
+  for (int i = 0; i < steps; i++) {
+    v3 pos = v3_madd(rd, t, ro);
+    float nnd;
+    v4 denGra = cloudsMap(c, pos, &nnd);
+    float den = denGra.x;
+    float dt = rm_max(0.3f, 0.011f * t);
+    if (den > 0.001f) {
+      hasHit = 1;
+      float kk;
+      cloudsMap(c, v3_madd(sunDir, 70.0f, pos), &kk);
+      float sha = 1.0f - rm_smoothstep(-200.0f, 200.0f, kk);
+      sha = sha * 1.5f;
+      v3 nor = normalize3(V3(denGra.y, denGra.z, denGra.w));
+      float dif = rm_clamp(rm_fma(0.6f, dot3(nor, sunDir), 0.4f), 0.0f, 1.0f) * sha;
+      float occ = rm_fma(0.1f, 1.0f - den, rm_fma(0.7f, rm_max(1.0f - kk / 200.0f, 0.0f), 0.2f));
+      float up = rm_fma(0.5f, nor.y, 0.5f), dn = rm_fma(-0.5f, nor.y, 0.5f);
+      v3 lin = V3(0.0f, 0.0f, 0.0f);
+      lin = V3(lin.x + ((0.70f * 1.0f) * up) * occ, lin.y + ((0.80f * 1.0f) * up) * occ, lin.z + ((1.00f * 1.0f) * up) * occ);
+      lin = V3(lin.x + ((0.10f * 1.0f) * dn) * occ, lin.y + ((0.40f * 1.0f) * dn) * occ, lin.z + ((0.20f * 1.0f) * dn) * occ);
+      lin = V3(lin.x + rm_fma((sunColor.x * 3.0f) * dif, occ, 0.1f), lin.y + rm_fma((sunColor.y * 3.0f) * dif, occ, 0.1f),
+               lin.z + rm_fma((sunColor.z * 3.0f) * dif, occ, 0.1f));
+      v3 col = V3(0.8f * 0.45f, 0.8f * 0.45f, 0.8f * 0.45f);
+      col = v3_mul(col, lin);
+      col = fog(col, t);
+      float alp = rm_clamp(((den * 0.5f) * 0.125f) * dt, 0.0f, 1.0f);
+      col = v3_scale(col, alp);
+      float om = 1.0f - sum->w;
+      *sum = V4(rm_fma(col.x, om, sum->x), rm_fma(col.y, om, sum->y), rm_fma(col.z, om, sum->z), rm_fma(alp, om, sum->w));
+      thickness = rm_fma(dt, den, thickness);
+      if (lastT < 0.0f) lastT = t;
+    } else {
+      dt = rm_abs(den) + 0.2f;
+    }
+    t = t + dt;
+    if (sum->w > 0.995f || t > maxT) break;
+  }
+  float glow = rm_pow(rm_clamp(dot3(sunDir, rd), 0.0f, 1.0f), 32.0f);
+  float mx = rm_max(0.0f, rm_fma(-0.0125f, thickness, 1.0f));
+  sum->x = sum->x + ((mx * sunColor.x) * 0.3f) * glow;
+  sum->y = sum->y + ((mx * sunColor.y) * 0.3f) * glow;
+  sum->z = sum->z + ((mx * sunColor.z) * 0.3f) * glow;
+  return hasHit;
+}
+/* frag:2031-2057.  The blue-noise texture blob is missing from the reference checkout, so the dither sample is 0
+ * (incomplete texture, realtimerender.cpp:405-408); FRAME = 1 (frag:131, 2385). */
+static v3 cloudRender(const Ctx *c, v3 ro, v3 rd, v3 bgCol, int *hit, float maxT) {
+  float minT = 0.0f;
+  float tl = (600.0f - ro.y) / rd.y, th = (1200.0f - ro.y) / rd.y;
+  if (tl > 0.0f) minT = rm_max(minT, tl);
+  else { *hit = 0; return bgCol; }
+  if (th > 0.0f) maxT = rm_min(maxT, th);
+  v4 sum = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  float off = (float)(1 % 64) + 0.61803398875f;
+  minT = rm_fma(0.3f, rm_fract(off + 0.0f), minT);
+  *hit = cloudMarch(c, 128, ro, rd, minT, maxT, &sum);
+  sum = V4(rm_clamp(sum.x, 0.0f, 1.0f), rm_clamp(sum.y, 0.0f, 1.0f), rm_clamp(sum.z, 0.0f, 1.0f), rm_clamp(sum.w, 0.0f, 1.0f));
+  float om = 1.0f - sum.w;
+  return V3(rm_fma(bgCol.x, om, sum.x), rm_fma(bgCol.y, om, sum.y), rm_fma(bgCol.z, om, sum.z));
+}
+/* frag:2060-2090 */
+static float raymarchTerrain(v3 ro, v3 rd, float tmin, float tmax) {
+  float tp = (700.0f - ro.y) / rd.y;
+  if (tp > 0.0f) tmax = rm_min(tmax, tp);
+  float dis = 0.0f, th = 0.0f, t = tmin, ot = t, odis = 0.0f;
+  for (int i = 0; i < 400; i++) {
+    th = 0.001f * t;
+    v3 pos = v3_madd(rd, t, ro);
+    v2 env = sdTerrain(pos.x, pos.z);
+    dis = pos.y - env.x;
+    if (dis < th) break;
+    ot = t;
+    odis = dis;
+    t = rm_fma(dis * 0.8f, rm_fma(-0.75f, env.y, 1.0f), t);
+    if (t > tmax) break;
+  }
+  if (t > tmax) return -1.0f;
+  return ot + ((th - odis) * (t - ot)) / (dis - odis);
+}
+/* frag:2106-2111 */
+static v3 terrainNormal(float px, float pz) {
+  const float e = 0.03f;
+  return normalize3(V3(sdTerrain(px - e, pz - 0.0f).x - sdTerrain(px + e, pz + 0.0f).x, 2.0f * e,
+                       sdTerrain(px - 0.0f, pz - e).x - sdTerrain(px + 0.0f, pz + e).x));
+}
+/* frag:2113-2125 */
+static float terrainShadow(v3 ro, v3 rd, float mint) {
+  float res = 1.0f, t = mint;
+  for (int i = 0; i < 32; i++) {
+    v3 pos = v3_madd(rd, t, ro);
+    v2 env = sdTerrain(pos.x, pos.z);
+    float hei = pos.y - env.x;
+    res = rm_min(res, (32.0f * hei) / t);
+    if (res < 0.0001f || pos.y > 700.0f) break;
+    t = t + rm_clamp(hei, rm_fma(t, 0.1f, 2.0f), 100.0f);
+  }
+  return rm_clamp(res, 0.0f, 1.0f);
+}
+/* frag:2128-2158: returns 1 on hit and fills col, d */
+static int terrainRender(const Ctx *c, v3 ro, v3 rd, float maxT, v3 bgCol, v3 *colOut, float *dOut) {
+  *colOut = bgCol; *dOut = maxT;
+  float res = raymarchTerrain(ro, rd, 15.0f, maxT);
+  if (!(res > 0.0f)) return 0;
+  *dOut = res;
+  v3 p = v3_madd(rd, res, ro);
+  v3 pn = terrainNormal(p.x, p.z);
+  v3 epos = V3(p.x + 0.0f, p.y + 4.8f, p.z + 0.0f);
+  const v3 sunColor = getSunColor(), sunDir = getSunDir();
+  float sha1 = terrainShadow(V3(p.x + 0.0f, p.y + 0.02f, p.z + 0.0f), sunDir, 0.02f);
+  sha1 = sha1 * rm_smoothstep(-0.325f, -0.075f, cloudsShadowFlat(c, epos, sunDir));
+  v4 fb = fbmd_8(V3(((p.x - 0.0f) * 0.15f) * 1.0f, ((p.y - 600.0f) * 0.15f) * 0.2f, ((p.z - 0.0f) * 0.15f) * 1.0f));
+  float k = (0.8f * (1.0f - rm_abs(pn.y))) * 0.8f;
+  v3 nor = normalize3(V3(rm_fma(k, fb.y, pn.x), rm_fma(k, fb.z, pn.y), rm_fma(k, fb.w, pn.z)));
+  v3 col = V3(0.18f * 0.85f, 0.12f * 0.85f, 0.10f * 0.85f);
+  col = mix3(col, V3(0.1f * 0.2f, 0.1f * 0.2f, 0.0f * 0.2f), rm_smoothstep(0.7f, 0.9f, nor.y));
+  float dif = rm_clamp(dot3(nor, sunDir), 0.0f, 1.0f) * sha1;
+  float bac = rm_clamp(dot3(normalize3(V3(-sunDir.x, 0.0f, -sunDir.z)), nor), 0.0f, 1.0f);
+  float foc = rm_clamp((p.y / 2.0f - 180.0f) / 130.0f, 0.0f, 1.0f);
+  float dom = rm_clamp(rm_fma(0.5f, nor.y, 0.5f), 0.0f, 1.0f);
+  v3 lin = mix3(V3(0.1f * 0.1f, 0.1f * 0.2f, 0.1f * 0.1f), v3_scale(sunColor, 3.0f), dom);
+  lin = V3((0.2f * lin.x) * foc, (0.2f * lin.y) * foc, (0.2f * lin.z) * foc);
+  lin = V3(rm_fma(8.5f * sunColor.x, dif, lin.x), rm_fma(8.5f * sunColor.y, dif, lin.y), rm_fma(8.5f * sunColor.z, dif, lin.z));
+  lin = V3(rm_fma((0.27f * sunColor.x) * bac, foc, lin.x), rm_fma((0.27f * sunColor.y) * bac, foc, lin.y),
+           rm_fma((0.27f * sunColor.z) * bac, foc, lin.z));
+  *colOut = v3_mul(col, lin);
+  return 1;
+}
+/* The env layers applied after a render() (frag:2444-2456, 2506-2518, 2555-2567): terrain then cloud. */
+static void envLayers(const Ctx *c, v3 ro, v3 rd, float d, v3 bgCol, int *terrainHit, int *cloudHit, v3 *tcol, v3 *ccol) {
+  float td = d;
+  *terrainHit = 0; *cloudHit = 0;
+  if (c->s.features & RM_FEAT_TERRAIN) *terrainHit = terrainRender(c, ro, rd, d, bgCol, tcol, &td);
+  if (c->s.features & RM_FEAT_CLOUD) *ccol = cloudRender(c, ro, rd, bgCol, cloudHit, td);
+}
+
 /* ---------------------------------------------------------------- render (frag:2318-2375) */
 static RenderInfo render(Ctx *c, v3 ro, v3 rd, IntersectionInfo *info, float side, float maxT, v3 bgCol) {
   RenderInfo ri;
@@ -575,14 +874,27 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
     v3 rd = normalize3(v3_sub(farC, ro));
     /* frag:2405-2419 (later #ifdefs override earlier ones) */
     v3 bgCol = V3(0.0f, 0.0f, 0.0f);
+    if (c->s.features & RM_FEAT_SKY_BACKGROUND) bgCol = getSky(rd);
     if (c->s.features & RM_FEAT_WHITE_BACKGROUND) bgCol = V3(1.0f, 1.0f, 1.0f);
     if (c->s.features & RM_FEAT_DARK_BACKGROUND) bgCol = V3(0.0f, 0.0f, 0.0f);
-    float far = c->cam->initialFar; /* frag:2425 */
+    const int env = (c->s.features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD)) != 0;
+    float far = (c->s.features & RM_FEAT_CLOUD) ? 2000.0f : c->cam->initialFar; /* frag:2422-2426 */
 
     IntersectionInfo info, oi;
     RenderInfo ri = render(c, ro, rd, &info, OUTSIDE, far, bgCol); /* frag:2443 */
-    if (ri.isEnv) { /* frag:2459-2465 */
+    int terrainHit = 0, cloudHit = 0;
+    v3 tcol = bgCol, ccol = bgCol;
+    if (env) envLayers(c, ro, rd, ri.d, bgCol, &terrainHit, &cloudHit, &tcol, &ccol); /* frag:2444-2456 */
+    if (ri.isEnv && !cloudHit && !terrainHit) { /* frag:2459-2465 */
       fragColor = ri.fragColor;
+      goto done;
+    } else if (cloudHit) { /* frag:2466-2468 */
+      fragColor = V4(ccol.x, ccol.y, ccol.z, 1.0f);
+      bright = brightOf(ccol);
+      goto done;
+    } else if (terrainHit) { /* frag:2469-2471 */
+      fragColor = V4(tcol.x, tcol.y, tcol.z, 1.0f);
+      bright = brightOf(tcol);
       goto done;
     }
     c->nHit++;
@@ -600,6 +912,12 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
                     rm_fma(r.z * SURFACE_DIST, 3.0f, info.p.z));
         fil = v3_mul(fil, cRefl);
         RenderInfo res = render(c, sro, r, &info, OUTSIDE, far, bgCol);
+        if (env) { /* frag:2506-2518: terrain, then cloud, override the bounce colour and end the loop */
+          int th, ch; v3 tc, cc;
+          envLayers(c, sro, r, res.d, bgCol, &th, &ch, &tc, &cc);
+          if (th) { res.fragColor = V4(tc.x, tc.y, tc.z, 1.0f); res.isEnv = 1; }
+          if (ch) { res.fragColor = V4(cc.x, cc.y, cc.z, 1.0f); res.isEnv = 1; }
+        }
         refl.x += (c->g.ks * fil.x) * res.fragColor.x;
         refl.y += (c->g.ks * fil.y) * res.fragColor.y;
         refl.z += (c->g.ks * fil.z) * res.fragColor.z;
@@ -624,6 +942,12 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
         v3 sro = V3(rm_fma(-(nExit.x * SURFACE_DIST), 5.0f, pExit.x), rm_fma(-(nExit.y * SURFACE_DIST), 5.0f, pExit.y),
                     rm_fma(-(nExit.z * SURFACE_DIST), 5.0f, pExit.z));
         RenderInfo res = render(c, sro, rdOut, &info, OUTSIDE, far, bgCol);
+        if (env) { /* frag:2555-2567 */
+          int th, ch; v3 tc, cc;
+          envLayers(c, sro, rdOut, res.d, bgCol, &th, &ch, &tc, &cc);
+          if (th) res.fragColor = V4(tc.x, tc.y, tc.z, 1.0f);
+          if (ch) res.fragColor = V4(cc.x, cc.y, cc.z, 1.0f);
+        }
         refr.x += (c->g.kt * ct.x) * res.fragColor.x;
         refr.y += (c->g.kt * ct.y) * res.fragColor.y;
         refr.z += (c->g.kt * ct.z) * res.fragColor.z;
@@ -646,8 +970,7 @@ static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, c
   if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights)) return RM_ERR_INVALID_ARGUMENT;
   if (numObjects < 0 || numLights < 0) return RM_ERR_INVALID_ARGUMENT;
   if (numObjects > RM_MAX_OBJECTS || numLights > RM_MAX_LIGHTS) return RM_ERR_CAPACITY;
-  if (s->features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA | RM_FEAT_CLOUD | RM_FEAT_TERRAIN | RM_FEAT_SKY_BACKGROUND))
-    return RM_ERR_UNSUPPORTED;
+  if (s->features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) return RM_ERR_UNSUPPORTED;
   if (s->enableSkyBox) return RM_ERR_UNSUPPORTED;
   for (int i = 0; i < numObjects; i++) {
     if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM) return RM_ERR_UNSUPPORTED;
@@ -709,6 +1032,24 @@ int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, 
   for (int i = 0; i < n; i++) {
     SceneMin m = sdScene(&c, V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     out[4 * i] = m.minD; out[4 * i + 1] = (float)m.minObjIdx; out[4 * i + 2] = m.trap.y; out[4 * i + 3] = m.trap.z;
+  }
+  return RM_OK;
+}
+
+/* procedural-layer probes: kind 0 cloudsFbm → (value, gradient), 1 cloudsMap → (density, gra.y, nnd, 0),
+ * 2 sdTerrain(p.xz) → (height, slope flag, 0, 0) */
+int rmo_probe_env(int kind, float iTime, const float *pts, float *out, int n) {
+  Ctx c;
+  memset(&c, 0, sizeof c);
+  c.g.iTime = iTime;
+  for (int i = 0; i < n; i++) {
+    v3 p = V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    v4 r = V4(0, 0, 0, 0);
+    if (kind == 0) r = cloudsFbm(&c, p);
+    else if (kind == 1) { float nnd; v4 m = cloudsMap(&c, p, &nnd); r = V4(m.x, m.z, nnd, 0.0f); }
+    else if (kind == 2) { v2 t = sdTerrain(p.x, p.z); r = V4(t.x, t.y, 0.0f, 0.0f); }
+    else return RM_ERR_INVALID_ARGUMENT;
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
   }
   return RM_OK;
 }

@@ -16,6 +16,7 @@ int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const 
 int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float *out, int n);
 int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s,
                       const float *pts, float *out, int n);
+int rmo_probe_env(int kind, float iTime, const float *pts, float *out, int n);
 uint32_t rmo_const_bits(int which);
 #ifdef __cplusplus
 }

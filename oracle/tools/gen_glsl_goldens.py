@@ -49,8 +49,38 @@ def probe_case(name, kind, scene, settings, pts):
     print("probe", name, out.shape)
 
 
+def env_cases():
+    W, H = 64, 36
+    sky_terr = abi.RM_FEAT_SKY_BACKGROUND | abi.RM_FEAT_TERRAIN
+    frame_case("env_terrain_sky", tg.env_scene(W, H), abi.default_settings(features=sky_terr), W, H)
+    frame_case("env_terrain_cloud_sky", tg.env_scene(W, H), abi.default_settings(features=sky_terr | abi.RM_FEAT_CLOUD), W, H)
+    frame_case("env_all_reflect", tg.env_scene(W, H, (0, 560, 0), (0.2, 0.3, -1)),
+               abi.default_settings(features=tg.ENV_ALL, enableReflection=1), W, H)
+    # function-level probes of the procedural layers (the defines must be on for these functions to exist)
+    orig = run_ref.build_program
+
+    def with_env(defines, consts, **kw):
+        d = dict(defines)
+        d.update({"CLOUD": True, "TERRAIN": True, "SKY_BACKGROUND": True, "WHITE_BACKGROUND": False})
+        return orig(d, consts, **kw)
+
+    run_ref.build_program = with_env
+    try:
+        rng = np.random.default_rng(7)
+        pts = np.stack([rng.uniform(-2000, 2000, 4096), rng.uniform(600, 1200, 4096), rng.uniform(-2000, 2000, 4096)], 1)
+        sc, s = tg.env_scene(8, 8), abi.default_settings(features=tg.ENV_ALL)
+        probe_case("env_cloudsfbm", "cloudsfbm", sc, s, pts)
+        probe_case("env_cloudsmap", "cloudsmap", sc, s, pts)
+        probe_case("env_terrain", "terrain", sc, s, pts)
+    finally:
+        run_ref.build_program = orig
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "env":
+        return env_cases()
+    env_cases()
     W, H = 64, 48
     WB, DB = abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND
     prims = tg.all_primitives_scene(W, H)

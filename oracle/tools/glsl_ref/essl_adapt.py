@@ -77,6 +77,9 @@ PROBE_MAIN = {
     "sdscene": "SceneMin m = sdScene(q.xyz); fragColor = vec4(m.minD, float(m.minObjIdx), m.trap.y, m.trap.z);",
     "pnoise": "fragColor = vec4(pnoise(q.xyz), 0.0, 0.0, 0.0);",
     "normal": "fragColor = vec4(getNormal(q.xyz), 0.0);",
+    "cloudsfbm": "fragColor = cloudsFbm(q.xyz);",
+    "cloudsmap": "float nn = 0.0; vec4 r = cloudsMap(q.xyz, nn); fragColor = vec4(r.x, r.z, nn, 0.0);",
+    "terrain": "vec2 e = sdTerrain(q.xz); fragColor = vec4(e.x, e.y, 0.0, 0.0);",
 }
 
 

@@ -45,6 +45,11 @@ RM_DEV V3 mix(V3 a, V3 b, float t) { return v3(mix_(a.x, b.x, t), mix_(a.y, b.y,
 
 constexpr float kSurfaceDist = 0.001f;  // frag:32
 
+}  // namespace rm
+#include "rm_env.hip.h"
+namespace rm {
+
+
 // Everything a frame needs, in one constant block (uploaded once per launch by the launcher).
 struct SceneBlock {
   RmCamera cam;
@@ -59,7 +64,7 @@ struct SceneBlock {
 struct SceneMin { int idx; float d; V4 trap; };
 struct MarchRes { int obj; float d; V4 trap; };
 struct Hit { V3 rd, p, n; int obj; };
-struct RenderOut { V3 col; int isEnv; };
+struct RenderOut { V3 col; int isEnv; float d; };
 
 // Per-lane work counters (only live in the COUNT instantiation).
 struct Counters { unsigned long long evals, iters; };
@@ -471,9 +476,11 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   if (res.obj == -1) {
     out.col = bg;
     out.isEnv = 1;
+    out.d = maxT;  // frag:2328
     return out;
   }
   out.isEnv = 0;
+  out.d = res.d;  // frag:2332
   V3 p = madd(rd, res.d, ro);
   V3 pn = getNormal<BULB, COUNT>(sb, p, cnt);
   if (sb->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p);
@@ -516,8 +523,9 @@ RM_DEV void primaryRay(const SceneBlock *sb, float ndcx, float ndcy, V3 &ro, V3 
              fma(M[14], 1.0f, fma(M[10], 1.0f, bz)) / fw);  // frag:2389
   rd = normalize(sub(fc, ro));                              // frag:2392
 }
-RM_DEV V3 backgroundColor(const SceneBlock *sb) {  // frag:2405-2419, later #ifdefs override earlier ones
+RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd = V3{0.0f, 0.0f, 0.0f}) {  // frag:2405-2419, later #ifdefs override earlier ones
   V3 bg = v3(0.0f, 0.0f, 0.0f);
+  if (sb->s.features & RM_FEAT_SKY_BACKGROUND) bg = getSky(rd);
   if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
   if (sb->s.features & RM_FEAT_DARK_BACKGROUND) bg = v3(0.0f, 0.0f, 0.0f);
   return bg;
@@ -538,13 +546,25 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   }
   V3 ro, rd;
   primaryRay(sb, ndcx, ndcy, ro, rd);
-  const V3 bg = backgroundColor(sb);
-  const float far = sb->cam.initialFar;
+  const V3 bg = backgroundColor(sb, rd);
+  const uint32_t feat = sb->s.features;
+  const bool env = (feat & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD)) != 0;
+  const float far = (feat & RM_FEAT_CLOUD) ? 2000.0f : sb->cam.initialFar;  // frag:2422-2426
+  const float iTime = sb->g.iTime;
 
   Hit info;
   RenderOut ri = render<BULB, COUNT>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
-  if (ri.isEnv) {  // frag:2459-2465
+  bool terrainHit = false, cloudHit = false;
+  V3 tcol = bg, ccol = bg;
+  if (env) envLayers(feat, iTime, ro, rd, ri.d, bg, terrainHit, cloudHit, tcol, ccol);  // frag:2444-2456
+  if (ri.isEnv && !cloudHit && !terrainHit) {  // frag:2459-2465
     fragColor = v4(ri.col.x, ri.col.y, ri.col.z, 1.0f);
+    return;
+  }
+  if (cloudHit || terrainHit) {  // frag:2466-2471: cloud wins over terrain
+    V3 c = cloudHit ? ccol : tcol;
+    fragColor = v4(c.x, c.y, c.z, 1.0f);
+    if (dot(c, v3(0.2126f, 0.7152f, 0.0722f)) > 1.0f) bright = v4(c.x, c.y, c.z, 1.0f);
     return;
   }
   hitFlag = true;
@@ -564,6 +584,12 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
                   fma(r.z * kSurfaceDist, 3.0f, info.p.z));
       fil = mul(fil, cRefl);
       RenderOut res = render<BULB, COUNT>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
+      if (env) {  // frag:2506-2518
+        bool th, ch; V3 tc, cc;
+        envLayers(feat, iTime, sro, r, res.d, bg, th, ch, tc, cc);
+        if (th) { res.col = tc; res.isEnv = 1; }
+        if (ch) { res.col = cc; res.isEnv = 1; }
+      }
       refl.x += (sb->g.ks * fil.x) * res.col.x;
       refl.y += (sb->g.ks * fil.y) * res.col.y;
       refl.z += (sb->g.ks * fil.z) * res.col.z;
@@ -583,6 +609,12 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
       V3 sro = v3(fma(-(nExit.x * kSurfaceDist), 5.0f, pExit.x), fma(-(nExit.y * kSurfaceDist), 5.0f, pExit.y),
                   fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
       RenderOut res = render<BULB, COUNT>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
+      if (env) {  // frag:2555-2567
+        bool th, ch; V3 tc, cc;
+        envLayers(feat, iTime, sro, rdOut, res.d, bg, th, ch, tc, cc);
+        if (th) res.col = tc;
+        if (ch) res.col = cc;
+      }
       refr.x += (sb->g.kt * cRefr.x) * res.col.x;
       refr.y += (sb->g.kt * cRefr.y) * res.col.y;
       refr.z += (sb->g.kt * cRefr.z) * res.col.z;

@@ -205,8 +205,7 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
     set_error("negative loop bound in RmSettings");
     return RM_ERR_INVALID_ARGUMENT;
   }
-  const uint32_t unsupported = RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA | RM_FEAT_CLOUD | RM_FEAT_TERRAIN |
-                               RM_FEAT_SKY_BACKGROUND;
+  const uint32_t unsupported = RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA;
   if ((s->features & unsupported) || s->enableSkyBox) {
     set_error("feature mask / skybox outside the implemented hot-path scope");
     return RM_ERR_UNSUPPORTED;
@@ -265,7 +264,8 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
   int path = g_kernelPath ? g_kernelPath : envPath;
   if (path == 0) path = kAutoBulbPath;
-  const bool pipeline = bulb && !count && path != 1 && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
+  const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND)) != 0;
+  const bool pipeline = bulb && !count && path != 1 && !envFeatures && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
   TimedLaunch tl{};
