@@ -80,6 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raymarcher_amd import Renderer, abi, lib, scenes
+    from raymarcher_amd.dist import ShardPlan, gather_to_root
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,8 +97,8 @@ def main():
     tables = scenes.mandelbulb(W, H)
     settings = abi.default_settings(fractalIters=FRACTAL_ITERS)
     L = lib()
-    my_rows = L.rm_shard_rows(H, TILE_ROWS, rank, world)
-    slot_rows = L.rm_shard_rows(H, TILE_ROWS, 0, world)  # shard 0 owns the most rows → equal gather slots
+    plan = ShardPlan(H, TILE_ROWS, world)
+    my_rows, slot_rows = plan.rows(rank), plan.slot_rows  # shard 0 owns the most rows → equal gather slots
     mine = torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device)
     gathered = torch.empty((world * slot_rows, W, 4), dtype=torch.float32, device=r.device) if (distributed and rank == 0) else None
     frame_holder = {}
@@ -107,11 +108,9 @@ def main():
             frame_holder["f"] = r.render(tables, settings, W, H, out=mine)
             return
         r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=mine[:my_rows])
+        g = gather_to_root(mine, plan, rank, gathered)  # RCCL gather over xGMI
         if rank == 0:
-            dist.gather(mine, list(gathered.view(world, slot_rows, W, 4).unbind(0)), dst=0)
-            frame_holder["f"] = r.deinterleave(gathered, W, H, TILE_ROWS, world, slot_rows)
-        else:
-            dist.gather(mine, None, dst=0)
+            frame_holder["f"] = r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows)
 
     def fence():
         torch.cuda.synchronize(r.device)

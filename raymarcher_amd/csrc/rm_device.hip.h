@@ -523,7 +523,13 @@ RM_DEV void primaryRay(const SceneBlock *sb, float ndcx, float ndcy, V3 &ro, V3 
              fma(M[14], 1.0f, fma(M[10], 1.0f, bz)) / fw);  // frag:2389
   rd = normalize(sub(fc, ro));                              // frag:2392
 }
-RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd = V3{0.0f, 0.0f, 0.0f}) {  // frag:2405-2419, later #ifdefs override earlier ones
+RM_DEV V3 backgroundColor(const SceneBlock *sb) {  // frag:2405-2419 without SKY_BACKGROUND; later #ifdefs override earlier ones
+  V3 bg = v3(0.0f, 0.0f, 0.0f);
+  if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
+  if (sb->s.features & RM_FEAT_DARK_BACKGROUND) bg = v3(0.0f, 0.0f, 0.0f);
+  return bg;
+}
+RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
   V3 bg = v3(0.0f, 0.0f, 0.0f);
   if (sb->s.features & RM_FEAT_SKY_BACKGROUND) bg = getSky(rd);
   if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
@@ -532,7 +538,9 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd = V3{0.0f, 0.0f, 0.0f}) { 
 }
 
 // raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
-template <bool BULB, bool COUNT>
+// ENV = false compiles the procedural layers out (the launcher picks the instantiation from the feature bits),
+// so the common kernels do not carry their registers and code.
+template <bool BULB, bool COUNT, bool ENV>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
                        V4 &bright, Counters &cnt, bool &hitFlag) {
   float ndcx, ndcy;
@@ -546,10 +554,10 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   }
   V3 ro, rd;
   primaryRay(sb, ndcx, ndcy, ro, rd);
-  const V3 bg = backgroundColor(sb, rd);
+  const V3 bg = ENV ? backgroundColor(sb, rd) : backgroundColor(sb);
   const uint32_t feat = sb->s.features;
-  const bool env = (feat & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD)) != 0;
-  const float far = (feat & RM_FEAT_CLOUD) ? 2000.0f : sb->cam.initialFar;  // frag:2422-2426
+  const bool env = ENV && (feat & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD)) != 0;
+  const float far = (ENV && (feat & RM_FEAT_CLOUD)) ? 2000.0f : sb->cam.initialFar;  // frag:2422-2426
   const float iTime = sb->g.iTime;
 
   Hit info;

@@ -19,7 +19,7 @@ namespace rm {
 // Block = 4 waves side by side, each wave an 8×8 pixel tile → the block covers 32×8 pixels.
 constexpr int kBlockW = 32, kBlockH = 8;
 
-template <bool BULB, bool COUNT>
+template <bool BULB, bool COUNT, bool ENV>
 __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
   V4 col, br;
   Counters cnt{0, 0};
   bool hit;
-  shadePixel<BULB, COUNT>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, COUNT, ENV>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -316,12 +316,16 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if ((st = stamp(4)) != RM_OK) return st;
   } else {
     if ((st = stamp(0)) != RM_OK) return st;
-    if (bulb) {
-      if (count) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-      else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    // instantiations: {bulb class, generic} × {plain, counted} without the procedural layers; generic with them
+    if (envFeatures) {
+      if (count) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      else hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    } else if (bulb) {
+      if (count) hipLaunchKernelGGL((render_kernel<true, true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      else hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
     } else {
-      if (count) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-      else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      if (count) hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
     }
     if ((st = stamp(1)) != RM_OK) return st;
   }

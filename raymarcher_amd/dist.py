@@ -1,0 +1,56 @@
+"""Row-tile sharding of one frame over the GPUs of a node: one process per GPU, no data-path collective while
+rendering, one gather of the packed tiles to rank 0 (RCCL over xGMI with the "nccl" backend; "gloo" in the CPU
+tests).  The reference renders whole frames on one GPU; this layer has no counterpart there.
+
+Partition: the frame is cut into tiles of `tile_rows` rows, rank r owns tiles t ≡ r (mod world) — the bulb sits in
+the middle of the image, contiguous bands would give the middle GPUs several times the work of the outer ones.
+"""
+from dataclasses import dataclass
+
+from ._lib import lib
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    H: int
+    tile_rows: int
+    world: int
+
+    def rows(self, rank):
+        """Rows rank `rank` renders (rm_shard_rows)."""
+        return lib().rm_shard_rows(self.H, self.tile_rows, rank, self.world)
+
+    @property
+    def slot_rows(self):
+        """Rows of one gather slot: shard 0 always owns the most rows, so every slot is sized for it."""
+        return self.rows(0)
+
+    def frame_rows(self, rank):
+        """Frame row of each packed row of `rank` (rm_shard_row_to_frame)."""
+        L = lib()
+        return [L.rm_shard_row_to_frame(self.H, self.tile_rows, rank, self.world, r) for r in range(self.rows(rank))]
+
+
+def gather_to_root(local_slot, plan, rank, gathered=None):
+    """dist.gather of equal-sized slots to rank 0.  `local_slot`: (slot_rows, W, 4) tensor whose first
+    plan.rows(rank) rows are valid.  Returns the (world·slot_rows, W, 4) tensor on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if rank == 0:
+        if gathered is None:
+            gathered = torch.empty((plan.world * plan.slot_rows,) + tuple(local_slot.shape[1:]), dtype=local_slot.dtype,
+                                   device=local_slot.device)
+        dist.gather(local_slot, list(gathered.view(plan.world, plan.slot_rows, *local_slot.shape[1:]).unbind(0)), dst=0)
+        return gathered
+    dist.gather(local_slot, None, dst=0)
+    return None
+
+
+def deinterleave_host(gathered, plan):
+    """Index-map de-interleave for host tensors (the GPU path is rm_deinterleave)."""
+    import torch
+    frame = torch.empty((plan.H,) + tuple(gathered.shape[1:]), dtype=gathered.dtype)
+    for k in range(plan.world):
+        rows = plan.frame_rows(k)
+        frame[torch.tensor(rows, dtype=torch.long)] = gathered[k * plan.slot_rows:k * plan.slot_rows + len(rows)]
+    return frame

@@ -1,0 +1,53 @@
+"""Multi-process path on CPU: world_size-2 (and 3) gloo groups run the same shard → gather → de-interleave logic
+bench.py uses with RCCL, with the oracle standing in for the GPU render (tests may use the oracle)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import helpers as h
+from raymarcher_amd import abi
+from raymarcher_amd.dist import ShardPlan, gather_to_root, deinterleave_host
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+W, H, T = 40, 50, 8            # last tile is partial
+plan = ShardPlan(H, T, world)
+scene = h.scene_mandelbulb(W, H)
+s = abi.default_settings(fractalIters=12)
+rows = plan.frame_rows(rank)
+slot = torch.zeros((plan.slot_rows, W, 4), dtype=torch.float32)
+for i, y in enumerate(rows):     # render this rank's rows with the oracle (one call per contiguous tile would also do)
+    slot[i] = torch.from_numpy(h.oracle_render(scene, s, W, H, y, y + 1, threads=1)[0])
+g = gather_to_root(slot, plan, rank)
+ok = True
+if rank == 0:
+    frame = deinterleave_host(g, plan).numpy()
+    ref = h.oracle_render(scene, s, W, H, threads=2)
+    ok = bool((frame.view(np.uint32) == ref.view(np.uint32)).all())
+    assert sum(plan.rows(k) for k in range(world)) == H
+flag = torch.tensor([1 if ok else 0])
+dist.broadcast(flag, src=0)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if int(flag.item()) == 1 else 3)
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_gather_deinterleave_gloo(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = 29400 + world + (os.getpid() % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
