@@ -104,6 +104,15 @@ typedef struct RmLight {
   int32_t twoSided;
 } RmLight;
 
+/* One object texture — objTextures[i] (frag:265), uploaded by initShapesTextures (realtimerender.cpp:267-303):
+ * RGBA8, GL_LINEAR min/mag filter, GL_REPEAT wrap, no mipmaps; rows bottom-up (the reference mirrors the image
+ * at load, raymarchscene.cpp:208).  `pixels` is a DEVICE pointer for rm_render_ex. */
+#define RM_MAX_TEXTURES 10 /* src/realtime.h:17-27 */
+typedef struct RmTexture {
+  const uint8_t *pixels;
+  int32_t width, height;
+} RmTexture;
+
 /* Camera uniforms — configureCameraUniforms, realtimerender.cpp:596-615. */
 typedef struct RmCamera {
   float invProjView[16]; /* inverse(proj·view), column-major */
@@ -141,7 +150,7 @@ void rm_settings_default(RmSettings *s);
 /* ---- library / device ---------------------------------------------------------------------- */
 int rm_abi_version(void);
 /* sizeof() of ABI struct `which` as compiled into the library (0 RmObject, 1 RmLight, 2 RmCamera, 3 RmGlobals,
- * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData; -1 otherwise) so bindings can verify layout. */
+ * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData, 8 RmTexture; -1 otherwise) so bindings can verify layout. */
 int rm_abi_sizeof(int which);
 const char *rm_status_string(int status);
 /* Thread-local text of the last failure in this thread ("" if none). */
@@ -162,6 +171,16 @@ int rm_set_device(int device);
 int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
               int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
               int rowEnd, float *d_rgba, float *d_bright, void *stream);
+
+/*
+ * rm_render_ex — rm_render with object textures: objects whose texLoc is 0..numTextures-1 take their diffuse
+ * colour from textures[texLoc] through the reference's uv maps (cube, cone, cylinder, sphere: frag:1299-1398) and
+ * getDiffuse's blend (frag:1746-1781).  Other textured primitive types are rejected (the reference indexes
+ * customTextures[texLoc-15] out of bounds for them).
+ */
+int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                 const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
+                 int rowBegin, int rowEnd, float *d_rgba, float *d_bright, void *stream);
 
 /*
  * rm_render_tiles — the multi-GPU shard of the same frame (no reference counterpart; the reference
@@ -219,7 +238,7 @@ int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *s
 /* ---- math spec probes (tests only: evaluate the device implementation of one rm_math function
  *      element-wise so it can be compared bit-for-bit with the oracle) ---------------------------- */
 enum { RM_FN_SIN = 0, RM_FN_COS, RM_FN_ACOS, RM_FN_ATAN2, RM_FN_LOG2, RM_FN_EXP2, RM_FN_POW, RM_FN_SQRT,
-       RM_FN_DIV, RM_FN_PNOISE3, RM_FN_COUNT };
+       RM_FN_DIV, RM_FN_PNOISE3, RM_FN_ASIN, RM_FN_COUNT };
 int rm_probe_math(int fn, const float *d_x, const float *d_y, const float *d_z, float *d_out, int n,
                   void *stream);
 /* Evaluate sdScene (frag:1406-1430) at n world-space points: d_out[4n] = (minD, minObjIdx, trap.y, trap.z). */
@@ -261,6 +280,12 @@ int rm_scene_globals(const RmScene *scene, const RmHostSettings *hs, RmGlobals *
 int rm_scene_camera_data(const RmScene *scene, RmCameraData *out);
 /* Texture file referenced by object i, or NULL (kept for callers; textures are not rendered yet). */
 const char *rm_scene_object_texture(const RmScene *scene, int i);
+
+/* Image file → RGBA8 (stands in for QImage::load + convertToFormat(RGBA8888) + mirrored(), raymarchscene.cpp:198-209).
+ * PNG only (8/16-bit grey, grey+alpha, RGB, RGBA, palette; non-interlaced).  flipVertical = 1 gives the bottom-up
+ * rows the renderer expects.  *outPixels is malloc'ed host memory of w·h·4 bytes; free with rm_image_free. */
+int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *w, int *h);
+void rm_image_free(uint8_t *pixels);
 
 /* PNG writer for RGBA8 rows (top row first) — stands in for QImage::save (realtime.cpp:346). */
 int rm_write_png(const char *path, const uint8_t *rgba, int W, int H);

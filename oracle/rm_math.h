@@ -122,6 +122,22 @@ static inline float rm_acos(float x) {
   return (x > 0.0f) ? 0.0f : RM_PI;
 }
 
+/* asin(x) = sign(x)·(pi/2 − acos-branch); |x| >= 1 or NaN clamps: x > 0 → pi/2, otherwise −pi/2. */
+static inline float rm_asin(float x) {
+  float ax = fabsf(x);
+  if (ax <= 0.5f) {
+    float z = x * x;
+    return rm_fma(x * z, rm__asin_p(z), x);
+  } else if (ax < 1.0f) {
+    float z = (1.0f - ax) * 0.5f;
+    float s = sqrtf(z);
+    float as = rm_fma(s * z, rm__asin_p(z), s);
+    float r = RM_PIO2 - 2.0f * as;
+    return (x < 0.0f) ? -r : r;
+  }
+  return (x > 0.0f) ? RM_PIO2 : -RM_PIO2;
+}
+
 /* ---- atan(y, x) ----------------------------------------------------------------------------- */
 /* atan(t) = t + t·s·P(s), s = t², t ∈ [0,1]  (max rel approx err 2.1e-8) */
 static inline float rm__atan_p(float s) {

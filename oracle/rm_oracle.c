@@ -95,6 +95,8 @@ typedef struct {
   int numLights;
   RmGlobals g;
   RmSettings s;
+  const RmTexture *tex;
+  int numTex;
   uint64_t nEval, nIter, nHit; /* per-thread work counters */
 } Ctx;
 
@@ -461,10 +463,94 @@ static float angularFalloff(const RmLight *li, v3 L) {
   return 1.0f - rm_fma(-2.0f, rm_pow(t, 3.0f), 3.0f * rm_pow(t, 2.0f));
 }
 
+
+/* ---------------------------------------------------------------- textured diffuse (frag:1299-1398, 1746-1781) */
+#define TEXTURE_EPS 0.005f /* frag:37 */
+#define GL_PI 3.14159265f  /* frag:41 */
+static v2 uvMapCube(v3 p, float rU, float rV) { /* frag:1299-1333 */
+  float u, v;
+  float ax = rm_abs(p.x), ay = rm_abs(p.y), az = rm_abs(p.z);
+  float m = rm_max(rm_max(ax, ay), az);
+  if (m == ax) {
+    if (p.x < 0.0f) { u = p.z + 0.5f; v = p.y + 0.5f; } else { u = -p.z + 0.5f; v = p.y + 0.5f; }
+  } else if (m == ay) {
+    if (p.y < 0.0f) { u = p.x + 0.5f; v = p.z + 0.5f; } else { u = p.x + 0.5f; v = -p.z + 0.5f; }
+  } else {
+    if (p.z < 0.0f) { u = -p.x + 0.5f; v = p.y + 0.5f; } else { u = p.x + 0.5f; v = p.y + 0.5f; }
+  }
+  v2 r = {u * rU, v * rV};
+  return r;
+}
+static float uFromTheta(float theta) { /* frag:1346-1350 */
+  if (theta < 0.0f) return -theta / (2.0f * GL_PI);
+  return 1.0f - (theta / (2.0f * GL_PI));
+}
+static v2 uvMapCone(v3 p, float rU, float rV) { /* frag:1336-1354 */
+  float u, v;
+  if (rm_abs(p.y + 0.5f) < TEXTURE_EPS) { u = p.x + 0.5f; v = p.z + 0.5f; }
+  else { u = uFromTheta(rm_atan2(p.z, p.x)); v = p.y + 0.5f; }
+  v2 r = {u * rU, v * rV};
+  return r;
+}
+static v2 uvMapCylinder(v3 p, float rU, float rV) { /* frag:1357-1378 */
+  float u, v;
+  if (rm_abs(p.y - 0.5f) < TEXTURE_EPS) { u = p.x + 0.5f; v = -p.z + 0.5f; }
+  else if (rm_abs(p.y + 0.5f) < TEXTURE_EPS) { u = p.x + 0.5f; v = p.z + 0.5f; }
+  else { u = uFromTheta(rm_atan2(p.z, p.x)); v = p.y + 0.5f; }
+  v2 r = {u * rU, v * rV};
+  return r;
+}
+static v2 uvMapSphere(v3 p, float rU, float rV) { /* frag:1381-1398 */
+  float u = uFromTheta(rm_atan2(p.z, p.x));
+  float phi = rm_asin(p.y / 0.5f);
+  float v = phi / GL_PI + 0.5f;
+  if (v == 0.0f || v == 1.0f) u = 0.5f;
+  v2 r = {u * rU, v * rV};
+  return r;
+}
+/* texture(sampler2D, uv) for an RGBA8 texture with GL_LINEAR filtering and GL_REPEAT wrap (GL 3.3 §3.8.11),
+ * weights in binary32: mix(mix(t00,t10,a), mix(t01,t11,a), b), texel = byte / 255. */
+static inline int wrapi(float f, int n) {
+  if (!(rm_abs(f) < 1.0e9f)) f = 0.0f;
+  int i = (int)f % n;
+  return i < 0 ? i + n : i;
+}
+static v3 sampleTexture(const RmTexture *t, v2 uv) {
+  float u = rm_fma(uv.x, (float)t->width, -0.5f), v = rm_fma(uv.y, (float)t->height, -0.5f);
+  float fu = rm_floor(u), fv = rm_floor(v);
+  float a = u - fu, b = v - fv;
+  int i0 = wrapi(fu, t->width), j0 = wrapi(fv, t->height);
+  int i1 = (i0 + 1 == t->width) ? 0 : i0 + 1, j1 = (j0 + 1 == t->height) ? 0 : j0 + 1;
+  const uint8_t *p00 = t->pixels + ((size_t)j0 * t->width + i0) * 4, *p10 = t->pixels + ((size_t)j0 * t->width + i1) * 4;
+  const uint8_t *p01 = t->pixels + ((size_t)j1 * t->width + i0) * 4, *p11 = t->pixels + ((size_t)j1 * t->width + i1) * 4;
+  float c[3];
+  for (int k = 0; k < 3; k++) {
+    float lo = rm_mix((float)p00[k] / 255.0f, (float)p10[k] / 255.0f, a);
+    float hi = rm_mix((float)p01[k] / 255.0f, (float)p11[k] / 255.0f, a);
+    c[k] = rm_mix(lo, hi, b);
+  }
+  return V3(c[0], c[1], c[2]);
+}
+/* frag:1746-1781 */
+static v3 getDiffuse(const Ctx *c, const RmObject *obj, v3 p) {
+  const float kd = c->g.kd;
+  if (obj->texLoc == -1) return V3(kd * obj->cDiffuse[0], kd * obj->cDiffuse[1], kd * obj->cDiffuse[2]);
+  v3 po = xform_point(obj->invModel, p);
+  v2 uv;
+  if (obj->type == RM_CUBE) uv = uvMapCube(po, obj->repeatU, obj->repeatV);
+  else if (obj->type == RM_CONE) uv = uvMapCone(po, obj->repeatU, obj->repeatV);
+  else if (obj->type == RM_CYLINDER) uv = uvMapCylinder(po, obj->repeatU, obj->repeatV);
+  else uv = uvMapSphere(po, obj->repeatU, obj->repeatV);
+  v3 t = sampleTexture(&c->tex[obj->texLoc], uv);
+  float k = (1.0f - obj->blend) * kd;
+  return V3(rm_fma(obj->blend, t.x, k * obj->cDiffuse[0]), rm_fma(obj->blend, t.y, k * obj->cDiffuse[1]),
+            rm_fma(obj->blend, t.z, k * obj->cDiffuse[2]));
+}
+
 /* frag:1842-1933 (texLoc == -1 path of getDiffuse, frag:1749-1752; getSpecular frag:1787-1792) */
 static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
   const RmObject *obj = &c->objs[intersectObj];
-  const float ka = c->g.ka, kd = c->g.kd, ks = c->g.ks;
+  const float ka = c->g.ka, ks = c->g.ks;
   float ao = 1.0f;
   if (c->s.enableAmbientOcclusion) ao = calcAO(c, p, N);
   v3 total = V3((obj->cAmbient[0] * ka) * ao, (obj->cAmbient[1] * ka) * ao, (obj->cAmbient[2] * ka) * ao);
@@ -497,8 +583,8 @@ static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
     if (NdotL <= 0.005f) continue;
     NdotL = rm_clamp(NdotL, 0.0f, 1.0f);
     v3 lc = V3(li->color[0], li->color[1], li->color[2]);
-    v3 cur = V3(((kd * obj->cDiffuse[0]) * NdotL) * lc.x, ((kd * obj->cDiffuse[1]) * NdotL) * lc.y,
-                ((kd * obj->cDiffuse[2]) * NdotL) * lc.z);
+    v3 dif = getDiffuse(c, obj, p);
+    v3 cur = V3((dif.x * NdotL) * lc.x, (dif.y * NdotL) * lc.y, (dif.z * NdotL) * lc.z);
     v3 R = reflect3(v3_neg(L), N);
     float RdotV = rm_clamp(dot3(R, V), 0.0f, 1.0f);
     float sp = (obj->shininess == 0.0f) ? (ks * RdotV) : (ks * rm_pow(RdotV, obj->shininess));
@@ -966,7 +1052,7 @@ done:
 
 /* ---------------------------------------------------------------- public oracle API */
 static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
-                    int numLights, const RmGlobals *g, const RmSettings *s) {
+                    int numLights, const RmGlobals *g, const RmSettings *s, const RmTexture *tex, int numTex) {
   if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights)) return RM_ERR_INVALID_ARGUMENT;
   if (numObjects < 0 || numLights < 0) return RM_ERR_INVALID_ARGUMENT;
   if (numObjects > RM_MAX_OBJECTS || numLights > RM_MAX_LIGHTS) return RM_ERR_CAPACITY;
@@ -974,7 +1060,14 @@ static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, c
   if (s->enableSkyBox) return RM_ERR_UNSUPPORTED;
   for (int i = 0; i < numObjects; i++) {
     if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM) return RM_ERR_UNSUPPORTED;
-    if (objs[i].texLoc != -1 || objs[i].isEmissive) return RM_ERR_UNSUPPORTED;
+    if (objs[i].isEmissive) return RM_ERR_UNSUPPORTED;
+    if (objs[i].texLoc != -1) {
+      if (objs[i].texLoc < 0 || objs[i].texLoc >= numTex || !tex) return RM_ERR_UNSUPPORTED;
+      if (objs[i].type != RM_CUBE && objs[i].type != RM_CONE && objs[i].type != RM_CYLINDER && objs[i].type != RM_SPHERE)
+        return RM_ERR_UNSUPPORTED;
+      if (!tex[objs[i].texLoc].pixels || tex[objs[i].texLoc].width <= 0 || tex[objs[i].texLoc].height <= 0)
+        return RM_ERR_INVALID_ARGUMENT;
+    }
   }
   for (int i = 0; i < numLights; i++)
     if (lights[i].type < 0 || lights[i].type > RM_LIGHT_SPOT) return RM_ERR_UNSUPPORTED;
@@ -984,7 +1077,15 @@ static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, c
 int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *rgba,
                float *bright, RmCounters *counters, int threads) {
-  int st = validate(cam, objs, numObjects, lights, numLights, g, s);
+  return rmo_render_tex(cam, objs, numObjects, lights, numLights, g, s, NULL, 0, W, H, rowBegin, rowEnd, rgba, bright,
+                        counters, threads);
+}
+
+int rmo_render_tex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                   const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
+                   int rowBegin, int rowEnd, float *rgba, float *bright, RmCounters *counters, int threads) {
+  if (numTextures < 0 || numTextures > RM_MAX_TEXTURES) return RM_ERR_CAPACITY;
+  int st = validate(cam, objs, numObjects, lights, numLights, g, s, textures, numTextures);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || rowBegin < 0 || rowEnd > H || rowBegin > rowEnd || !rgba) return RM_ERR_INVALID_ARGUMENT;
   uint64_t nEval = 0, nIter = 0, nHit = 0;
@@ -993,7 +1094,7 @@ int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const 
   for (int y = rowBegin; y < rowEnd; y++) {
     Ctx c;
     c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
-    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0;
+    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = textures; c.numTex = numTextures;
     for (int x = 0; x < W; x++) {
       size_t o = ((size_t)(y - rowBegin) * W + x) * 4;
       shadePixel(&c, x, y, W, H, rgba + o, bright ? bright + o : NULL);
@@ -1018,6 +1119,7 @@ int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float
       case RM_FN_SQRT: out[i] = rm_sqrt(x[i]); break;
       case RM_FN_DIV: out[i] = x[i] / y[i]; break;
       case RM_FN_PNOISE3: out[i] = pnoise(V3(x[i], y[i], z[i])); break;
+      case RM_FN_ASIN: out[i] = rm_asin(x[i]); break;
       default: return RM_ERR_INVALID_ARGUMENT;
     }
   }
@@ -1028,7 +1130,7 @@ int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, 
                       const float *pts, float *out, int n) {
   Ctx c;
   c.cam = NULL; c.objs = objs; c.numObjects = numObjects; c.lights = NULL; c.numLights = 0;
-  c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0;
+  c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = NULL; c.numTex = 0;
   for (int i = 0; i < n; i++) {
     SceneMin m = sdScene(&c, V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     out[4 * i] = m.minD; out[4 * i + 1] = (float)m.minObjIdx; out[4 * i + 2] = m.trap.y; out[4 * i + 3] = m.trap.z;

@@ -26,6 +26,10 @@ SIGNATURES = {
     "rm_device_count": (C.c_int, []),
     "rm_set_device": (C.c_int, [C.c_int]),
     "rm_render": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rm_render_ex": (C.c_int, _SCENE_ARGS + [_P(abi.RmTexture), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "rm_image_load": (C.c_int, [C.c_char_p, C.c_int, _P(C.c_void_p), _P(C.c_int), _P(C.c_int)]),
+    "rm_image_free": (None, [C.c_void_p]),
     "rm_render_tiles": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]),
     "rm_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -32,7 +32,7 @@ RM_FEAT_REFERENCE_DEFAULT = RM_FEAT_WHITE_BACKGROUND | RM_FEAT_PERLIN_BUMP
 RM_OK, RM_ERR_INVALID_ARGUMENT, RM_ERR_CAPACITY, RM_ERR_UNSUPPORTED, RM_ERR_DEVICE, RM_ERR_IO, RM_ERR_PARSE = range(7)
 
 (RM_FN_SIN, RM_FN_COS, RM_FN_ACOS, RM_FN_ATAN2, RM_FN_LOG2, RM_FN_EXP2, RM_FN_POW, RM_FN_SQRT, RM_FN_DIV,
- RM_FN_PNOISE3, RM_FN_COUNT) = range(11)
+ RM_FN_PNOISE3, RM_FN_ASIN, RM_FN_COUNT) = range(12)
 
 f32 = C.c_float
 i32 = C.c_int32
@@ -52,6 +52,13 @@ class RmLight(C.Structure):
         ("type", i32), ("color", f32 * 3), ("dir", f32 * 3), ("pos", f32 * 3), ("func", f32 * 3),
         ("angle", f32), ("penumbra", f32), ("points", (f32 * 3) * 4), ("intensity", f32), ("twoSided", i32),
     ]
+
+
+RM_MAX_TEXTURES = 10
+
+
+class RmTexture(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", i32), ("height", i32)]
 
 
 class RmCamera(C.Structure):

@@ -346,12 +346,13 @@ __global__ __launch_bounds__(256) void bulb_shade_kernel(const SceneBlock *__res
   const uint32_t nHits = ws.counters[1];
   const int nl = sb->numLights;
   const float ka = sb->g.ka, kd = sb->g.kd, ks = sb->g.ks;
+  (void)kd;
   const float far = sb->cam.initialFar;
   const bool soft = sb->s.enableSoftShadow != 0;
   const RmObject &o = sb->objs[0];
   Material mat;
   mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
-  mat.dif = v3(o.cDiffuse[0], o.cDiffuse[1], o.cDiffuse[2]);
+  mat.dif = v3(sb->g.kd * o.cDiffuse[0], sb->g.kd * o.cDiffuse[1], sb->g.kd * o.cDiffuse[2]);  // getDiffuse, untextured
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void bulb_shade_kernel(const SceneBlock *__res
       const LightGeom g = lightSetup(li, p, far);
       const int2 sh = ws.shadow[(uint32_t)i * nHits + h];
       V3 cur;
-      if (lightTerm(li, g, mat, N, V, kd, ks, sh.x, u2f((uint32_t)sh.y), soft, cur)) total = add(total, cur);
+      if (lightTerm(li, g, mat, N, V, ks, sh.x, u2f((uint32_t)sh.y), soft, cur)) total = add(total, cur);
     }
     const V3 c = bulbTrapColor(rec.y, rec.z, rec.w);  // frag:2356-2360
     const V3 col = v3(c.x * (total.x * 8.0f), c.y * (total.y * 8.0f), c.z * (total.z * 8.0f));  // frag:2361
@@ -519,12 +520,13 @@ __global__ __launch_bounds__(256) void bulbB_shade_kernel(const SceneBlock *__re
   const uint32_t nHits = ws.counters[1];
   const int nl = sb->numLights;
   const float ka = sb->g.ka, kd = sb->g.kd, ks = sb->g.ks;
+  (void)kd;
   const float far = sb->cam.initialFar;
   const bool soft = sb->s.enableSoftShadow != 0;
   const RmObject &o = sb->objs[0];
   Material mat;
   mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
-  mat.dif = v3(o.cDiffuse[0], o.cDiffuse[1], o.cDiffuse[2]);
+  mat.dif = v3(sb->g.kd * o.cDiffuse[0], sb->g.kd * o.cDiffuse[1], sb->g.kd * o.cDiffuse[2]);  // getDiffuse, untextured
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256) void bulbB_shade_kernel(const SceneBlock *__re
       const LightGeom g = lightSetup(li, p, far);
       const int2 sh = ws.shadow[(uint32_t)i * ws.cap + h];
       V3 cur;
-      if (lightTerm(li, g, mat, N, V, kd, ks, sh.x, u2f((uint32_t)sh.y), soft, cur)) total = add(total, cur);
+      if (lightTerm(li, g, mat, N, V, ks, sh.x, u2f((uint32_t)sh.y), soft, cur)) total = add(total, cur);
     }
     const V3 c = bulbTrapColor(rec.y, rec.z, rec.w);  // frag:2356-2360
     const V3 col = v3(c.x * (total.x * 8.0f), c.y * (total.y * 8.0f), c.z * (total.z * 8.0f));  // frag:2361

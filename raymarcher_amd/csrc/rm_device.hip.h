@@ -59,6 +59,8 @@ struct SceneBlock {
   int32_t numLights;
   RmObject objs[RM_MAX_OBJECTS];
   RmLight lights[RM_MAX_LIGHTS];
+  RmTexture tex[RM_MAX_TEXTURES];  // device pixel pointers
+  int32_t numTextures;
 };
 
 struct SceneMin { int idx; float d; V4 trap; };
@@ -386,8 +388,76 @@ RM_DEV float angularFalloff(const RmLight &li, V3 L) {
   return (cosalpha <= cos_(li.angle)) ? 0.0f : r;
 }
 
-// Material of the hit object, fetched per lane (the index may differ across the wave).
+// Material of the hit object, fetched per lane (the index may differ across the wave).  `dif` is getDiffuse's
+// result for the shaded point: kd·cDiffuse, or its blend with the texture sample (frag:1746-1781).
 struct Material { V3 amb, dif, spec; float shininess; };
+
+// ---- textured diffuse (frag:1299-1398, 1746-1781) ---------------------------------------------------------
+constexpr float kTextureEps = 0.005f;  // frag:37
+constexpr float kGlPi = 3.14159265f;   // frag:41
+RM_DEV float uFromTheta(float theta) {  // frag:1346-1350
+  return (theta < 0.0f) ? (-theta / (2.0f * kGlPi)) : (1.0f - (theta / (2.0f * kGlPi)));
+}
+RM_DEV void uvMap(int type, V3 p, float rU, float rV, float &su, float &sv) {
+  float u, v;
+  if (type == RM_CUBE) {  // frag:1299-1333
+    float ax = fabs_(p.x), ay = fabs_(p.y), az = fabs_(p.z);
+    float m = max_(max_(ax, ay), az);
+    if (m == ax) { u = (p.x < 0.0f) ? (p.z + 0.5f) : (-p.z + 0.5f); v = p.y + 0.5f; }
+    else if (m == ay) { u = p.x + 0.5f; v = (p.y < 0.0f) ? (p.z + 0.5f) : (-p.z + 0.5f); }
+    else { u = (p.z < 0.0f) ? (-p.x + 0.5f) : (p.x + 0.5f); v = p.y + 0.5f; }
+  } else if (type == RM_SPHERE) {  // frag:1381-1398
+    u = uFromTheta(atan2_(p.z, p.x));
+    float phi = asin_(p.y / 0.5f);
+    v = phi / kGlPi + 0.5f;
+    if (v == 0.0f || v == 1.0f) u = 0.5f;
+  } else {  // cone frag:1336-1354, cylinder frag:1357-1378
+    bool top = (type == RM_CYLINDER) && (fabs_(p.y - 0.5f) < kTextureEps);
+    bool base = fabs_(p.y + 0.5f) < kTextureEps;
+    if (top) { u = p.x + 0.5f; v = -p.z + 0.5f; }
+    else if (base) { u = p.x + 0.5f; v = p.z + 0.5f; }
+    else { u = uFromTheta(atan2_(p.z, p.x)); v = p.y + 0.5f; }
+  }
+  su = u * rU;
+  sv = v * rV;
+}
+RM_DEV int wrapIndex(float f, int n) {
+  f = (fabs_(f) < 1.0e9f) ? f : 0.0f;
+  int i = (int)f % n;
+  return i < 0 ? i + n : i;
+}
+// texture(sampler2D, uv): RGBA8, GL_LINEAR, GL_REPEAT (GL 3.3 §3.8.11), weights in binary32.
+RM_DEV V3 sampleTexture(const RmTexture &t, float su, float sv) {
+  const int W = t.width, H = t.height;
+  float u = fma(su, (float)W, -0.5f), v = fma(sv, (float)H, -0.5f);
+  float fu = floor_(u), fv = floor_(v);
+  float a = u - fu, b = v - fv;
+  int i0 = wrapIndex(fu, W), j0 = wrapIndex(fv, H);
+  int i1 = (i0 + 1 == W) ? 0 : i0 + 1, j1 = (j0 + 1 == H) ? 0 : j0 + 1;
+  const uchar4 *px = reinterpret_cast<const uchar4 *>(t.pixels);
+  uchar4 p00 = px[(size_t)j0 * W + i0], p10 = px[(size_t)j0 * W + i1], p01 = px[(size_t)j1 * W + i0], p11 = px[(size_t)j1 * W + i1];
+  V3 lo = v3(mix_((float)p00.x / 255.0f, (float)p10.x / 255.0f, a), mix_((float)p00.y / 255.0f, (float)p10.y / 255.0f, a),
+             mix_((float)p00.z / 255.0f, (float)p10.z / 255.0f, a));
+  V3 hi = v3(mix_((float)p01.x / 255.0f, (float)p11.x / 255.0f, a), mix_((float)p01.y / 255.0f, (float)p11.y / 255.0f, a),
+             mix_((float)p01.z / 255.0f, (float)p11.z / 255.0f, a));
+  return v3(mix_(lo.x, hi.x, b), mix_(lo.y, hi.y, b), mix_(lo.z, hi.z, b));
+}
+// frag:1746-1781.  `o` is the per-lane object record (LDS copy).
+template <bool TEX>
+RM_DEV V3 getDiffuse(const SceneBlock *sb, const RmObject &o, V3 p) {
+  const float kd = sb->g.kd;
+  V3 plain = v3(kd * o.cDiffuse[0], kd * o.cDiffuse[1], kd * o.cDiffuse[2]);
+  if (!TEX) return plain;
+  if (o.texLoc == -1) return plain;
+  const float *M = o.invModel;
+  V3 po = v3(fma(M[8], p.z, fma(M[4], p.y, fma(M[0], p.x, M[12]))), fma(M[9], p.z, fma(M[5], p.y, fma(M[1], p.x, M[13]))),
+             fma(M[10], p.z, fma(M[6], p.y, fma(M[2], p.x, M[14]))));
+  float su, sv;
+  uvMap(o.type, po, o.repeatU, o.repeatV, su, sv);
+  V3 t = sampleTexture(sb->tex[o.texLoc], su, sv);
+  float k = (1.0f - o.blend) * kd;
+  return v3(fma(o.blend, t.x, k * o.cDiffuse[0]), fma(o.blend, t.y, k * o.cDiffuse[1]), fma(o.blend, t.z, k * o.cDiffuse[2]));
+}
 
 // Per-light geometry of getPhong (frag:1864-1880): direction to the light, shadow-march range, attenuation,
 // spot falloff.  `li` is read with a wave-uniform index (scalar loads).
@@ -415,13 +485,13 @@ RM_DEV V3 shadowOrigin(V3 p, V3 N) {
 }
 // One light's contribution (frag:1910-1928) given the shadow-march result; returns false if the light is
 // skipped (occluded, or N·L <= 0.005).
-RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat, V3 N, V3 V, float kd, float ks,
+RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat, V3 N, V3 V, float ks,
                       int shadowObj, float pen, bool soft, V3 &cur) {
   float NdotL = dot(N, g.L);
   bool lit = (shadowObj == -1) && !(NdotL <= 0.005f);
   NdotL = clamp_(NdotL, 0.0f, 1.0f);
   V3 lc = v3(li.color[0], li.color[1], li.color[2]);
-  cur = v3(((kd * mat.dif.x) * NdotL) * lc.x, ((kd * mat.dif.y) * NdotL) * lc.y, ((kd * mat.dif.z) * NdotL) * lc.z);
+  cur = v3((mat.dif.x * NdotL) * lc.x, (mat.dif.y * NdotL) * lc.y, (mat.dif.z * NdotL) * lc.z);
   V3 R = reflect(neg(g.L), N);
   float RdotV = clamp_(dot(R, V), 0.0f, 1.0f);
   float sp = (mat.shininess == 0.0f) ? (ks * RdotV) : (ks * pow_(RdotV, mat.shininess));
@@ -434,7 +504,7 @@ RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
 template <bool BULB, bool COUNT>
 RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
-  const float ka = sb->g.ka, kd = sb->g.kd, ks = sb->g.ks;
+  const float ka = sb->g.ka, ks = sb->g.ks;
   float ao = 1.0f;
   if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT>(sb, p, N, cnt);
   V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);
@@ -452,7 +522,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd,
     sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
     if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
     V3 cur;
-    if (lightTerm(li, g, mat, N, V, kd, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
+    if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
   return total;
 }
@@ -467,7 +537,7 @@ RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
 }
 
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
-template <bool BULB, bool COUNT>
+template <bool BULB, bool COUNT, bool TEX>
 RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
                         V3 bg, Counters &cnt) {
   RenderOut out;
@@ -487,7 +557,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   const RmObject &o = objs[BULB ? 0 : res.obj];
   Material mat;
   mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
-  mat.dif = v3(o.cDiffuse[0], o.cDiffuse[1], o.cDiffuse[2]);
+  mat.dif = getDiffuse<TEX>(sb, o, p);
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   const int type = BULB ? (int)RM_MANDELBULB : o.type;
@@ -540,7 +610,7 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
 // raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
 // ENV = false compiles the procedural layers out (the launcher picks the instantiation from the feature bits),
 // so the common kernels do not carry their registers and code.
-template <bool BULB, bool COUNT, bool ENV>
+template <bool BULB, bool COUNT, bool ENV, bool TEX>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
                        V4 &bright, Counters &cnt, bool &hitFlag) {
   float ndcx, ndcy;
@@ -561,7 +631,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   const float iTime = sb->g.iTime;
 
   Hit info;
-  RenderOut ri = render<BULB, COUNT>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
+  RenderOut ri = render<BULB, COUNT, TEX>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
   bool terrainHit = false, cloudHit = false;
   V3 tcol = bg, ccol = bg;
   if (env) envLayers(feat, iTime, ro, rd, ri.d, bg, terrainHit, cloudHit, tcol, ccol);  // frag:2444-2456
@@ -591,7 +661,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
       V3 sro = v3(fma(r.x * kSurfaceDist, 3.0f, info.p.x), fma(r.y * kSurfaceDist, 3.0f, info.p.y),
                   fma(r.z * kSurfaceDist, 3.0f, info.p.z));
       fil = mul(fil, cRefl);
-      RenderOut res = render<BULB, COUNT>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
+      RenderOut res = render<BULB, COUNT, TEX>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2506-2518
         bool th, ch; V3 tc, cc;
         envLayers(feat, iTime, sro, r, res.d, bg, th, ch, tc, cc);
@@ -616,7 +686,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
     if (len(rdOut) != 0.0f) {
       V3 sro = v3(fma(-(nExit.x * kSurfaceDist), 5.0f, pExit.x), fma(-(nExit.y * kSurfaceDist), 5.0f, pExit.y),
                   fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
-      RenderOut res = render<BULB, COUNT>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
+      RenderOut res = render<BULB, COUNT, TEX>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2555-2567
         bool th, ch; V3 tc, cc;
         envLayers(feat, iTime, sro, rdOut, res.d, bg, th, ch, tc, cc);

@@ -5,8 +5,10 @@
 // src/realtime.cpp:284-350 (saveViewportImage).
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -181,6 +183,110 @@ int rm_shard_row_to_frame(int H, int tileRows, int shard, int numShards, int loc
   if (localRow < 0 || localRow >= shard_rows(H, tileRows, shard, numShards)) return -1;
   return ((localRow / tileRows) * numShards + shard) * tileRows + (localRow % tileRows);
 }
+
+// ---- PNG reader (stands in for QImage::load → RGBA8888 → mirrored(), raymarchscene.cpp:198-209) ------------
+namespace {
+inline uint32_t be32r(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+inline int paeth(int a, int b, int c) {
+  int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+}  // namespace
+
+int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *w, int *h) {
+  if (!path || !outPixels || !w || !h) { set_error("null argument"); return RM_ERR_INVALID_ARGUMENT; }
+  *outPixels = nullptr;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) { set_error(std::string("could not open ") + path); return RM_ERR_IO; }
+  std::vector<uint8_t> file;
+  uint8_t buf[65536];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+  std::fclose(f);
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) {
+    set_error(std::string(path) + ": not a PNG file (only PNG textures are supported)");
+    return RM_ERR_UNSUPPORTED;
+  }
+  uint32_t W = 0, H = 0;
+  int depth = 0, ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte, trns;
+  size_t pos = 8;
+  while (pos + 12 <= file.size()) {
+    uint32_t len = be32r(&file[pos]);
+    const char *tag = reinterpret_cast<const char *>(&file[pos + 4]);
+    if (pos + 12 + (size_t)len > file.size()) { set_error("truncated PNG chunk"); return RM_ERR_PARSE; }
+    const uint8_t *d = &file[pos + 8];
+    if (!std::memcmp(tag, "IHDR", 4) && len >= 13) {
+      W = be32r(d); H = be32r(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+    } else if (!std::memcmp(tag, "PLTE", 4)) plte.assign(d, d + len);
+    else if (!std::memcmp(tag, "tRNS", 4)) trns.assign(d, d + len);
+    else if (!std::memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+    else if (!std::memcmp(tag, "IEND", 4)) break;
+    pos += 12 + (size_t)len;
+  }
+  if (W == 0 || H == 0 || W > 32768 || H > 32768) { set_error("bad PNG size"); return RM_ERR_PARSE; }
+  if (interlace != 0) { set_error("interlaced PNG not supported"); return RM_ERR_UNSUPPORTED; }
+  int channels = (ctype == 0) ? 1 : (ctype == 2) ? 3 : (ctype == 3) ? 1 : (ctype == 4) ? 2 : (ctype == 6) ? 4 : 0;
+  if (!channels || !(depth == 8 || depth == 16 || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4)) ||
+                     (ctype == 0 && (depth == 1 || depth == 2 || depth == 4)))) {
+    set_error("unsupported PNG colour type / bit depth");
+    return RM_ERR_UNSUPPORTED;
+  }
+  const size_t bpp = (size_t)std::max(1, channels * depth / 8), stride = ((size_t)W * channels * depth + 7) / 8;
+  std::vector<uint8_t> raw((stride + 1) * H);
+  uLongf rawLen = raw.size();
+  if (uncompress(raw.data(), &rawLen, idat.data(), idat.size()) != Z_OK || rawLen != raw.size()) {
+    set_error("PNG inflate failed");
+    return RM_ERR_PARSE;
+  }
+  std::vector<uint8_t> img(stride * H);
+  for (uint32_t y = 0; y < H; y++) {
+    const uint8_t *in = &raw[(stride + 1) * y];
+    uint8_t *cur = &img[stride * y];
+    const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
+    const int ft = in[0];
+    for (size_t x = 0; x < stride; x++) {
+      int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0, v = in[1 + x];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) / 2; break;
+        case 4: v += paeth(a, b, c); break;
+        default: set_error("bad PNG filter"); return RM_ERR_PARSE;
+      }
+      cur[x] = (uint8_t)v;
+    }
+  }
+  uint8_t *out = static_cast<uint8_t *>(std::malloc((size_t)W * H * 4));
+  if (!out) { set_error("out of memory"); return RM_ERR_IO; }
+  auto sample = [&](const uint8_t *row, size_t idx) -> int {  // idx-th sample of the row, scaled to 8 bits
+    if (depth == 8) return row[idx];
+    if (depth == 16) return row[idx * 2];  // high byte (what an 8-bit conversion keeps)
+    const int per = 8 / depth, shift = (per - 1 - (int)(idx % per)) * depth;
+    const int v = (row[idx / per] >> shift) & ((1 << depth) - 1);
+    return (ctype == 3) ? v : v * 255 / ((1 << depth) - 1);
+  };
+  for (uint32_t y = 0; y < H; y++) {
+    const uint8_t *row = &img[stride * y];
+    uint8_t *o = out + (size_t)(flipVertical ? (H - 1 - y) : y) * W * 4;
+    for (uint32_t x = 0; x < W; x++, o += 4) {
+      if (ctype == 3) {
+        const int i = sample(row, x);
+        if ((size_t)i * 3 + 2 >= plte.size() + 0 && (size_t)i * 3 + 2 >= plte.size()) { o[0] = o[1] = o[2] = 0; o[3] = 255; continue; }
+        o[0] = plte[i * 3]; o[1] = plte[i * 3 + 1]; o[2] = plte[i * 3 + 2];
+        o[3] = ((size_t)i < trns.size()) ? trns[i] : 255;
+      } else if (ctype == 0) { o[0] = o[1] = o[2] = (uint8_t)sample(row, x); o[3] = 255; }
+      else if (ctype == 4) { o[0] = o[1] = o[2] = (uint8_t)sample(row, x * 2); o[3] = (uint8_t)sample(row, x * 2 + 1); }
+      else if (ctype == 2) { o[0] = (uint8_t)sample(row, x * 3); o[1] = (uint8_t)sample(row, x * 3 + 1); o[2] = (uint8_t)sample(row, x * 3 + 2); o[3] = 255; }
+      else { o[0] = (uint8_t)sample(row, x * 4); o[1] = (uint8_t)sample(row, x * 4 + 1); o[2] = (uint8_t)sample(row, x * 4 + 2); o[3] = (uint8_t)sample(row, x * 4 + 3); }
+    }
+  }
+  *outPixels = out; *w = (int)W; *h = (int)H;
+  return RM_OK;
+}
+void rm_image_free(uint8_t *pixels) { std::free(pixels); }
 
 // RGBA8, filter 0 on every row, one zlib stream.
 int rm_write_png(const char *path, const uint8_t *rgba, int W, int H) {

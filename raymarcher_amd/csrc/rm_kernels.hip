@@ -19,7 +19,7 @@ namespace rm {
 // Block = 4 waves side by side, each wave an 8×8 pixel tile → the block covers 32×8 pixels.
 constexpr int kBlockW = 32, kBlockH = 8;
 
-template <bool BULB, bool COUNT, bool ENV>
+template <bool BULB, bool COUNT, bool ENV, bool TEX>
 __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
   V4 col, br;
   Counters cnt{0, 0};
   bool hit;
-  shadePixel<BULB, COUNT, ENV>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, COUNT, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -67,6 +67,7 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
     case RM_FN_SQRT: r = sqrt_(a); break;
     case RM_FN_DIV: r = a / b; break;
     case RM_FN_PNOISE3: r = pnoise(v3(a, b, c)); break;
+    case RM_FN_ASIN: r = asin_(a); break;
   }
   out[i] = r;
 }
@@ -192,7 +193,9 @@ int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, B
 }
 
 int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                   const RmGlobals *g, const RmSettings *s) {
+                   const RmGlobals *g, const RmSettings *s, const RmTexture *tex = nullptr, int numTex = 0) {
+  if (numTex < 0 || (numTex > 0 && !tex)) { set_error("bad texture table"); return RM_ERR_INVALID_ARGUMENT; }
+  if (numTex > RM_MAX_TEXTURES) { set_error("more than RM_MAX_TEXTURES textures"); return RM_ERR_CAPACITY; }
   if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights) || numObjects < 0 || numLights < 0) {
     set_error("null scene pointer or negative count");
     return RM_ERR_INVALID_ARGUMENT;
@@ -211,9 +214,24 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
     return RM_ERR_UNSUPPORTED;
   }
   for (int i = 0; i < numObjects; i++) {
-    if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM || objs[i].texLoc != -1 || objs[i].isEmissive) {
-      set_error("object " + std::to_string(i) + ": CUSTOM type, texture or emissive (area light) not supported");
+    if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM || objs[i].isEmissive) {
+      set_error("object " + std::to_string(i) + ": CUSTOM type or emissive (area light) not supported");
       return RM_ERR_UNSUPPORTED;
+    }
+    if (objs[i].texLoc != -1) {
+      const int t = objs[i].texLoc, ty = objs[i].type;
+      if (t < 0 || t >= numTex) {
+        set_error("object " + std::to_string(i) + ": texLoc without a matching texture (use rm_render_ex)");
+        return RM_ERR_UNSUPPORTED;
+      }
+      if (ty != RM_CUBE && ty != RM_CONE && ty != RM_CYLINDER && ty != RM_SPHERE) {
+        set_error("object " + std::to_string(i) + ": textures are only defined for cube, cone, cylinder, sphere");
+        return RM_ERR_UNSUPPORTED;
+      }
+      if (!tex[t].pixels || tex[t].width <= 0 || tex[t].height <= 0) {
+        set_error("texture " + std::to_string(t) + ": null pixels or empty size");
+        return RM_ERR_INVALID_ARGUMENT;
+      }
     }
   }
   for (int i = 0; i < numLights; i++) {
@@ -226,7 +244,8 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
 }
 
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut) {
+                const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut,
+                const RmTexture *tex = nullptr, int numTex = 0) {
   Slot *slot;
   int st = acquire_slot(&slot);
   if (st != RM_OK) return st;
@@ -235,6 +254,8 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   h->numObjects = numObjects; h->numLights = numLights;
   for (int i = 0; i < numObjects; i++) h->objs[i] = objs[i];
   for (int i = 0; i < numLights; i++) h->lights[i] = lights[i];
+  h->numTextures = numTex;
+  for (int i = 0; i < numTex; i++) h->tex[i] = tex[i];
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   *slotOut = slot;
   return RM_OK;
@@ -242,15 +263,16 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                   const RmGlobals *g, const RmSettings *s, int W, int H, RowMap map, int nRows, float *d_rgba,
-                  float *d_bright, hipStream_t stream, bool count, RmCounters *countersOut) {
+                  float *d_bright, hipStream_t stream, bool count, RmCounters *countersOut,
+                  const RmTexture *tex = nullptr, int numTex = 0) {
   std::lock_guard<std::mutex> lock(g_mu);
-  int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s);
+  int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s, tex, numTex);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || nRows < 0) { set_error("bad frame size"); return RM_ERR_INVALID_ARGUMENT; }
   if (nRows == 0) return RM_OK;  // empty row range: nothing to write, a null buffer is fine
   if (!d_rgba) { set_error("null output buffer"); return RM_ERR_INVALID_ARGUMENT; }
   Slot *slot;
-  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot);
+  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot, tex, numTex);
   if (st != RM_OK) return st;
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -316,17 +338,24 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if ((st = stamp(4)) != RM_OK) return st;
   } else {
     if ((st = stamp(0)) != RM_OK) return st;
-    // instantiations: {bulb class, generic} × {plain, counted} without the procedural layers; generic with them
-    if (envFeatures) {
-      if (count) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-      else hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+    // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
+    // procedural layers or textures; the generic kernel with either or both.  Features a launch does not need are
+    // compiled out so the common kernels keep their register budget.
+    bool textured = false;
+    for (int i = 0; i < numObjects; i++) textured = textured || objs[i].texLoc != -1;
+#define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
+    if (envFeatures || textured) {
+      if (envFeatures && textured) RM_LAUNCH(false, false, true, true);
+      else if (envFeatures) RM_LAUNCH(false, false, true, false);
+      else RM_LAUNCH(false, false, false, true);
     } else if (bulb) {
-      if (count) hipLaunchKernelGGL((render_kernel<true, true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-      else hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      if (count) RM_LAUNCH(true, true, false, false);
+      else RM_LAUNCH(true, false, false, false);
     } else {
-      if (count) hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-      else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      if (count) RM_LAUNCH(false, true, false, false);
+      else RM_LAUNCH(false, false, false, false);
     }
+#undef RM_LAUNCH
     if ((st = stamp(1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
@@ -365,6 +394,16 @@ int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const R
   RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
                        static_cast<hipStream_t>(stream), false, nullptr);
+}
+
+int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                 const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
+                 int rowBegin, int rowEnd, float *d_rgba, float *d_bright, void *stream) {
+  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
+  int n = rowEnd - rowBegin;
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
+                       static_cast<hipStream_t>(stream), false, nullptr, textures, numTextures);
 }
 
 int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,

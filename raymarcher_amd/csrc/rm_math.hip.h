@@ -86,6 +86,19 @@ RM_DEV float acos_(float x) {
   return (small || ax < 1.0f) ? r : edge;
 }
 
+RM_DEV float asin_(float x) {
+  float ax = fabs_(x);
+  bool small = ax <= 0.5f;
+  float z = small ? (x * x) : ((1.0f - ax) * 0.5f);
+  float s = small ? x : sqrt_(z);
+  float as = fma(s * z, asin_p(z), s);
+  float big = kPio2 - 2.0f * as;
+  big = (x < 0.0f) ? -big : big;
+  float r = small ? as : big;
+  float edge = (x > 0.0f) ? kPio2 : -kPio2;
+  return (small || ax < 1.0f) ? r : edge;
+}
+
 RM_DEV float atan_p(float s) {
   float p = fma(s, 2.920665313e-03f, -1.636782475e-02f);
   p = fma(s, p, 4.321170226e-02f);

@@ -678,6 +678,7 @@ int rm_abi_sizeof(int which) {
     case 5: return (int)sizeof(RmCounters);
     case 6: return (int)sizeof(RmHostSettings);
     case 7: return (int)sizeof(RmCameraData);
+    case 8: return (int)sizeof(RmTexture);
     default: return -1;
   }
 }

@@ -21,10 +21,24 @@ class SceneTables:
     lights: C.Array
     num_lights: int
     globals_: abi.RmGlobals
+    textures: list = None  # host uint8 arrays (H, W, 4), rows bottom-up, indexed by RmObject.texLoc
 
     def args(self, settings):
         return (C.byref(self.camera), self.objects, self.num_objects, self.lights, self.num_lights,
                 C.byref(self.globals_), C.byref(settings))
+
+
+def load_image(path, flip_vertical=True):
+    """rm_image_load → numpy uint8 (H, W, 4); flip_vertical=True gives the bottom-up rows the renderer samples
+    (QImage::mirrored at load, raymarchscene.cpp:208)."""
+    import numpy as np
+    px, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    check(lib().rm_image_load(str(path).encode(), 1 if flip_vertical else 0, C.byref(px), C.byref(w), C.byref(h)))
+    try:
+        arr = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().rm_image_free(px)
+    return arr
 
 
 def build_camera(pos, look, up, height_angle_rad, W, H, near=0.1, far=100.0):
@@ -99,7 +113,13 @@ class Scene:
         cd = self.camera_data()
         cam = abi.RmCamera()
         check(L.rm_camera_build(C.byref(cd), W, H, near, far, None, None, C.byref(cam)))
-        return SceneTables(cam, objs, no, lights, nl, g)
+        # texture slots in texLoc order (configureShapesUniforms binds them in first-use order, realtimerender.cpp:735-806)
+        textures = {}
+        for i in range(no):
+            if objs[i].texLoc >= 0 and objs[i].texLoc not in textures:
+                textures[objs[i].texLoc] = load_image(self.texture_of(i), flip_vertical=True)
+        tex_list = [textures[k] for k in sorted(textures)] if textures else None
+        return SceneTables(cam, objs, no, lights, nl, g, tex_list)
 
 
 class Renderer:
@@ -118,6 +138,25 @@ class Renderer:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _textures(self, tables):
+        """Upload (once per array) the host textures of `tables`; returns (RmTexture array, count, keep-alive)."""
+        host = tables.textures or []
+        if not host:
+            return None, 0, None
+        if not hasattr(self, "_tex_cache"):
+            self._tex_cache = {}
+        arr = (abi.RmTexture * len(host))()
+        keep = []
+        for i, a in enumerate(host):
+            key = id(a)
+            if key not in self._tex_cache:
+                self._tex_cache[key] = (a, self.torch.from_numpy(a).contiguous().to(self.device))
+            dev = self._tex_cache[key][1]
+            keep.append(dev)
+            arr[i].pixels = dev.data_ptr()
+            arr[i].height, arr[i].width = a.shape[0], a.shape[1]
+        return arr, len(host), keep
+
     def render(self, tables, settings, W, H, row_begin=0, row_end=None, bright=False, out=None):
         """rm_render: rows [row_begin,row_end) → float32 tensor (rows, W, 4), row 0 = bottom."""
         t = self.torch
@@ -126,8 +165,9 @@ class Renderer:
         if out is None:
             out = t.empty((max(n, 0), W, 4), dtype=t.float32, device=self.device)
         br = t.empty_like(out) if bright else None
-        check(lib().rm_render(*tables.args(settings), W, H, row_begin, row_end, C.c_void_p(out.data_ptr()),
-                              C.c_void_p(br.data_ptr()) if bright else None, self._stream()))
+        tex, ntex, _keep = self._textures(tables)
+        check(lib().rm_render_ex(*tables.args(settings), tex, ntex, W, H, row_begin, row_end, C.c_void_p(out.data_ptr()),
+                                 C.c_void_p(br.data_ptr()) if bright else None, self._stream()))
         return (out, br) if bright else out
 
     def render_counted(self, tables, settings, W, H):

@@ -133,14 +133,23 @@ def scene_mandelbulb(W, H):
     return cam, objs, 1, lights, 3, make_globals()
 
 
-def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=False, counters=False):
-    cam, objs, no, lights, nl, g = scene
+def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=False, counters=False, textures=None):
+    """textures: list of uint8 (H, W, 4) arrays, rows bottom-up, indexed by RmObject.texLoc."""
+    cam, objs, no, lights, nl, g = scene[:6]
     row1 = H if row1 is None else row1
     out = np.zeros((row1 - row0, W, 4), dtype=np.float32)
     br = np.zeros_like(out) if bright else None
     cnt = abi.RmCounters()
-    st = oracle().rmo_render(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(settings), W, H, row0, row1,
-                             fptr(out), fptr(br) if bright else None, C.byref(cnt), threads)
+    tex, ntex = None, 0
+    if textures:
+        ntex = len(textures)
+        tex = (abi.RmTexture * ntex)()
+        for i, a in enumerate(textures):
+            assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"] and a.shape[2] == 4
+            tex[i].pixels = a.ctypes.data
+            tex[i].height, tex[i].width = a.shape[0], a.shape[1]
+    st = oracle().rmo_render_tex(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(settings), tex, ntex, W, H,
+                                 row0, row1, fptr(out), fptr(br) if bright else None, C.byref(cnt), threads)
     assert st == 0, f"oracle status {st}"
     res = [out]
     if bright:

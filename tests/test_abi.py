@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_compiled_library():
     L = lib()
     structs = [abi.RmObject, abi.RmLight, abi.RmCamera, abi.RmGlobals, abi.RmSettings, abi.RmCounters,
-               abi.RmHostSettings, abi.RmCameraData]
+               abi.RmHostSettings, abi.RmCameraData, abi.RmTexture]
     for i, s in enumerate(structs):
         assert L.rm_abi_sizeof(i) == C.sizeof(s), s.__name__
     assert L.rm_abi_sizeof(99) == -1
@@ -93,6 +93,47 @@ def test_png_writer_roundtrip(tmp_path):
     assert lib().rm_write_png(str(p).encode(), img.ctypes.data_as(C.c_void_p), 17, 13) == 0
     assert (np.asarray(Image.open(p)) == img).all()
     assert lib().rm_write_png(b"/nonexistent_dir/x.png", img.ctypes.data_as(C.c_void_p), 17, 13) == abi.RM_ERR_IO
+
+
+@pytest.mark.parametrize("mode,bits", [("RGB", 8), ("RGBA", 8), ("L", 8), ("LA", 8), ("P", 8), ("I;16", 16), ("1", 1)])
+def test_png_reader_matches_pillow(tmp_path, mode, bits):
+    from PIL import Image
+    from raymarcher_amd.render import load_image
+    rng = np.random.default_rng(5)
+    W, H = 29, 17
+    if mode == "P":
+        im = Image.fromarray(rng.integers(0, 256, (H, W), dtype=np.uint8), "P")
+        im.putpalette(list(rng.integers(0, 256, 768)))
+    elif mode == "I;16":
+        im = Image.fromarray(rng.integers(0, 65536, (H, W)).astype(np.uint16))
+    elif mode == "1":
+        im = Image.fromarray(rng.integers(0, 2, (H, W)).astype(bool))
+    else:
+        ch = {"RGB": 3, "RGBA": 4, "L": 1, "LA": 2}[mode]
+        a = rng.integers(0, 256, (H, W, ch), dtype=np.uint8)
+        im = Image.fromarray(a[..., 0] if ch == 1 else a, mode)
+    p = tmp_path / f"t_{bits}.png"
+    im.save(p)
+    got = load_image(p, flip_vertical=False)
+    if mode == "I;16":
+        exp16 = np.asarray(Image.open(p)).astype(np.uint16)
+        exp = np.stack([exp16 >> 8] * 3 + [np.full_like(exp16, 255)], -1).astype(np.uint8)
+    else:
+        exp = np.asarray(Image.open(p).convert("RGBA"))
+    assert got.shape == (H, W, 4) and (got == exp).all()
+    assert (load_image(p, flip_vertical=True) == exp[::-1]).all()
+
+
+def test_png_reader_errors(tmp_path):
+    from raymarcher_amd import RaymarcherError
+    from raymarcher_amd.render import load_image
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"0" * 64)
+    with pytest.raises(RaymarcherError) as e:
+        load_image(tmp_path / "x.jpg")
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
+    with pytest.raises(RaymarcherError) as e:
+        load_image(tmp_path / "missing.png")
+    assert e.value.status == abi.RM_ERR_IO
 
 
 def test_no_cpu_fallback_in_the_product_path():

@@ -41,7 +41,7 @@ def _math_inputs(fn, n, rng):
         x = np.concatenate([rng.uniform(-30, 30, n // 2), rng.uniform(-1e4, 1e4, n // 4), rng.normal(0, 1e-3, n // 4)])
         x = np.concatenate([x, [0.0, -0.0, np.pi, 1e7, -1e7, np.inf, -np.inf, np.nan, 4194303.5, 4194304.0]])
         return x.astype(f), None
-    if fn == abi.RM_FN_ACOS:
+    if fn in (abi.RM_FN_ACOS, abi.RM_FN_ASIN):
         x = np.concatenate([rng.uniform(-1, 1, n), [0, 1, -1, 0.5, -0.5, 1.0000001, -1.0000001, 2, -2, np.nan, 0.49999997]])
         return x.astype(f), None
     if fn == abi.RM_FN_ATAN2:
@@ -70,7 +70,7 @@ def _math_inputs(fn, n, rng):
     raise ValueError(fn)
 
 
-@pytest.mark.parametrize("fn", [abi.RM_FN_SIN, abi.RM_FN_COS, abi.RM_FN_ACOS, abi.RM_FN_ATAN2, abi.RM_FN_LOG2,
+@pytest.mark.parametrize("fn", [abi.RM_FN_SIN, abi.RM_FN_COS, abi.RM_FN_ACOS, abi.RM_FN_ASIN, abi.RM_FN_ATAN2, abi.RM_FN_LOG2,
                                 abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV])
 def test_math_contract_bit_exact(renderer, fn):
     import torch
@@ -280,6 +280,97 @@ def test_bulb_schedules_are_bit_identical(renderer):
                 lib().rm_set_kernel_path(0)
             assert_bit_equal(a.cpu().numpy(), ref, f"path {path} vs oracle {over}")
             assert_bit_equal(ab.cpu().numpy(), ref_b, f"path {path} bright vs oracle {over}")
+
+
+def synthetic_textures():
+    """Two procedural RGBA8 textures (rows bottom-up): a 37×23 colour gradient with a grid and a 64×64 checker."""
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:23, 0:37]
+    a = np.stack([xx * 255 // 36, yy * 255 // 22, (xx * 7 + yy * 13) % 256, np.full_like(xx, 255)], -1).astype(np.uint8)
+    a[::4, :, :3] //= 2
+    yy, xx = np.mgrid[0:64, 0:64]
+    b = np.where(((xx // 8 + yy // 8) % 2)[..., None] == 0, np.array([230, 40, 40, 255]), np.array([30, 60, 220, 255])).astype(np.uint8)
+    b[..., :3] = np.clip(b[..., :3].astype(int) + rng.integers(-20, 20, (64, 64, 3)), 0, 255).astype(np.uint8)
+    return [np.ascontiguousarray(a), np.ascontiguousarray(b)]
+
+
+def textured_scene(W, H):
+    """scenefiles/textures_tests in one frame: textured cube (floor), sphere, cone and cylinder + an untextured torus."""
+    cam = h.make_camera((0.4, 2.2, 5.5), (-0.05, -0.35, -1), (0, 1, 0), 42.0, W, H)
+    def tex(o, loc, ru, rv, blend):
+        o.texLoc, o.repeatU, o.repeatV, o.blend = loc, ru, rv, blend
+        return o
+    objs = (abi.RmObject * 5)(
+        tex(h.make_object(abi.RM_CUBE, model=h.translate(0, -0.8, 0) @ h.scale(7, 0.5, 7), scale_factor=0.5, ambient=(.2, .2, .2),
+                          diffuse=(.9, .9, .9), specular=(.4, .4, .4), shininess=8), 1, 6.0, 6.0, 0.8),
+        tex(h.make_object(abi.RM_SPHERE, model=h.translate(-1.5, 0.3, 0) @ h.scale(1.6, 1.6, 1.6), scale_factor=1.6,
+                          ambient=(.1, .1, .1), diffuse=(1, 1, 1), specular=(1, 1, 1), shininess=30), 0, 2.0, 1.0, 1.0),
+        tex(h.make_object(abi.RM_CONE, model=h.translate(0.3, 0.2, 0.8) @ h.scale(1.2, 1.5, 1.2), scale_factor=1.2,
+                          ambient=(.1, .1, .1), diffuse=(.7, .9, .7), specular=(.5, .5, .5), shininess=12), 0, 3.0, 2.0, 0.5),
+        tex(h.make_object(abi.RM_CYLINDER, model=h.translate(1.9, 0.2, -0.4) @ h.scale(1.1, 1.5, 1.1), scale_factor=1.1,
+                          ambient=(.1, .1, .1), diffuse=(.9, .8, .6), specular=(.5, .5, .5), shininess=12), 1, 2.0, 1.0, 0.9),
+        h.make_object(abi.RM_TORUS, model=h.translate(0, 1.6, -1.5) @ h.scale(2, 2, 2), scale_factor=2.0, ambient=(.1, .1, .2),
+                      diffuse=(.3, .4, .9), specular=(1, 1, 1), shininess=20))
+    lights = (abi.RmLight * 2)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.4, -1, -0.5)),
+                               h.make_light(abi.RM_LIGHT_POINT, (.9, .8, .7), pos=(3, 4, 4), func=(0.7, 0.04, 0.0)))
+    return cam, objs, 5, lights, 2, h.make_globals()
+
+
+@pytest.mark.parametrize("over", [{}, {"features": abi.RM_FEAT_WHITE_BACKGROUND, "enableSoftShadow": 1, "enableAmbientOcclusion": 1},
+                                  {"features": ENV_ALL}])
+def test_textured_frames_bit_exact(renderer, over):
+    W, H = 112, 72
+    scene = textured_scene(W, H)
+    texs = synthetic_textures()
+    s = abi.default_settings(**over)
+    ref = h.oracle_render(scene, s, W, H, textures=texs)
+    plain = [o for o in scene[1]]
+    t = tables_of(scene)
+    t.textures = texs
+    out = renderer.render(t, s, W, H)
+    assert_bit_equal(out.cpu().numpy(), ref, f"textured {over}")
+    # the textures really contribute
+    for o in scene[1]:
+        o.texLoc = -1
+    assert np.abs(h.oracle_render(scene, s, W, H) - ref).max() > 0.05
+
+
+def test_texture_errors(renderer):
+    from raymarcher_amd import RaymarcherError
+    W, H = 16, 16
+    scene = textured_scene(W, H)
+    t = tables_of(scene)
+    with pytest.raises(RaymarcherError) as e:  # texLoc set but no textures supplied
+        renderer.render(t, abi.default_settings(), W, H)
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
+    t.textures = synthetic_textures()
+    t.objects[4].texLoc = 0  # torus: the reference has no uv map for it
+    with pytest.raises(RaymarcherError) as e:
+        renderer.render(t, abi.default_settings(), W, H)
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
+
+
+def test_scenefile_with_texture_end_to_end(renderer, tmp_path):
+    """Scenefile → loader → PNG decode → upload → render, against the oracle fed the same decoded pixels."""
+    from PIL import Image
+    from raymarcher_amd.render import Scene
+    (tmp_path / "scenes").mkdir()
+    (tmp_path / "texture_store").mkdir()
+    tex = synthetic_textures()[0]
+    Image.fromarray(tex[::-1, :, :3]).save(tmp_path / "texture_store" / "grad.png")  # file rows are top-down
+    scene_json = """{"globalData": {"ambientCoeff": 0.5, "diffuseCoeff": 0.5, "specularCoeff": 0.5},
+      "cameraData": {"position": [0, 1.5, 4], "up": [0, 1, 0], "heightAngle": 40, "focus": [0, 0, 0]},
+      "groups": [{"lights": [{"type": "directional", "color": [1, 1, 1], "direction": [-0.3, -1, -0.6]}]},
+                 {"translate": [0, 0, 0], "scale": [2, 2, 2], "primitives": [{"type": "sphere", "diffuse": [1, 1, 1],
+                   "ambient": [0.2, 0.2, 0.2], "specular": [1, 1, 1], "shininess": 20, "blend": 0.9,
+                   "textureFile": "texture_store/grad.png", "textureU": 3, "textureV": 2}]}]}"""
+    (tmp_path / "scenes" / "s.json").write_text(scene_json)
+    W, H = 64, 48
+    t = Scene(path=tmp_path / "scenes" / "s.json").tables(W, H)
+    assert t.textures is not None and (t.textures[0] == tex[..., :4]).all()
+    s = abi.default_settings()
+    ref = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures)
+    assert_bit_equal(renderer.render(t, s, W, H).cpu().numpy(), ref, "scenefile with texture")
 
 
 # ---------------------------------------------------------------- edge cases of the boundary

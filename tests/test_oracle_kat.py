@@ -174,6 +174,38 @@ def test_shadow_reflection_refraction_change_the_image_in_the_expected_places():
     assert (ao[..., :3] <= base[..., :3] + 1e-6).all()
 
 
+def test_textured_cube_face_samples_the_expected_texels():
+    """A 2×2 texture on the +z face of a unit cube seen head-on, ambient off, one head-on light: the image
+    quadrants take the four texel colours (uvMapCube frag:1299-1333, bilinear GL_REPEAT sampling)."""
+    W = Hh = 64
+    cam = h.make_camera((0, 0, 3), (0, 0, -1), (0, 1, 0), 20.0, W, Hh)
+    o = h.make_object(abi.RM_CUBE, diffuse=(0, 0, 0))
+    o.texLoc, o.repeatU, o.repeatV, o.blend = 0, 1.0, 1.0, 1.0
+    objs = (abi.RmObject * 1)(o)
+    lights = (abi.RmLight * 1)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (0, 0, -1)))
+    scene = (cam, objs, 1, lights, 1, h.make_globals(ka=0, kd=1, ks=0))
+    tex = np.zeros((2, 2, 4), dtype=np.uint8)  # rows bottom-up
+    tex[0, 0], tex[0, 1], tex[1, 0], tex[1, 1] = (255, 0, 0, 255), (0, 255, 0, 255), (0, 0, 255, 255), (255, 255, 0, 255)
+    s = abi.default_settings(features=abi.RM_FEAT_DARK_BACKGROUND)
+    img = h.oracle_render(scene, s, W, Hh, textures=[tex])
+    # independent float64 restatement: the ray through pixel (x, y) meets the z = +0.5 face at
+    # p = ndc · tan(10°) · 2.5 (the eye is 2.5 away), uvMapCube gives (p.x + .5, p.y + .5), then GL bilinear/REPEAT
+    t64 = tex[..., :3].astype(np.float64) / 255.0
+    k = np.tan(np.deg2rad(10.0)) * 2.5
+    worst = 0.0
+    for (x, y) in [(5, 7), (20, 20), (44, 20), (20, 44), (44, 44), (32, 32), (60, 3), (1, 62)]:
+        u = ((x + 0.5) / W * 2 - 1) * k + 0.5
+        v = ((y + 0.5) / Hh * 2 - 1) * k + 0.5
+        fu, fv = u * 2 - 0.5, v * 2 - 0.5
+        i0, j0 = int(np.floor(fu)), int(np.floor(fv))
+        a_, b_ = fu - i0, fv - j0
+        tx = lambda i, j: t64[j % 2, i % 2]
+        exp = (tx(i0, j0) * (1 - a_) + tx(i0 + 1, j0) * a_) * (1 - b_) + (tx(i0, j0 + 1) * (1 - a_) + tx(i0 + 1, j0 + 1) * a_) * b_
+        worst = max(worst, np.abs(img[y, x, :3] - exp).max())
+    assert worst < 2e-3, worst  # hit point is within 1e-3 of the face (SURFACE_DIST) → uv within 1e-3
+    assert np.allclose(img[Hh // 2, W // 2, :3], [0.5, 0.5, 0.25], atol=0.02)  # centre: average of the four texels
+
+
 def test_row_range_equals_full_frame_rows_and_is_thread_count_independent():
     W, Hh = 40, 30
     scene = h.scene_mandelbulb(W, Hh)

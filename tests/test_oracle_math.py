@@ -52,6 +52,16 @@ def test_acos_accuracy_and_clamping():
     assert list(edge) == [0.0, pi, 0.0, pi, pi, 0.0]
 
 
+def test_asin_accuracy_and_clamping():
+    x = np.linspace(-1, 1, 400001).astype(np.float32)
+    got = probe(abi.RM_FN_ASIN, x)
+    exact = np.arcsin(x.astype(np.float64))
+    assert np.abs(got - exact).max() < 2.5e-7
+    edge = probe(abi.RM_FN_ASIN, np.array([1.0, -1.0, 1.5, -1.5, np.nan, 0.0], dtype=np.float32))
+    h2 = np.float32(1.57079637)
+    assert list(edge) == [h2, -h2, h2, -h2, -h2, 0.0]
+
+
 def test_atan2_accuracy_and_special_cases():
     rng = np.random.default_rng(1)
     y, x = rng.normal(0, 1, 400000).astype(np.float32), rng.normal(0, 1, 400000).astype(np.float32)
