@@ -36,9 +36,10 @@ def pack(scene, settings):
                 settings=raw(settings))
 
 
-def frame_case(name, scene, settings, W, H):
-    rgba, bright = run_ref.render(scene, settings, W, H)
-    np.savez_compressed(os.path.join(OUT, f"frame_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, **pack(scene, settings))
+def frame_case(name, scene, settings, W, H, texture=None):
+    rgba, bright = run_ref.render(scene, settings, W, H, texture)
+    extra = {} if texture is None else {"texture": texture}
+    np.savez_compressed(os.path.join(OUT, f"frame_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, **extra, **pack(scene, settings))
     print("frame", name, rgba.shape, float(np.nanmax(rgba)))
 
 
@@ -76,10 +77,25 @@ def env_cases():
         run_ref.build_program = orig
 
 
+def texture_cases():
+    """unit_sphere.json-like: the four textured primitive types sharing ONE texture (the ESSL adaptation reads
+    objTextures[0] for every texLoc), LINEAR filtering, REPEAT wrap."""
+    W, H = 64, 48
+    scene = tg.textured_scene(W, H)
+    for o in scene[1]:
+        if o.texLoc != -1:
+            o.texLoc = 0
+    frame_case("textured_prims", scene, abi.default_settings(features=abi.RM_FEAT_WHITE_BACKGROUND), W, H,
+               texture=tg.synthetic_textures()[1])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "env":
         return env_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "tex":
+        return texture_cases()
+    texture_cases()
     env_cases()
     W, H = 64, 48
     WB, DB = abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND

@@ -104,9 +104,26 @@ def set_uniforms(prog, cam, objs, no, lights, nl, g, s):
     i1("skybox", 10)
 
 
-def render(scene, settings, W, H):
+def bind_object_texture(tex):
+    """Upload one RGBA8 texture (rows bottom-up) to unit 0 the way initShapesTextures does (realtimerender.cpp:295-300):
+    GL_LINEAR min/mag, GL_REPEAT wrap, no mipmaps.  Every objTextures[i] sampler reads unit 0."""
+    gl = ctx().gl
+    t = C.c_uint()
+    gl.glGenTextures(1, C.byref(t))
+    gl.glActiveTexture(0x84C0)
+    gl.glBindTexture(gles.GL_TEXTURE_2D, t)
+    a = np.ascontiguousarray(tex, dtype=np.uint8)
+    gl.glTexImage2D(gles.GL_TEXTURE_2D, 0, 0x8058, a.shape[1], a.shape[0], 0, 0x1908, 0x1401, a.ctypes.data_as(C.c_void_p))
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, gles.GL_TEXTURE_MIN_FILTER, 0x2601)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, gles.GL_TEXTURE_MAG_FILTER, 0x2601)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, 0x2802, 0x2901)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, 0x2803, 0x2901)
+    return t
+
+
+def render(scene, settings, W, H, texture=None):
     """scene = (cam, objs, numObjects, lights, numLights, globals); returns (fragColor, BrightColor) float32 HxWx4,
-    row 0 = bottom (GL read-back order)."""
+    row 0 = bottom (GL read-back order).  `texture`: optional RGBA8 array bound as objTextures[0]."""
     from raymarcher_amd import abi
     cam, objs, no, lights, nl, g = scene
     f = settings.features
@@ -131,6 +148,8 @@ def render(scene, settings, W, H):
     c = ctx()
     c.target(W, H, 2)
     set_uniforms(prog, cam, objs, no, lights, nl, g, settings)
+    if texture is not None:
+        bind_object_texture(texture)
     c.draw_fullscreen(prog)
     err = c.error()
     assert err == 0, f"GL error {err:#x}"
