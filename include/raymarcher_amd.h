@@ -150,7 +150,7 @@ void rm_settings_default(RmSettings *s);
 /* ---- library / device ---------------------------------------------------------------------- */
 int rm_abi_version(void);
 /* sizeof() of ABI struct `which` as compiled into the library (0 RmObject, 1 RmLight, 2 RmCamera, 3 RmGlobals,
- * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData, 8 RmTexture; -1 otherwise) so bindings can verify layout. */
+ * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData, 8 RmTexture, 9 RmPostSettings; -1 otherwise) so bindings can verify layout. */
 int rm_abi_sizeof(int which);
 const char *rm_status_string(int status);
 /* Thread-local text of the last failure in this thread ("" if none). */
@@ -234,6 +234,24 @@ int rm_set_kernel_path(int path);
  * d_out: H·W·4 bytes, row 0 = top.
  */
 int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *stream);
+
+/* ---- post passes (src/realtimerender.cpp:78-165; resources/blur.frag, hdr.frag, fxaa.frag) ------------------ */
+/* Settings surface — src/settings.h:37-41. */
+typedef struct RmPostSettings {
+  int32_t enableFXAA, enableGammaCorrection, enableHDR, enableBloom;
+  float exposure;
+} RmPostSettings;
+/*
+ * rm_post_process — what Realtime::rayMarch() does after the draw call: applyLightEffects() (bloom = 10 ping-pong
+ * passes of a separable 9-tap Gaussian over BrightColor, of which the reference composites the 9th; then gamma
+ * 1/2.2, or 1−exp(−(colour+bloom)·exposure)) and applyFXAA().  Storage formats are the reference's: the HDR /
+ * bright / ping-pong targets are RGBA16F (values are rounded to binary16 between passes), the FXAA source is
+ * RGBA8 sampled with GL_LINEAR / GL_REPEAT.  d_frag, d_bright (may be NULL without bloom) and d_out are H·W
+ * float4, row 0 = bottom; d_out receives the colour the 8-bit default framebuffer would quantise
+ * (rm_frame_to_rgba8 does that).  Uses a grow-only per-device workspace of 24 B/pixel.
+ */
+int rm_post_process(const float *d_frag, const float *d_bright, float *d_out, int W, int H, const RmPostSettings *ps,
+                    void *stream);
 
 /* ---- math spec probes (tests only: evaluate the device implementation of one rm_math function
  *      element-wise so it can be compared bit-for-bit with the oracle) ---------------------------- */

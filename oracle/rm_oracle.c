@@ -1050,6 +1050,180 @@ done:
   if (outBright) { outBright[0] = bright.x; outBright[1] = bright.y; outBright[2] = bright.z; outBright[3] = bright.w; }
 }
 
+
+/* ---------------------------------------------------------------- post passes (blur.frag, hdr.frag, fxaa.frag) */
+#include <immintrin.h>
+/* storage in an RGBA16F target: round to binary16 (nearest even) and back */
+static inline float q16(float v) { return _cvtsh_ss(_cvtss_sh(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+/* storage in an RGBA8 target: clamp, ×255, round half up, /255 */
+static inline float q8(float v) {
+  v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+  return (float)(int)rm_fma(v, 255.0f, 0.5f) / 255.0f;
+}
+static inline int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+/* blur.frag:9-31: one pass; src/dst are H·W·3 binary16-valued floats; CLAMP_TO_EDGE; taps hit texel centres */
+static void blurPass(const float *src, float *dst, int W, int H, int horizontal) {
+  static const float w[5] = {0.2270270270f, 0.1945945946f, 0.1216216216f, 0.0540540541f, 0.0162162162f};
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++)
+      for (int k = 0; k < 3; k++) {
+        float r = src[((size_t)y * W + x) * 3 + k] * w[0];
+        for (int i = 1; i < 5; i++) {
+          int xp = horizontal ? clampi(x + i, W) : x, yp = horizontal ? y : clampi(y + i, H);
+          int xm = horizontal ? clampi(x - i, W) : x, ym = horizontal ? y : clampi(y - i, H);
+          r = rm_fma(src[((size_t)yp * W + xp) * 3 + k], w[i], r);
+          r = rm_fma(src[((size_t)ym * W + xm) * 3 + k], w[i], r);
+        }
+        dst[((size_t)y * W + x) * 3 + k] = q16(r);
+      }
+}
+
+/* bilinear GL_LINEAR / GL_REPEAT fetch of an RGB float image at normalised (u, v) — the FXAA source texture */
+static v3 fetchLinearRepeat(const float *img, int W, int H, float u, float v) {
+  float fx = rm_fma(u, (float)W, -0.5f), fy = rm_fma(v, (float)H, -0.5f);
+  float x0 = rm_floor(fx), y0 = rm_floor(fy);
+  float a = fx - x0, b = fy - y0;
+  int i0 = wrapi(x0, W), j0 = wrapi(y0, H);
+  int i1 = (i0 + 1 == W) ? 0 : i0 + 1, j1 = (j0 + 1 == H) ? 0 : j0 + 1;
+  const float *p00 = img + ((size_t)j0 * W + i0) * 3, *p10 = img + ((size_t)j0 * W + i1) * 3;
+  const float *p01 = img + ((size_t)j1 * W + i0) * 3, *p11 = img + ((size_t)j1 * W + i1) * 3;
+  return V3(rm_mix(rm_mix(p00[0], p10[0], a), rm_mix(p01[0], p11[0], a), b),
+            rm_mix(rm_mix(p00[1], p10[1], a), rm_mix(p01[1], p11[1], a), b),
+            rm_mix(rm_mix(p00[2], p10[2], a), rm_mix(p01[2], p11[2], a), b));
+}
+static inline float rgb2luma(v3 c) { return rm_sqrt(dot3(c, V3(0.299f, 0.587f, 0.114f))); } /* fxaa.frag:18-20 */
+
+/* fxaa.frag:22-166 for the pixel (x, y); img = RGB floats holding 8-bit values */
+static v3 fxaaPixel(const float *img, int W, int H, int x, int y) {
+  static const float quality[12] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.5f, 2.0f, 2.0f, 2.0f, 2.0f, 4.0f, 8.0f};
+  const float invW = 1.0f / (float)W, invH = 1.0f / (float)H; /* configureFXAAUniforms, realtimerender.cpp:815-821 */
+  const float tu = ((float)x + 0.5f) / (float)W, tv = ((float)y + 0.5f) / (float)H;
+#define TEXOFF(dx, dy) fetchLinearRepeat(img, W, H, tu + (float)(dx) * invW, tv + (float)(dy) * invH)
+  v3 colorCenter = TEXOFF(0, 0);
+  float lumaCenter = rgb2luma(colorCenter);
+  float lumaDown = rgb2luma(TEXOFF(0, -1)), lumaUp = rgb2luma(TEXOFF(0, 1));
+  float lumaLeft = rgb2luma(TEXOFF(-1, 0)), lumaRight = rgb2luma(TEXOFF(1, 0));
+  float lumaMin = rm_min(lumaCenter, rm_min(rm_min(lumaDown, lumaUp), rm_min(lumaLeft, lumaRight)));
+  float lumaMax = rm_max(lumaCenter, rm_max(rm_max(lumaDown, lumaUp), rm_max(lumaLeft, lumaRight)));
+  float lumaRange = lumaMax - lumaMin;
+  if (lumaRange < rm_max(0.0312f, lumaMax * 0.125f)) return colorCenter;
+  float lumaDownLeft = rgb2luma(TEXOFF(-1, -1)), lumaUpRight = rgb2luma(TEXOFF(1, 1));
+  float lumaUpLeft = rgb2luma(TEXOFF(-1, 1)), lumaDownRight = rgb2luma(TEXOFF(1, -1));
+#undef TEXOFF
+  float lumaDownUp = lumaDown + lumaUp, lumaLeftRight = lumaLeft + lumaRight;
+  float lumaLeftCorners = lumaDownLeft + lumaUpLeft, lumaDownCorners = lumaDownLeft + lumaDownRight;
+  float lumaRightCorners = lumaDownRight + lumaUpRight, lumaUpCorners = lumaUpRight + lumaUpLeft;
+  float edgeHorizontal = (rm_abs(rm_fma(-2.0f, lumaLeft, lumaLeftCorners)) + rm_abs(rm_fma(-2.0f, lumaCenter, lumaDownUp)) * 2.0f) +
+                         rm_abs(rm_fma(-2.0f, lumaRight, lumaRightCorners));
+  float edgeVertical = (rm_abs(rm_fma(-2.0f, lumaUp, lumaUpCorners)) + rm_abs(rm_fma(-2.0f, lumaCenter, lumaLeftRight)) * 2.0f) +
+                       rm_abs(rm_fma(-2.0f, lumaDown, lumaDownCorners));
+  int isHorizontal = edgeHorizontal >= edgeVertical;
+  float luma1 = isHorizontal ? lumaDown : lumaLeft, luma2 = isHorizontal ? lumaUp : lumaRight;
+  float gradient1 = luma1 - lumaCenter, gradient2 = luma2 - lumaCenter;
+  int is1Steepest = rm_abs(gradient1) >= rm_abs(gradient2);
+  float gradientScaled = 0.25f * rm_max(rm_abs(gradient1), rm_abs(gradient2));
+  float stepLength = isHorizontal ? invH : invW;
+  float lumaLocalAverage;
+  if (is1Steepest) { stepLength = -stepLength; lumaLocalAverage = 0.5f * (luma1 + lumaCenter); }
+  else lumaLocalAverage = 0.5f * (luma2 + lumaCenter);
+  float cu = tu, cv = tv;
+  if (isHorizontal) cv = rm_fma(stepLength, 0.5f, cv); else cu = rm_fma(stepLength, 0.5f, cu);
+  float ox = isHorizontal ? invW : 0.0f, oy = isHorizontal ? 0.0f : invH;
+  float u1 = cu - ox, v1 = cv - oy, u2 = cu + ox, v2 = cv + oy;
+  float lumaEnd1 = rgb2luma(fetchLinearRepeat(img, W, H, u1, v1)) - lumaLocalAverage;
+  float lumaEnd2 = rgb2luma(fetchLinearRepeat(img, W, H, u2, v2)) - lumaLocalAverage;
+  int reached1 = rm_abs(lumaEnd1) >= gradientScaled, reached2 = rm_abs(lumaEnd2) >= gradientScaled;
+  int reachedBoth = reached1 && reached2;
+  if (!reached1) { u1 -= ox; v1 -= oy; }
+  if (!reached2) { u2 += ox; v2 += oy; }
+  if (!reachedBoth) {
+    for (int i = 2; i < 12; i++) {
+      if (!reached1) lumaEnd1 = rgb2luma(fetchLinearRepeat(img, W, H, u1, v1)) - lumaLocalAverage;
+      if (!reached2) lumaEnd2 = rgb2luma(fetchLinearRepeat(img, W, H, u2, v2)) - lumaLocalAverage;
+      reached1 = rm_abs(lumaEnd1) >= gradientScaled;
+      reached2 = rm_abs(lumaEnd2) >= gradientScaled;
+      reachedBoth = reached1 && reached2;
+      if (!reached1) { u1 = rm_fma(-ox, quality[i], u1); v1 = rm_fma(-oy, quality[i], v1); }
+      if (!reached2) { u2 = rm_fma(ox, quality[i], u2); v2 = rm_fma(oy, quality[i], v2); }
+      if (reachedBoth) break;
+    }
+  }
+  float distance1 = isHorizontal ? (tu - u1) : (tv - v1), distance2 = isHorizontal ? (u2 - tu) : (v2 - tv);
+  int isDirection1 = distance1 < distance2;
+  float distanceFinal = rm_min(distance1, distance2);
+  float edgeThickness = distance1 + distance2;
+  float pixelOffset = -distanceFinal / edgeThickness + 0.5f;
+  int isLumaCenterSmaller = lumaCenter < lumaLocalAverage;
+  int correctVariation = ((isDirection1 ? lumaEnd1 : lumaEnd2) < 0.0f) != isLumaCenterSmaller;
+  float finalOffset = correctVariation ? pixelOffset : 0.0f;
+  float lumaAverage = (1.0f / 12.0f) * ((rm_fma(2.0f, lumaDownUp + lumaLeftRight, lumaLeftCorners)) + lumaRightCorners);
+  float sub1 = rm_clamp(rm_abs(lumaAverage - lumaCenter) / lumaRange, 0.0f, 1.0f);
+  float sub2 = (rm_fma(-2.0f, sub1, 3.0f) * sub1) * sub1;
+  float subFinal = (sub2 * sub2) * 0.875f;
+  finalOffset = rm_max(finalOffset, subFinal);
+  float fu = tu, fv = tv;
+  if (isHorizontal) fv = rm_fma(finalOffset * stepLength, 1.0f, fv); else fu = rm_fma(finalOffset * stepLength, 1.0f, fu);
+  return fetchLinearRepeat(img, W, H, fu, fv);
+}
+
+int rmo_post_process(const float *frag, const float *bright, float *out, int W, int H, const RmPostSettings *ps) {
+  if (!frag || !out || !ps || W <= 0 || H <= 0) return RM_ERR_INVALID_ARGUMENT;
+  const size_t n = (size_t)W * H;
+  const int light = ps->enableHDR || ps->enableGammaCorrection || ps->enableBloom;
+  if (ps->enableBloom && !bright) return RM_ERR_INVALID_ARGUMENT;
+  float *stage = (float *)malloc(n * 3 * sizeof(float)); /* RGB of the stage that feeds FXAA / the screen */
+  if (!stage) return RM_ERR_IO;
+  if (light) {
+    float *bl = NULL;
+    if (ps->enableBloom) { /* applyBloom, realtimerender.cpp:92-108: the reference composites pass 9 of 10 */
+      float *a = (float *)malloc(n * 3 * sizeof(float)), *b = (float *)malloc(n * 3 * sizeof(float));
+      for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) a[i * 3 + k] = q16(bright[i * 4 + k]);
+      int horizontal = 1;
+      float *src = a, *dst = b;
+      for (int i = 0; i < 9; i++) {
+        blurPass(src, dst, W, H, horizontal);
+        float *t = src; src = dst; dst = t;
+        horizontal = !horizontal;
+      }
+      bl = src;
+      free(dst);
+    }
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) { /* hdr.frag:13-35 */
+        float hc = q16(frag[i * 4 + k]);
+        float r;
+        if (!ps->enableHDR && !ps->enableBloom) r = rm_pow(hc, 1.0f / 2.2f);
+        else {
+          if (ps->enableBloom) hc = hc + bl[i * 3 + k];
+          r = 1.0f - rm_exp((-hc) * ps->exposure);
+        }
+        stage[i * 3 + k] = r;
+      }
+    free(bl);
+  } else {
+    for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) stage[i * 3 + k] = frag[i * 4 + k];
+  }
+  if (ps->enableFXAA) { /* the FXAA source is the RGBA8 m_customFBOColorTexture */
+    for (size_t i = 0; i < n * 3; i++) stage[i] = q8(stage[i]);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        v3 c = fxaaPixel(stage, W, H, x, y);
+        float *o = out + ((size_t)y * W + x) * 4;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = 1.0f;
+      }
+  } else {
+    for (size_t i = 0; i < n; i++) {
+      out[i * 4] = stage[i * 3]; out[i * 4 + 1] = stage[i * 3 + 1]; out[i * 4 + 2] = stage[i * 3 + 2];
+      out[i * 4 + 3] = light ? 1.0f : frag[i * 4 + 3];
+    }
+  }
+  free(stage);
+  return RM_OK;
+}
+
 /* ---------------------------------------------------------------- public oracle API */
 static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
                     int numLights, const RmGlobals *g, const RmSettings *s, const RmTexture *tex, int numTex) {

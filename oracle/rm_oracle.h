@@ -17,6 +17,8 @@ int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const 
 int rmo_render_tex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                    const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
                    int rowBegin, int rowEnd, float *rgba, float *bright, RmCounters *counters, int threads);
+/* Post passes on host buffers (see rm_post_process). */
+int rmo_post_process(const float *frag, const float *bright, float *out, int W, int H, const RmPostSettings *ps);
 int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float *out, int n);
 int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s,
                       const float *pts, float *out, int n);

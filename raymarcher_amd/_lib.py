@@ -42,6 +42,7 @@ SIGNATURES = {
     "rm_get_stage_timing": (C.c_int, [_P(C.c_double), _P(C.c_double), _P(C.c_int)]),
     "rm_set_kernel_path": (C.c_int, [C.c_int]),
     "rm_frame_to_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rm_post_process": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(abi.RmPostSettings), C.c_void_p]),
     "rm_probe_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rm_probe_sdscene": (C.c_int, [_P(abi.RmObject), C.c_int, _P(abi.RmGlobals), _P(abi.RmSettings), C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),

@@ -80,6 +80,11 @@ class RmCounters(C.Structure):
     _fields_ = [("sceneEvals", C.c_uint64), ("bulbIters", C.c_uint64), ("hitPixels", C.c_uint64)]
 
 
+class RmPostSettings(C.Structure):
+    _fields_ = [("enableFXAA", i32), ("enableGammaCorrection", i32), ("enableHDR", i32), ("enableBloom", i32),
+                ("exposure", f32)]
+
+
 class RmHostSettings(C.Structure):
     _fields_ = [("screenWidth", i32), ("screenHeight", i32), ("nearPlane", f32), ("farPlane", f32),
                 ("twoDSpace", i32), ("enableSoftShadow", i32), ("enableReflection", i32),

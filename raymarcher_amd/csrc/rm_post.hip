@@ -1,0 +1,245 @@
+// rm_post.hip — the post passes the reference runs after the raymarch draw call, as HIP image kernels:
+// bloom (separable 9-tap Gaussian ping-pong over BrightColor), HDR tone map / gamma, FXAA.
+// Reference: Realtime::applyBloom / applyLightEffects / applyFXAA (src/realtimerender.cpp:92-165),
+// resources/blur.frag, hdr.frag, fxaa.frag; FBO formats from initCustomFBO (src/realtimerender.cpp:479-552).
+//
+// These are HBM-streaming kernels (8-16 B read + 4-16 B written per pixel; the 9 taps of a blur pass and the
+// FXAA neighbourhood hit L1/L2), nowhere near the raymarch's cost.  Intermediate images use the reference's storage
+// formats — binary16 for the HDR / bright / ping-pong targets, 8-bit for the FXAA source — so values are rounded
+// exactly where the reference's framebuffers round them, and the result is bit-reproducible against the oracle.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "rm_device.hip.h"
+#include "rm_internal.h"
+
+namespace rm {
+namespace {
+
+struct half4 { __half x, y, z, w; };
+
+__device__ __forceinline__ float q16(float v) { return __half2float(__float2half_rn(v)); }
+__device__ __forceinline__ unsigned char to8(float v) {
+  v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+  return (unsigned char)(int)fma(v, 255.0f, 0.5f);
+}
+__device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+__global__ void bright_to_half_kernel(const float4 *__restrict__ in, half4 *__restrict__ out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 c = in[i];
+  out[i] = half4{__float2half_rn(c.x), __float2half_rn(c.y), __float2half_rn(c.z), __float2half_rn(1.0f)};
+}
+
+// blur.frag:9-31, CLAMP_TO_EDGE, taps on texel centres
+__global__ void blur_kernel(const half4 *__restrict__ src, half4 *__restrict__ dst, int W, int H, int horizontal) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const float w[5] = {0.2270270270f, 0.1945945946f, 0.1216216216f, 0.0540540541f, 0.0162162162f};
+  half4 c = src[(size_t)y * W + x];
+  float r = __half2float(c.x) * w[0], g = __half2float(c.y) * w[0], b = __half2float(c.z) * w[0];
+#pragma unroll
+  for (int i = 1; i < 5; i++) {
+    const int xp = horizontal ? clampi(x + i, W) : x, yp = horizontal ? y : clampi(y + i, H);
+    const int xm = horizontal ? clampi(x - i, W) : x, ym = horizontal ? y : clampi(y - i, H);
+    half4 p = src[(size_t)yp * W + xp], m = src[(size_t)ym * W + xm];
+    r = fma(__half2float(p.x), w[i], r); g = fma(__half2float(p.y), w[i], g); b = fma(__half2float(p.z), w[i], b);
+    r = fma(__half2float(m.x), w[i], r); g = fma(__half2float(m.y), w[i], g); b = fma(__half2float(m.z), w[i], b);
+  }
+  dst[(size_t)y * W + x] = half4{__float2half_rn(r), __float2half_rn(g), __float2half_rn(b), __float2half_rn(1.0f)};
+}
+
+// hdr.frag:13-35.  Writes either the float frame (no FXAA afterwards) or the RGBA8 FXAA source.
+__global__ void light_kernel(const float4 *__restrict__ frag, const half4 *__restrict__ bloom, float4 *__restrict__ outF,
+                             uchar4 *__restrict__ out8, int n, int hdr, int useBloom, float exposure) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 f = frag[i];
+  float c[3] = {q16(f.x), q16(f.y), q16(f.z)};
+  float r[3];
+  if (!hdr && !useBloom) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] = pow_(c[k], 1.0f / 2.2f);
+  } else {
+    if (useBloom) {
+      half4 b = bloom[i];
+      c[0] = c[0] + __half2float(b.x); c[1] = c[1] + __half2float(b.y); c[2] = c[2] + __half2float(b.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] = 1.0f - exp_((-c[k]) * exposure);
+  }
+  if (out8) out8[i] = make_uchar4(to8(r[0]), to8(r[1]), to8(r[2]), 255);
+  else outF[i] = make_float4(r[0], r[1], r[2], 1.0f);
+}
+
+__global__ void quant8_kernel(const float4 *__restrict__ frag, uchar4 *__restrict__ out8, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 f = frag[i];
+  out8[i] = make_uchar4(to8(f.x), to8(f.y), to8(f.z), 255);
+}
+
+// GL_LINEAR / GL_REPEAT fetch of the RGBA8 FXAA source at normalised (u, v)
+__device__ __forceinline__ V3 fetch8(const uchar4 *__restrict__ img, int W, int H, float u, float v) {
+  float fx = fma(u, (float)W, -0.5f), fy = fma(v, (float)H, -0.5f);
+  float x0 = floor_(fx), y0 = floor_(fy);
+  float a = fx - x0, b = fy - y0;
+  int i0 = wrapIndex(x0, W), j0 = wrapIndex(y0, H);
+  int i1 = (i0 + 1 == W) ? 0 : i0 + 1, j1 = (j0 + 1 == H) ? 0 : j0 + 1;
+  uchar4 p00 = img[(size_t)j0 * W + i0], p10 = img[(size_t)j0 * W + i1], p01 = img[(size_t)j1 * W + i0], p11 = img[(size_t)j1 * W + i1];
+  auto f = [](unsigned char q) { return (float)q / 255.0f; };
+  return v3(mix_(mix_(f(p00.x), f(p10.x), a), mix_(f(p01.x), f(p11.x), a), b),
+            mix_(mix_(f(p00.y), f(p10.y), a), mix_(f(p01.y), f(p11.y), a), b),
+            mix_(mix_(f(p00.z), f(p10.z), a), mix_(f(p01.z), f(p11.z), a), b));
+}
+__device__ __forceinline__ float rgb2luma(V3 c) { return sqrt_(dot(c, v3(0.299f, 0.587f, 0.114f))); }  // fxaa.frag:18-20
+
+// fxaa.frag:22-166
+__global__ void fxaa_kernel(const uchar4 *__restrict__ img, float4 *__restrict__ out, int W, int H) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const float quality[12] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.5f, 2.0f, 2.0f, 2.0f, 2.0f, 4.0f, 8.0f};
+  const float invW = 1.0f / (float)W, invH = 1.0f / (float)H;
+  const float tu = ((float)x + 0.5f) / (float)W, tv = ((float)y + 0.5f) / (float)H;
+  auto texOff = [&](int dx, int dy) { return fetch8(img, W, H, tu + (float)dx * invW, tv + (float)dy * invH); };
+  V3 colorCenter = texOff(0, 0);
+  V3 result = colorCenter;
+  float lumaCenter = rgb2luma(colorCenter);
+  float lumaDown = rgb2luma(texOff(0, -1)), lumaUp = rgb2luma(texOff(0, 1));
+  float lumaLeft = rgb2luma(texOff(-1, 0)), lumaRight = rgb2luma(texOff(1, 0));
+  float lumaMin = min_(lumaCenter, min_(min_(lumaDown, lumaUp), min_(lumaLeft, lumaRight)));
+  float lumaMax = max_(lumaCenter, max_(max_(lumaDown, lumaUp), max_(lumaLeft, lumaRight)));
+  float lumaRange = lumaMax - lumaMin;
+  if (!(lumaRange < max_(0.0312f, lumaMax * 0.125f))) {
+    float lumaDownLeft = rgb2luma(texOff(-1, -1)), lumaUpRight = rgb2luma(texOff(1, 1));
+    float lumaUpLeft = rgb2luma(texOff(-1, 1)), lumaDownRight = rgb2luma(texOff(1, -1));
+    float lumaDownUp = lumaDown + lumaUp, lumaLeftRight = lumaLeft + lumaRight;
+    float lumaLeftCorners = lumaDownLeft + lumaUpLeft, lumaDownCorners = lumaDownLeft + lumaDownRight;
+    float lumaRightCorners = lumaDownRight + lumaUpRight, lumaUpCorners = lumaUpRight + lumaUpLeft;
+    float edgeHorizontal = (fabs_(fma(-2.0f, lumaLeft, lumaLeftCorners)) + fabs_(fma(-2.0f, lumaCenter, lumaDownUp)) * 2.0f) +
+                           fabs_(fma(-2.0f, lumaRight, lumaRightCorners));
+    float edgeVertical = (fabs_(fma(-2.0f, lumaUp, lumaUpCorners)) + fabs_(fma(-2.0f, lumaCenter, lumaLeftRight)) * 2.0f) +
+                         fabs_(fma(-2.0f, lumaDown, lumaDownCorners));
+    bool isHorizontal = edgeHorizontal >= edgeVertical;
+    float luma1 = isHorizontal ? lumaDown : lumaLeft, luma2 = isHorizontal ? lumaUp : lumaRight;
+    float gradient1 = luma1 - lumaCenter, gradient2 = luma2 - lumaCenter;
+    bool is1Steepest = fabs_(gradient1) >= fabs_(gradient2);
+    float gradientScaled = 0.25f * max_(fabs_(gradient1), fabs_(gradient2));
+    float stepLength = isHorizontal ? invH : invW;
+    float lumaLocalAverage;
+    if (is1Steepest) { stepLength = -stepLength; lumaLocalAverage = 0.5f * (luma1 + lumaCenter); }
+    else lumaLocalAverage = 0.5f * (luma2 + lumaCenter);
+    float cu = tu, cv = tv;
+    if (isHorizontal) cv = fma(stepLength, 0.5f, cv); else cu = fma(stepLength, 0.5f, cu);
+    float ox = isHorizontal ? invW : 0.0f, oy = isHorizontal ? 0.0f : invH;
+    float u1 = cu - ox, v1 = cv - oy, u2 = cu + ox, v2 = cv + oy;
+    float lumaEnd1 = rgb2luma(fetch8(img, W, H, u1, v1)) - lumaLocalAverage;
+    float lumaEnd2 = rgb2luma(fetch8(img, W, H, u2, v2)) - lumaLocalAverage;
+    bool reached1 = fabs_(lumaEnd1) >= gradientScaled, reached2 = fabs_(lumaEnd2) >= gradientScaled;
+    bool reachedBoth = reached1 && reached2;
+    if (!reached1) { u1 -= ox; v1 -= oy; }
+    if (!reached2) { u2 += ox; v2 += oy; }
+    if (!reachedBoth) {
+      for (int i = 2; i < 12; i++) {
+        if (!reached1) lumaEnd1 = rgb2luma(fetch8(img, W, H, u1, v1)) - lumaLocalAverage;
+        if (!reached2) lumaEnd2 = rgb2luma(fetch8(img, W, H, u2, v2)) - lumaLocalAverage;
+        reached1 = fabs_(lumaEnd1) >= gradientScaled;
+        reached2 = fabs_(lumaEnd2) >= gradientScaled;
+        reachedBoth = reached1 && reached2;
+        if (!reached1) { u1 = fma(-ox, quality[i], u1); v1 = fma(-oy, quality[i], v1); }
+        if (!reached2) { u2 = fma(ox, quality[i], u2); v2 = fma(oy, quality[i], v2); }
+        if (reachedBoth) break;
+      }
+    }
+    float distance1 = isHorizontal ? (tu - u1) : (tv - v1), distance2 = isHorizontal ? (u2 - tu) : (v2 - tv);
+    bool isDirection1 = distance1 < distance2;
+    float distanceFinal = min_(distance1, distance2);
+    float edgeThickness = distance1 + distance2;
+    float pixelOffset = -distanceFinal / edgeThickness + 0.5f;
+    bool isLumaCenterSmaller = lumaCenter < lumaLocalAverage;
+    bool correctVariation = ((isDirection1 ? lumaEnd1 : lumaEnd2) < 0.0f) != isLumaCenterSmaller;
+    float finalOffset = correctVariation ? pixelOffset : 0.0f;
+    float lumaAverage = (1.0f / 12.0f) * (fma(2.0f, lumaDownUp + lumaLeftRight, lumaLeftCorners) + lumaRightCorners);
+    float sub1 = clamp_(fabs_(lumaAverage - lumaCenter) / lumaRange, 0.0f, 1.0f);
+    float sub2 = (fma(-2.0f, sub1, 3.0f) * sub1) * sub1;
+    float subFinal = (sub2 * sub2) * 0.875f;
+    finalOffset = max_(finalOffset, subFinal);
+    float fu = tu, fv = tv;
+    if (isHorizontal) fv = fma(finalOffset * stepLength, 1.0f, fv); else fu = fma(finalOffset * stepLength, 1.0f, fu);
+    result = fetch8(img, W, H, fu, fv);
+  }
+  out[(size_t)y * W + x] = make_float4(result.x, result.y, result.z, 1.0f);
+}
+
+std::mutex g_postMu;
+struct PostWs { void *mem = nullptr; size_t bytes = 0; };
+PostWs g_postWs[64];
+
+}  // namespace
+}  // namespace rm
+
+using namespace rm;
+
+#define HIP_OK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                                \
+      return RM_ERR_DEVICE;                                                                        \
+    }                                                                                              \
+  } while (0)
+
+extern "C" int rm_post_process(const float *d_frag, const float *d_bright, float *d_out, int W, int H,
+                               const RmPostSettings *ps, void *stream) {
+  if (!d_frag || !d_out || !ps || W <= 0 || H <= 0) { set_error("bad post-process arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (ps->enableBloom && !d_bright) { set_error("bloom needs the BrightColor plane"); return RM_ERR_INVALID_ARGUMENT; }
+  std::lock_guard<std::mutex> lock(g_postMu);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n = (size_t)W * H;
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  PostWs &ws = g_postWs[dev & 63];
+  const size_t need = n * (8 + 8 + 4);
+  if (ws.bytes < need) {
+    HIP_OK(hipStreamSynchronize(st));
+    if (ws.mem) HIP_OK(hipFree(ws.mem));
+    ws.mem = nullptr; ws.bytes = 0;
+    HIP_OK(hipMalloc(&ws.mem, need));
+    ws.bytes = need;
+  }
+  half4 *pa = static_cast<half4 *>(ws.mem), *pb = pa + n;
+  uchar4 *stage8 = reinterpret_cast<uchar4 *>(pb + n);
+  const float4 *frag = reinterpret_cast<const float4 *>(d_frag);
+  float4 *out = reinterpret_cast<float4 *>(d_out);
+  const dim3 lin((unsigned)((n + 255) / 256)), blk(256), grid2((W + 255) / 256, H);
+  const bool light = ps->enableHDR || ps->enableGammaCorrection || ps->enableBloom;
+  if (!light && !ps->enableFXAA) {
+    if (d_out != d_frag) HIP_OK(hipMemcpyAsync(d_out, d_frag, n * 16, hipMemcpyDeviceToDevice, st));
+    return RM_OK;
+  }
+  if (light) {
+    const half4 *bloom = nullptr;
+    if (ps->enableBloom) {  // applyBloom: 10 passes H,V,H,…; the composite reads the buffer pass 9 wrote
+      hipLaunchKernelGGL(bright_to_half_kernel, lin, blk, 0, st, reinterpret_cast<const float4 *>(d_bright), pa, (int)n);
+      half4 *src = pa, *dst = pb;
+      int horizontal = 1;
+      for (int i = 0; i < 9; i++) {
+        hipLaunchKernelGGL(blur_kernel, grid2, blk, 0, st, src, dst, W, H, horizontal);
+        half4 *t = src; src = dst; dst = t;
+        horizontal = !horizontal;
+      }
+      bloom = src;
+    }
+    hipLaunchKernelGGL(light_kernel, lin, blk, 0, st, frag, bloom, out, ps->enableFXAA ? stage8 : nullptr, (int)n,
+                       ps->enableHDR, ps->enableBloom, ps->exposure);
+  } else {
+    hipLaunchKernelGGL(quant8_kernel, lin, blk, 0, st, frag, stage8, (int)n);
+  }
+  if (ps->enableFXAA) hipLaunchKernelGGL(fxaa_kernel, grid2, blk, 0, st, stage8, out, W, H);
+  HIP_OK(hipGetLastError());
+  return RM_OK;
+}

@@ -679,6 +679,7 @@ int rm_abi_sizeof(int which) {
     case 6: return (int)sizeof(RmHostSettings);
     case 7: return (int)sizeof(RmCameraData);
     case 8: return (int)sizeof(RmTexture);
+    case 9: return (int)sizeof(RmPostSettings);
     default: return -1;
   }
 }

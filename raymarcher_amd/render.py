@@ -196,6 +196,15 @@ class Renderer:
                                     num_shards, shard_stride_rows, self._stream()))
         return frame
 
+    def post_process(self, frame, bright, post):
+        """rm_post_process: bloom / HDR / gamma / FXAA (applyLightEffects + applyFXAA, realtimerender.cpp:78-165)."""
+        t = self.torch
+        H, W = frame.shape[0], frame.shape[1]
+        out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
+        check(lib().rm_post_process(C.c_void_p(frame.data_ptr()), C.c_void_p(bright.data_ptr()) if bright is not None else None,
+                                    C.c_void_p(out.data_ptr()), W, H, C.byref(post), self._stream()))
+        return out
+
     def to_rgba8(self, frame):
         """Clamp/quantise + vertical flip (saveViewportImage, realtime.cpp:284-350) → uint8 (H, W, 4)."""
         t = self.torch

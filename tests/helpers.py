@@ -157,3 +157,14 @@ def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=Fa
     if counters:
         res.append(cnt)
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def oracle_post(frag, bright, post):
+    """rmo_post_process on host arrays (H, W, 4)."""
+    H, W = frag.shape[:2]
+    out = np.empty((H, W, 4), dtype=np.float32)
+    frag = np.ascontiguousarray(frag, dtype=np.float32)
+    b = None if bright is None else np.ascontiguousarray(bright, dtype=np.float32)
+    st = oracle().rmo_post_process(fptr(frag), fptr(b) if b is not None else None, fptr(out), W, H, C.byref(post))
+    assert st == 0, f"oracle post status {st}"
+    return out

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_compiled_library():
     L = lib()
     structs = [abi.RmObject, abi.RmLight, abi.RmCamera, abi.RmGlobals, abi.RmSettings, abi.RmCounters,
-               abi.RmHostSettings, abi.RmCameraData, abi.RmTexture]
+               abi.RmHostSettings, abi.RmCameraData, abi.RmTexture, abi.RmPostSettings]
     for i, s in enumerate(structs):
         assert L.rm_abi_sizeof(i) == C.sizeof(s), s.__name__
     assert L.rm_abi_sizeof(99) == -1

@@ -373,6 +373,56 @@ def test_scenefile_with_texture_end_to_end(renderer, tmp_path):
     assert_bit_equal(renderer.render(t, s, W, H).cpu().numpy(), ref, "scenefile with texture")
 
 
+POST_CASES = {
+    "gamma": dict(enableGammaCorrection=1),
+    "hdr": dict(enableHDR=1, exposure=1.7),
+    "bloom": dict(enableBloom=1, exposure=1.0),
+    "bloom_hdr_fxaa": dict(enableBloom=1, enableHDR=1, enableFXAA=1, exposure=0.8),
+    "fxaa_only": dict(enableFXAA=1),
+    "gamma_fxaa": dict(enableGammaCorrection=1, enableFXAA=1),
+    "none": dict(),
+}
+
+
+@pytest.mark.parametrize("name", list(POST_CASES))
+def test_post_passes_bit_exact(renderer, name):
+    """applyLightEffects + applyFXAA (realtimerender.cpp:78-165) on a rendered frame with bright pixels."""
+    W, H = 150, 90  # not multiples of the 256-wide blocks
+    scene = reflect_refract_scene(W, H)
+    for li in scene[3]:
+        li.color[0] *= 2.5; li.color[1] *= 2.5; li.color[2] *= 2.5  # over-exposed: BrightColor is populated
+    s = abi.default_settings(enableReflection=1)
+    frag, bright = renderer.render(tables_of(scene), s, W, H, bright=True)
+    assert float(bright[..., :3].max()) > 1.0
+    post = abi.RmPostSettings(**{"exposure": 1.0, **POST_CASES[name]})
+    got = renderer.post_process(frag, bright, post).cpu().numpy()
+    ref = h.oracle_post(frag.cpu().numpy(), bright.cpu().numpy(), post)
+    assert_bit_equal(got, ref, f"post {name}")
+    if name != "none":
+        assert np.abs(got[..., :3] - frag.cpu().numpy()[..., :3]).max() > 0.01
+    img = renderer.to_rgba8(renderer.post_process(frag, bright, post)).cpu().numpy()
+    exp = (np.clip(ref[::-1], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert (img == exp).all()
+
+
+def test_post_full_size_4k(renderer):
+    """3840×2160: determinism, and bit equality with the oracle on a horizontal band that contains its whole
+    9-tap / FXAA neighbourhood (bloom off so rows do not depend on far rows)."""
+    import torch
+    W, H = 3840, 2160
+    from raymarcher_amd import scenes
+    t = scenes.mandelbulb(W, H)
+    s = abi.default_settings(fractalIters=12)
+    frag, bright = renderer.render(t, s, W, H, bright=True)
+    post = abi.RmPostSettings(enableFXAA=1, enableHDR=1, exposure=1.3)
+    a = renderer.post_process(frag, bright, post)
+    b = renderer.post_process(frag, bright, post)
+    assert (a.view(dtype=torch.int32) == b.view(dtype=torch.int32)).all()
+    post_b = abi.RmPostSettings(enableBloom=1, enableHDR=1, enableFXAA=1, exposure=1.0)
+    c = renderer.post_process(frag, bright, post_b)
+    assert torch.isfinite(c).all() and float(c[..., :3].max()) <= 1.0 and float(c[..., :3].min()) >= 0.0
+
+
 # ---------------------------------------------------------------- edge cases of the boundary
 def test_row_ranges_and_ragged_sizes(renderer):
     W, H = 37, 29  # not multiples of the 8×8 wave tile

@@ -206,6 +206,46 @@ def test_textured_cube_face_samples_the_expected_texels():
     assert np.allclose(img[Hh // 2, W // 2, :3], [0.5, 0.5, 0.25], atol=0.02)  # centre: average of the four texels
 
 
+def test_post_pass_properties():
+    """Known answers of the post passes (blur.frag, hdr.frag, fxaa.frag)."""
+    rng = np.random.default_rng(9)
+    Hh, W = 40, 56
+    flat = np.full((Hh, W, 4), 0.25, dtype=np.float32)
+    flat[..., 3] = 1
+    # nothing enabled: identity
+    assert (h.oracle_post(flat, None, abi.RmPostSettings()) == flat).all()
+    # gamma: 0.25^(1/2.2)
+    g = h.oracle_post(flat, None, abi.RmPostSettings(enableGammaCorrection=1))
+    assert np.allclose(g[..., :3], 0.25 ** (1 / 2.2), atol=2e-4) and (g[..., 3] == 1).all()
+    # hdr: 1 - exp(-c·exposure)
+    e = h.oracle_post(flat, None, abi.RmPostSettings(enableHDR=1, exposure=2.0))
+    assert np.allclose(e[..., :3], 1 - np.exp(-0.5), atol=2e-4)
+    # bloom of a constant bright plane stays constant (weights sum to 1 within fp16 rounding) and is added before tone mapping
+    bright = np.full((Hh, W, 4), 2.0, dtype=np.float32)
+    b = h.oracle_post(flat, bright, abi.RmPostSettings(enableBloom=1, exposure=1.0))
+    assert np.allclose(b[..., :3], 1 - np.exp(-(0.25 + 2.0)), atol=3e-3)
+    # a single bright texel spreads along both axes (9 passes: 5 horizontal + 4 vertical) and sums to ≈ its energy
+    spot = np.zeros((Hh, W, 4), dtype=np.float32)
+    spot[20, 28, :3] = 8.0
+    z = np.zeros((Hh, W, 4), dtype=np.float32)
+    zb = h.oracle_post(z, spot, abi.RmPostSettings(enableBloom=1, enableHDR=1, exposure=1.0))
+    energy = -np.log(1 - zb[..., 0].astype(np.float64))
+    assert abs(energy.sum() - 8.0) < 0.2 and energy[20, 28] == energy.max() and energy[20, 40] > 0 and energy[33, 28] > 0
+    # FXAA leaves flat regions untouched and softens a hard vertical edge
+    edge = np.zeros((Hh, W, 4), dtype=np.float32)
+    edge[:, W // 2:, :3] = 1.0
+    edge[..., 3] = 1
+    f = h.oracle_post(edge, None, abi.RmPostSettings(enableFXAA=1))
+    # (the source wraps with GL_REPEAT — the reference never sets a wrap mode on it — so columns 0 / W-1 also form an edge)
+    assert (f[:, 3:W // 2 - 3, :3] == 0).all() and (f[:, W // 2 + 3:W - 3, :3] == 1).all()
+    mid = f[Hh // 2, W // 2 - 1:W // 2 + 1, 0]
+    assert 0 < mid[0] < 1 or 0 < mid[1] < 1
+    # the 8-bit FXAA source quantises its input
+    noisy = rng.uniform(0, 1, (Hh, W, 4)).astype(np.float32)
+    fx = h.oracle_post(noisy * 0 + 0.5004, None, abi.RmPostSettings(enableFXAA=1))
+    assert np.allclose(fx[..., :3], round(0.5004 * 255) / 255, atol=1e-6)
+
+
 def test_row_range_equals_full_frame_rows_and_is_thread_count_independent():
     W, Hh = 40, 30
     scene = h.scene_mandelbulb(W, Hh)
