@@ -1294,6 +1294,7 @@ int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float
       case RM_FN_DIV: out[i] = x[i] / y[i]; break;
       case RM_FN_PNOISE3: out[i] = pnoise(V3(x[i], y[i], z[i])); break;
       case RM_FN_ASIN: out[i] = rm_asin(x[i]); break;
+      case RM_FN_Q16: out[i] = q16(x[i]); break;
       default: return RM_ERR_INVALID_ARGUMENT;
     }
   }

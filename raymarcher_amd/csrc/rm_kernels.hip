@@ -3,6 +3,7 @@
 // Replaces Realtime::rayMarch() of the reference (src/realtimerender.cpp:53-87): instead of uploading
 // ~600 uniforms by name and drawing a full-screen quad through resources/raymarch.{vert,frag}, the
 // launcher copies one constant SceneBlock to the device and launches one lane per pixel.
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -68,6 +69,7 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
     case RM_FN_DIV: r = a / b; break;
     case RM_FN_PNOISE3: r = pnoise(v3(a, b, c)); break;
     case RM_FN_ASIN: r = asin_(a); break;
+    case RM_FN_Q16: r = __half2float(__float2half_rn(a)); break;
   }
   out[i] = r;
 }

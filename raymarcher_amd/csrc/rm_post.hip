@@ -50,6 +50,10 @@ __global__ void blur_kernel(const half4 *__restrict__ src, half4 *__restrict__ d
     r = fma(__half2float(p.x), w[i], r); g = fma(__half2float(p.y), w[i], g); b = fma(__half2float(p.z), w[i], b);
     r = fma(__half2float(m.x), w[i], r); g = fma(__half2float(m.y), w[i], g); b = fma(__half2float(m.z), w[i], b);
   }
+  // The sums must be rounded to binary32 BEFORE the binary16 store (that is what a GL fragment shader writing an
+  // RGBA16F target does).  Without the barrier hipcc fuses the last fma with the conversion (v_fma_mixlo_f16, a
+  // single rounding), which differs from the two-step rounding in rare near-tie cases.
+  asm volatile("" : "+v"(r), "+v"(g), "+v"(b));
   dst[(size_t)y * W + x] = half4{__float2half_rn(r), __float2half_rn(g), __float2half_rn(b), __float2half_rn(1.0f)};
 }
 

@@ -60,6 +60,11 @@ def _math_inputs(fn, n, rng):
         x = np.concatenate([np.exp(rng.uniform(-5, 5, n)), [0, 0, 0, 1, 2, -1, np.inf, 0.9, 1e-40]])
         y = np.concatenate([rng.uniform(-20, 100, n), [0, 1, -1, 5, 0.5, 2, 2, 1e5, 2]])
         return x.astype(f), y.astype(f)
+    if fn == abi.RM_FN_Q16:
+        x = np.concatenate([rng.normal(0, 1, n) * np.exp(rng.uniform(-25, 12, n)),
+                            [0, -0.0, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8, 2.99e-8, 1e-9, 65504, 65519.9, 65520, 1e6, np.inf, np.nan,
+                             1.00048828125, 1.000244140625, 1.000732421875]])
+        return x.astype(f), None
     if fn == abi.RM_FN_SQRT:
         x = np.concatenate([np.exp(rng.uniform(-87, 88, n)), [0, -0.0, 1e-45, 1e-40, 1.17549435e-38, np.inf, -1, np.nan, 2, 4]])
         return x.astype(f), None
@@ -71,7 +76,7 @@ def _math_inputs(fn, n, rng):
 
 
 @pytest.mark.parametrize("fn", [abi.RM_FN_SIN, abi.RM_FN_COS, abi.RM_FN_ACOS, abi.RM_FN_ASIN, abi.RM_FN_ATAN2, abi.RM_FN_LOG2,
-                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV])
+                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV, abi.RM_FN_Q16])
 def test_math_contract_bit_exact(renderer, fn):
     import torch
     rng = np.random.default_rng(1000 + fn)
