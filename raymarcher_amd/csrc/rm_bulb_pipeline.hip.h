@@ -72,7 +72,7 @@ struct BulbParams {  // wave-uniform; read ONCE before the persistent loop so th
   float power, pexp, jx, jy, scale;
   float m00, m01, m02, m10, m11, m12, m20, m21, m22, m30, m31, m32;  // rows 0-2 of invModel, by column
   int iters;
-  bool julia;
+  bool julia, angleSafe;
 };
 RM_DEV BulbParams bulbParams(const SceneBlock *sb) {
   BulbParams k;
@@ -81,6 +81,7 @@ RM_DEV BulbParams bulbParams(const SceneBlock *sb) {
   k.jx = sb->g.juliaSeed[0];
   k.jy = sb->g.juliaSeed[1];
   k.julia = len2(k.jx, k.jy) != 0.0f;
+  k.angleSafe = fabs_(k.power) < 1.0e6f;
   k.iters = sb->s.fractalIters;
   k.scale = sb->objs[0].scaleFactor;
   const float *M = sb->objs[0].invModel;
@@ -108,8 +109,8 @@ RM_DEV bool deStep(BulbDE &s, const BulbParams &k) {
   float a = k.power * atan2_(s.w.x, s.w.z);
   float pr = pow_(r, k.power);
   float sb_, cb_, sa_, ca_;
-  sincos_(b, sb_, cb_);
-  sincos_(a, sa_, ca_);
+  if (k.angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
+  else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
   s.w = v3(fma(pr, sb_ * sa_, s.c.x), fma(pr, cb_, s.c.y), fma(pr, sb_ * ca_, s.c.z));
   s.ty = min_(s.ty, fabs_(s.w.y));
   s.tz = min_(s.tz, fabs_(s.w.z));

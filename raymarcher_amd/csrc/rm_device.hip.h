@@ -142,6 +142,9 @@ RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &
   const float pexp = (power - 1.0f) / 2.0f;
   const int iters = sb->s.fractalIters;
   const bool julia = len2(sb->g.juliaSeed[0], sb->g.juliaSeed[1]) != 0.0f;  // frag:782
+  // angles are power·acos(·) ∈ [0, power·pi] and power·atan(·,·) ∈ [−power·pi, power·pi], always finite: for
+  // |power| < 1e6 they stay inside the contract range of sin/cos and the range guard can be dropped
+  const bool angleSafe = fabs_(power) < 1.0e6f;
   V3 w = pos;
   float m = dot(w, w);
   V4 trap = v4(fabs_(w.x), fabs_(w.y), fabs_(w.z), m);
@@ -155,8 +158,8 @@ RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &
     float a = power * atan2_(w.x, w.z);         // frag:791
     float pr = pow_(r, power);
     float sb_, cb_, sa_, ca_;
-    sincos_(b, sb_, cb_);
-    sincos_(a, sa_, ca_);
+    if (angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
+    else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
     w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
     trap = v4(min_(trap.x, fabs_(w.x)), min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
     m = dot(w, w);

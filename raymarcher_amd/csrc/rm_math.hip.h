@@ -63,6 +63,26 @@ RM_DEV void sincos_(float x, float &sn, float &cs) {
   sn = u2f(f2u(sv) ^ ((uint32_t)(q & 2) << 30));
   cs = u2f(f2u(cv) ^ ((uint32_t)((q + 1) & 2) << 30));
 }
+// Same bits as sincos_ for finite |x| < 2^22 (the guard of the contract is dead there); used by the Mandelbulb
+// iteration, whose angles are power·acos(·) and power·atan(·,·): finite and bounded by power·pi.
+RM_DEV void sincos_inrange_(float x, float &sn, float &cs) {
+  float k = __builtin_rintf(x * k2oPi);
+  float r = fma(-k, kPio2, x);
+  r = fma(-k, kPio2Mid, r);
+  r = fma(-k, kPio2Lo, r);
+  int q = (int)k;
+  float z = r * r;
+  float s = fma(z, -1.950213627e-04f, 8.332063444e-03f);
+  s = fma(z, s, -1.666665375e-01f);
+  float sp = fma(s * z, r, r);
+  float c = fma(z, 2.441812649e-05f, -1.388718490e-03f);
+  c = fma(z, c, 4.166664183e-02f);
+  float cp = fma(z, c * z, fma(z, -0.5f, 1.0f));
+  float sv = (q & 1) ? cp : sp;
+  float cv = (q & 1) ? sp : cp;
+  sn = u2f(f2u(sv) ^ ((uint32_t)(q & 2) << 30));
+  cs = u2f(f2u(cv) ^ ((uint32_t)((q + 1) & 2) << 30));
+}
 RM_DEV float sin_(float x) { float s, c; sincos_(x, s, c); return s; }
 RM_DEV float cos_(float x) { float s, c; sincos_(x, s, c); return c; }
 
@@ -148,9 +168,11 @@ RM_DEV float exp2_(float x) {
   p = fma(f, p, 2.402264774e-01f);
   p = fma(f, p, 6.931471825e-01f);
   p = fma(f, p, 1.0f);
-  // clamp n only to keep the int conversion defined on lanes whose result is replaced below
-  int ni = (int)max_(min_(n, 200.0f), -200.0f);
-  float r = p * u2f((uint32_t)(ni + 127) << 23);
+  // 2^n without a float→int conversion: n + 1.5·2^23 holds the integer n in its low mantissa bits (exact for
+  // |n| < 2^22), so ((bits + 127) << 23) = (bits << 23) + 0x3f800000 is the exponent field of 2^n for every n the
+  // contract does not override below (−125 < x < 128); for other x the value is replaced.
+  uint32_t scale = (f2u(n + 12582912.0f) << 23) + 0x3f800000u;
+  float r = p * u2f(scale);
   r = (x >= 128.0f) ? __builtin_inff() : r;
   return (x > -125.0f) ? r : 0.0f;
 }
