@@ -1295,6 +1295,7 @@ int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float
       case RM_FN_PNOISE3: out[i] = pnoise(V3(x[i], y[i], z[i])); break;
       case RM_FN_ASIN: out[i] = rm_asin(x[i]); break;
       case RM_FN_Q16: out[i] = q16(x[i]); break;
+      case RM_FN_SQRT_FAST: out[i] = rm_sqrt(x[i]); break;
       default: return RM_ERR_INVALID_ARGUMENT;
     }
   }

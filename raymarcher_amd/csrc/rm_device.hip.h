@@ -153,7 +153,7 @@ RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &
   for (int i = 0; i < iters; i++) {
     if (COUNT) cnt.iters++;
     dz = fma(power * pow_(m, pexp), dz, 1.0f);  // frag:787
-    float r = sqrt_(m);                         // frag:789
+    float r = sqrt_fast_(m);                    // frag:789
     float b = power * acos_(w.y / r);           // frag:790
     float a = power * atan2_(w.x, w.z);         // frag:791
     float pr = pow_(r, power);
@@ -166,7 +166,7 @@ RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &
     if (m > 2.0f) break;  // frag:798 (FRACTALS_BAILOUT)
   }
   resColor = v4(m, trap.y, trap.z, trap.w);
-  return ((0.25f * log_(m)) * sqrt_(m)) / dz;  // frag:802
+  return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;  // frag:802
 }
 
 // frag:808-827

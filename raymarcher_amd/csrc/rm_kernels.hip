@@ -70,6 +70,7 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
     case RM_FN_PNOISE3: r = pnoise(v3(a, b, c)); break;
     case RM_FN_ASIN: r = asin_(a); break;
     case RM_FN_Q16: r = __half2float(__float2half_rn(a)); break;
+    case RM_FN_SQRT_FAST: r = sqrt_fast_(a); break;
   }
   out[i] = r;
 }

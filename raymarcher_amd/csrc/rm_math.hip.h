@@ -34,6 +34,22 @@ RM_DEV float smoothstep_(float e0, float e1, float x) {
   return (t * t) * fma(-2.0f, t, 3.0f);
 }
 RM_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded sqrt for x == ±0, x >= 2^-96, +inf, NaN and negative x: the refinement hipcc itself emits for
+// sqrtf (v_sqrt_f32, then pick among s−1ulp, s, s+1ulp by the sign of the fma residuals) without the 2^32
+// pre-scaling that only inputs below 2^-96 need.  Correct rounding is unique, so the bits equal sqrt_().
+RM_DEV float sqrt_noscale_(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  float sd = u2f(f2u(s) - 1u), su = u2f(f2u(s) + 1u);
+  float rd = fma(-sd, s, x), ru = fma(-su, s, x);
+  s = (rd <= 0.0f) ? sd : s;
+  return (ru > 0.0f) ? su : s;
+}
+// sqrt_() with a wave-uniform choice of the cheap form: the scaled form runs only if some lane holds a positive
+// input below 2^-96 (practically never).
+RM_DEV float sqrt_fast_(float x) {
+  if (__builtin_expect(__ballot((x > 0.0f) && (x < 1.262177448e-29f)) != 0, 0)) return sqrt_(x);
+  return sqrt_noscale_(x);
+}
 
 constexpr float kPi = 3.14159274f;          // 0x40490fdb
 constexpr float kPio2 = 1.57079637f;        // 0x3fc90fdb
@@ -97,7 +113,8 @@ RM_DEV float acos_(float x) {
   float ax = fabs_(x);
   bool small = ax <= 0.5f;
   float z = small ? (x * x) : ((1.0f - ax) * 0.5f);
-  float s = small ? x : sqrt_(z);
+  // on the sqrt branch z = (1−|x|)/2 is 0, >= 2^-25, negative or NaN: never a tiny positive number
+  float s = small ? x : sqrt_noscale_(z);
   float as = fma(s * z, asin_p(z), s);
   float big = 2.0f * as;
   big = (x < 0.0f) ? (kPi - big) : big;

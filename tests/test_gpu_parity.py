@@ -65,8 +65,9 @@ def _math_inputs(fn, n, rng):
                             [0, -0.0, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8, 2.99e-8, 1e-9, 65504, 65519.9, 65520, 1e6, np.inf, np.nan,
                              1.00048828125, 1.000244140625, 1.000732421875]])
         return x.astype(f), None
-    if fn == abi.RM_FN_SQRT:
-        x = np.concatenate([np.exp(rng.uniform(-87, 88, n)), [0, -0.0, 1e-45, 1e-40, 1.17549435e-38, np.inf, -1, np.nan, 2, 4]])
+    if fn in (abi.RM_FN_SQRT, abi.RM_FN_SQRT_FAST):
+        x = np.concatenate([np.exp(rng.uniform(-87, 88, n)), np.exp(rng.uniform(-68, -64, n // 4)), rng.uniform(0, 4, n),
+                            [0, -0.0, 1e-45, 1e-40, 1.17549435e-38, 1.2621774e-29, 1.2621775e-29, 1.262177e-29, np.inf, -1, np.nan, 2, 4, 0.25, 2.9802322e-8]])
         return x.astype(f), None
     if fn == abi.RM_FN_DIV:
         x = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-40, 40, n)), [0, 1, 1, -1, 0, np.inf, 1e-40, 1e38, 1]])
@@ -76,7 +77,7 @@ def _math_inputs(fn, n, rng):
 
 
 @pytest.mark.parametrize("fn", [abi.RM_FN_SIN, abi.RM_FN_COS, abi.RM_FN_ACOS, abi.RM_FN_ASIN, abi.RM_FN_ATAN2, abi.RM_FN_LOG2,
-                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV, abi.RM_FN_Q16])
+                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV, abi.RM_FN_Q16, abi.RM_FN_SQRT_FAST])
 def test_math_contract_bit_exact(renderer, fn):
     import torch
     rng = np.random.default_rng(1000 + fn)
