@@ -149,7 +149,8 @@ def main():
         kernel_name = {0: "rm::render_kernel<true,false> (one lane per pixel, 8x8 tile per wave)",
                        1: "rm::render_kernel<true,false> (one lane per pixel, 8x8 tile per wave)",
                        2: "pipeline A: bulb_primary+surface+shadow+shade kernels (state machines + lane refill)",
-                       3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)"}[path]
+                       3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)",
+                       4: "pipeline C: pipeline B with step-budgeted march passes and re-compaction"}[path]
         mpix = W * H * args.steps / dt / 1e6
         flops_frame = cnt.bulbIters * FLOP_PER_ITER + cnt.sceneEvals * FLOP_PER_EVAL + cnt.hitPixels * FLOP_PER_HIT
         # the dominant kernel of one launch processes 1/world of the frame (interleaved tiles ≈ equal work)

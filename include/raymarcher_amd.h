@@ -225,7 +225,8 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
 /* Which schedule renders the single-Mandelbulb scene class: 0 = the measured-fastest one (default),
  * 1 = one lane per pixel (rm::render_kernel, the only path for every other scene), 2 = four-kernel pipeline with
  * per-lane state machines and ballot-based lane refill, 3 = four-kernel pipeline with plain loops on compacted
- * hit / shadow-ray lists.  All paths produce identical bits; the switch exists for A/B measurement and tests. */
+ * hit / shadow-ray lists, 4 = as 3 with the march stages cut into step-budgeted passes (survivors re-compacted
+ * between launches).  All paths produce identical bits; the switch exists for A/B measurement and tests. */
 int rm_set_kernel_path(int path);
 
 /*

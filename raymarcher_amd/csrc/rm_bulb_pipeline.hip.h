@@ -560,4 +560,148 @@ __global__ __launch_bounds__(256) void bulbB_shade_kernel(const SceneBlock *__re
   }
 }
 
+// =====================================================================================================
+// Variant C: variant B with the two march stages cut into passes with a step budget.  A ray that has not
+// ended when its budget is used up is appended (block-aggregated) to a continuation queue with its state
+// (depth, step count, penumbra factor) and resumes in the next launch, packed densely with the other survivors.
+// The march state between two steps of frag:1459-1470 / 1708-1714 is exactly (t, i[, res]), so resuming is exact.
+// Lanes therefore idle for at most `budget` steps per pass instead of for the longest march of their wave.
+// =====================================================================================================
+struct BulbWsC {
+  BulbWsB b;
+  // primary continuation queues (ping-pong): packed output index, depth, steps done
+  int *pPix[2]; float *pT[2]; int *pSteps[2];
+  // shadow continuation queues (ping-pong): ray = light·cap + hit, depth, penumbra factor, steps done
+  uint32_t *sRay[2]; float *sT[2]; float *sPen[2]; int *sSteps[2];
+};
+constexpr int kCntPrimary = 8;   // counters[8 + pass]  : rays queued FOR primary pass `pass` (pass >= 1)
+constexpr int kCntShadow = 24;   // counters[24 + pass] : rays queued FOR shadow pass `pass` (pass >= 1)
+
+// One budgeted stretch of raymarch() (frag:1459-1470).  Returns 0 = budget used up, 1 = ended without a hit,
+// 2 = hit (res filled).
+RM_DEV int marchBudget(const SceneBlock *sb, V3 ro, V3 rd, float end, int maxSteps, int budget, float &t, int &steps,
+                       MarchRes &res) {
+  Counters cnt{0, 0};
+  for (int local = 0; ; ) {
+    if (steps >= maxSteps) return 1;
+    const SceneMin c = sdScene<true, false>(sb, madd(rd, t, ro), cnt);
+    const bool hit = fabs_(c.d) < kSurfaceDist;
+    if (hit || t > end) {
+      res.obj = hit ? c.idx : -1;
+      res.d = t - c.d;  // frag:1477
+      res.trap = c.trap;
+      return hit ? 2 : 1;
+    }
+    t = fma(c.d, 1.0f, t);
+    steps++;
+    if (++local >= budget) return 0;
+  }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void bulbC_primary_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+                                                             int nRows, float4 *__restrict__ out,
+                                                             float4 *__restrict__ bright, BulbWsC ws, int pass, int budget) {
+  __shared__ uint32_t scratch[8];
+  const int maxSteps = sb->s.maxSteps;
+  const float far = sb->cam.initialFar;
+  const int inQ = (pass + 1) & 1, outQ = pass & 1;  // pass p reads queue (p+1)&1 (written by pass p-1) and writes p&1
+  const uint32_t nIn = FIRST ? 0u : ws.b.counters[kCntPrimary + pass];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t trips = FIRST ? 1u : (nIn + stride - 1) / stride;
+  for (uint32_t trip = 0; trip < trips; trip++) {
+    bool live;
+    int pix = 0, steps = 0;
+    float t = 0.0f;
+    if (FIRST) {
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const int x = blockIdx.x * 32 + wave * 8 + (lane & 7), r = blockIdx.y * 8 + (lane >> 3);
+      live = x < W && r < nRows;
+      pix = r * W + x;
+    } else {
+      const uint32_t j = trip * stride + blockIdx.x * blockDim.x + threadIdx.x;
+      live = j < nIn;
+      if (live) { pix = ws.pPix[inQ][j]; t = ws.pT[inQ][j]; steps = ws.pSteps[inQ][j]; }
+    }
+    int state = 1;
+    MarchRes res;
+    res.obj = -1; res.d = 0.0f; res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) {
+      const int r = pix / W, x = pix - r * W;
+      float ndcx, ndcy;
+      pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
+      V3 ro, rd;
+      primaryRay(sb, ndcx, ndcy, ro, rd);
+      state = marchBudget(sb, ro, rd, far, maxSteps, budget, t, steps, res);
+      if (state == 1) {
+        const V3 bg = backgroundColor(sb);
+        out[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
+        if (bright) bright[pix] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+      }
+    }
+    const bool isHit = live && state == 2, cont = live && state == 0;
+    const uint32_t hs = blockAppend(isHit, &ws.b.counters[1], scratch);
+    if (isHit) {
+      ws.b.hitPix[hs] = pix;
+      ws.b.hitRec[hs] = make_float4(res.d, res.trap.y, res.trap.z, res.trap.w);
+    }
+    const uint32_t cs = blockAppend(cont, &ws.b.counters[kCntPrimary + pass + 1], scratch);
+    if (cont) { ws.pPix[outQ][cs] = pix; ws.pT[outQ][cs] = t; ws.pSteps[outQ][cs] = steps; }
+  }
+}
+
+// One budgeted stretch of softshadow() (frag:1708-1714).  Returns 0 = budget used up, 1 = ended, hit flag in `hit`.
+RM_DEV int shadowBudget(const SceneBlock *sb, V3 so, V3 L, float maxT, int maxSteps, int budget, float &t, float &pen,
+                        int &steps, bool &hit) {
+  Counters cnt{0, 0};
+  for (int local = 0; ; ) {
+    hit = false;
+    if (steps >= maxSteps) return 1;
+    const SceneMin c = sdScene<true, false>(sb, madd(L, t, so), cnt);
+    hit = fabs_(c.d) < kSurfaceDist;
+    if (hit || t > maxT) return 1;
+    pen = min_(pen, (8.0f * c.d) / t);
+    t = t + fabs_(c.d);
+    steps++;
+    if (++local >= budget) return 0;
+  }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void bulbC_shadow_kernel(const SceneBlock *__restrict__ sb, BulbWsC ws, int pass, int budget) {
+  __shared__ uint32_t scratch[8];
+  const int maxSteps = sb->s.maxSteps;
+  const float far = sb->cam.initialFar;
+  const int nl = sb->numLights;
+  const int inQ = (pass + 1) & 1, outQ = pass & 1;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  // FIRST: the per-light lists stage 2 emitted; otherwise the continuation queue of the previous pass
+  const int lists = FIRST ? nl : 1;
+  for (int li0 = 0; li0 < lists; li0++) {
+    const uint32_t nIn = FIRST ? ws.b.counters[4 + li0] : ws.b.counters[kCntShadow + pass];
+    const uint32_t trips = (nIn + stride - 1) / stride;
+    for (uint32_t trip = 0; trip < trips; trip++) {
+      const uint32_t j = trip * stride + blockIdx.x * blockDim.x + threadIdx.x;
+      const bool live = j < nIn;
+      uint32_t ray = 0;
+      float t = 0.0f, pen = 1.0f;
+      int steps = 0, state = 1;
+      bool hit = false;
+      if (live) {
+        if (FIRST) ray = (uint32_t)li0 * ws.b.cap + ws.b.rayHit[(uint32_t)li0 * ws.b.cap + j];
+        else { ray = ws.sRay[inQ][j]; t = ws.sT[inQ][j]; pen = ws.sPen[inQ][j]; steps = ws.sSteps[inQ][j]; }
+        const uint32_t li = ray / ws.b.cap, h = ray - li * ws.b.cap;
+        const float4 P = ws.b.surfP[h], Nn = ws.b.surfN[h];
+        const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
+        const LightGeom g = lightSetup(sb->lights[li], p, far);
+        state = shadowBudget(sb, shadowOrigin(p, N), g.L, g.maxT, maxSteps, budget, t, pen, steps, hit);
+        if (state == 1) ws.b.shadow[ray] = make_int2(hit ? 0 : -1, (int)f2u(pen));
+      }
+      const bool cont = live && state == 0;
+      const uint32_t cs = blockAppend(cont, &ws.b.counters[kCntShadow + pass + 1], scratch);
+      if (cont) { ws.sRay[outQ][cs] = ray; ws.sT[outQ][cs] = t; ws.sPen[outQ][cs] = pen; ws.sSteps[outQ][cs] = steps; }
+    }
+  }
+}
+
 }  // namespace rm

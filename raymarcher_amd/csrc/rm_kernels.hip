@@ -18,7 +18,11 @@
 namespace rm {
 
 // Block = 4 waves side by side, each wave an 8×8 pixel tile → the block covers 32×8 pixels.
-constexpr int kBlockW = 32, kBlockH = 8;
+#ifndef RM_TILE_W
+#define RM_TILE_W 8   // pixels per wave tile, horizontally (RM_TILE_W × RM_TILE_H = 64)
+#endif
+constexpr int kTileW = RM_TILE_W, kTileH = 64 / RM_TILE_W;
+constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 
 template <bool BULB, bool COUNT, bool ENV, bool TEX>
 __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
@@ -35,8 +39,8 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int x = blockIdx.x * kBlockW + wave * 8 + (lane & 7);
-  const int r = blockIdx.y * kBlockH + (lane >> 3);
+  const int x = blockIdx.x * kBlockW + wave * kTileW + (lane % kTileW);
+  const int r = blockIdx.y * kBlockH + (lane / kTileW);
   if (x >= W || r >= nRows) return;
   const int y = map.frameRow(r);
   V4 col, br;
@@ -168,12 +172,14 @@ int acquire_slot(Slot **out) {
 }
 
 // Carve the pipeline workspace for `pixels` pixels and `nl` lights out of the device allocation.
-int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWsB *wsB) {
+int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWsB *wsB, BulbWsC *wsC,
+                   bool withQueues) {
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
   const size_t nlq = (size_t)(nl > 0 ? nl : 1);
-  const size_t oCnt = 0, oPix = align(64), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
+  const size_t oCnt = 0, oPix = align(256), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
                oN = oP + align(pixels * 16), oSh = oN + align(pixels * 16), oRay = oSh + align(pixels * nlq * 8),
-               total = oRay + align(pixels * nlq * 4);
+               oQ = oRay + align(pixels * nlq * 4),
+               qBytes = withQueues ? 2 * (3 * align(pixels * 4) + 4 * align(pixels * nlq * 4)) : 0, total = oQ + qBytes;
   if (total > ds.wsBytes) {
     HIP_OK(hipStreamSynchronize(stream));
     if (ds.wsMem) HIP_OK(hipFree(ds.wsMem));
@@ -192,6 +198,20 @@ int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, B
   wsB->surfN = ws->surfN; wsB->shadow = ws->shadow;
   wsB->rayHit = reinterpret_cast<uint32_t *>(b + oRay);
   wsB->cap = (uint32_t)pixels;
+  wsC->b = *wsB;
+  if (withQueues) {
+    char *q = b + oQ;
+    auto take = [&](size_t bytes) { char *r = q; q += align(bytes); return r; };
+    for (int k = 0; k < 2; k++) {
+      wsC->pPix[k] = reinterpret_cast<int *>(take(pixels * 4));
+      wsC->pT[k] = reinterpret_cast<float *>(take(pixels * 4));
+      wsC->pSteps[k] = reinterpret_cast<int *>(take(pixels * 4));
+      wsC->sRay[k] = reinterpret_cast<uint32_t *>(take(pixels * nlq * 4));
+      wsC->sT[k] = reinterpret_cast<float *>(take(pixels * nlq * 4));
+      wsC->sPen[k] = reinterpret_cast<float *>(take(pixels * nlq * 4));
+      wsC->sSteps[k] = reinterpret_cast<int *>(take(pixels * nlq * 4));
+    }
+  }
   return RM_OK;
 }
 
@@ -311,11 +331,12 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     }
     BulbWs ws;
     BulbWsB wsB;
+    BulbWsC wsC;
     // hit-list capacity: every pixel may hit, plus one partly used 64-slot chunk per persistent wave
     const size_t slots = (size_t)nRows * W + (size_t)kSlotChunk * ds.numCUs * 8 * 4;
-    st = bulb_workspace(ds, slots, numLights, stream, &ws, &wsB);
+    st = bulb_workspace(ds, slots, numLights, stream, &ws, &wsB, &wsC, path == 4);
     if (st != RM_OK) return st;
-    HIP_OK(hipMemsetAsync(ws.counters, 0, 64, stream));
+    HIP_OK(hipMemsetAsync(ws.counters, 0, 256, stream));
     // tuning knobs for A/B runs (defaults are the measured best)
     static const int blocksPerCU = std::getenv("RM_PIPE_BLOCKS_PER_CU") ? std::atoi(std::getenv("RM_PIPE_BLOCKS_PER_CU")) : 8;
     static const int flushThr = std::getenv("RM_PIPE_FLUSH") ? std::atoi(std::getenv("RM_PIPE_FLUSH")) : kDefaultFlushThreshold;
@@ -329,6 +350,21 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       hipLaunchKernelGGL(bulb_shadow_kernel, persistent, block, 0, stream, slot->dev, ws, flushThr);
       if ((st = stamp(3)) != RM_OK) return st;
       hipLaunchKernelGGL(bulb_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws);
+    } else if (path == 4) {
+      // step budgets per pass; the last pass always runs to the end of the march
+      static const int kBudgets[] = {16, 16, 32, 64, 1 << 30};
+      const int nPass = (int)(sizeof(kBudgets) / sizeof(kBudgets[0]));
+      hipLaunchKernelGGL((bulbC_primary_kernel<true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsC, 0, kBudgets[0]);
+      for (int p = 1; p < nPass; p++)
+        hipLaunchKernelGGL((bulbC_primary_kernel<false>), persistent, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsC, p, kBudgets[p]);
+      if ((st = stamp(1)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulbB_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, wsB);
+      if ((st = stamp(2)) != RM_OK) return st;
+      hipLaunchKernelGGL((bulbC_shadow_kernel<true>), dense, block, 0, stream, slot->dev, wsC, 0, kBudgets[0]);
+      for (int p = 1; p < nPass; p++)
+        hipLaunchKernelGGL((bulbC_shadow_kernel<false>), persistent, block, 0, stream, slot->dev, wsC, p, kBudgets[p]);
+      if ((st = stamp(3)) != RM_OK) return st;
+      hipLaunchKernelGGL(bulbB_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, wsB);
     } else {
       hipLaunchKernelGGL(bulbB_primary_kernel, grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsB);
       if ((st = stamp(1)) != RM_OK) return st;
@@ -491,7 +527,7 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
 }
 int rm_set_kernel_path(int path) {
   std::lock_guard<std::mutex> lock(g_mu);
-  if (path < 0 || path > 3) { set_error("kernel path must be 0..3"); return RM_ERR_INVALID_ARGUMENT; }
+  if (path < 0 || path > 4) { set_error("kernel path must be 0..4"); return RM_ERR_INVALID_ARGUMENT; }
   g_kernelPath = path;
   return RM_OK;
 }

@@ -278,7 +278,7 @@ def test_bulb_schedules_are_bit_identical(renderer):
                  {"features": abi.RM_FEAT_DARK_BACKGROUND, "fractalIters": 1}):
         s = abi.default_settings(**over)
         ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
-        for path in (1, 2, 3, 0):
+        for path in (1, 2, 3, 4, 0):
             try:
                 lib().rm_set_kernel_path(path)
                 a, ab = renderer.render(tables_of(scene), s, W, H, bright=True)
