@@ -89,14 +89,49 @@ def texture_cases():
                texture=tg.synthetic_textures()[1])
 
 
+def post_cases():
+    """Post passes (blur.frag ×10 / hdr.frag / fxaa.frag through fullscreen.vert) on SwiftShader, driven as
+    Realtime::applyBloom / applyLightEffects / applyFXAA do, on an over-bright reflective frame from the oracle."""
+    import run_post
+    W, H = 72, 48
+    scene = tg.reflect_refract_scene(W, H)
+    for li in scene[3]:
+        for k in range(3):
+            li.color[k] *= 2.5
+    frag, bright = h.oracle_render(scene, abi.default_settings(enableReflection=1), W, H, bright=True)
+    assert (bright[..., :3].max(-1) > 0).mean() > 0.02, "the bloom source must not be empty"
+    cases = {
+        "gamma": dict(enableGamma=1),
+        "hdr": dict(enableHDR=1, exposure=1.7),
+        "bloom": dict(enableBloom=1),
+        "bloom_hdr": dict(enableBloom=1, enableHDR=1, exposure=0.6),
+        "fxaa": dict(enableFXAA=1),
+        "all": dict(enableBloom=1, enableHDR=1, enableFXAA=1, exposure=0.8),
+    }
+    for name, kw in cases.items():
+        out = run_post.post_process(frag, bright, **kw)
+        extra = {}
+        if kw.get("enableFXAA"):
+            stage = run_post.post_process(frag, bright, **{**kw, "enableFXAA": 0}) if len(kw) > 1 else frag
+            extra["tie"] = run_post.fxaa_tie_mask(stage)
+            extra["rgba_u8src"] = run_post.post_process(frag, bright, fxaa_source="u8", **kw)
+        ps = np.array([kw.get("enableFXAA", 0), kw.get("enableGamma", 0), kw.get("enableHDR", 0), kw.get("enableBloom", 0)], np.int32)
+        np.savez_compressed(os.path.join(OUT, f"post_{name}.npz"), frag=frag, bright=bright, flags=ps,
+                            exposure=np.float32(kw.get("exposure", 1.0)), rgba=out, **extra)
+        print("post", name, out.shape, {k: float(v.mean()) for k, v in extra.items() if k == "tie"})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "post":
+        return post_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "env":
         return env_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "tex":
         return texture_cases()
     texture_cases()
     env_cases()
+    post_cases()
     W, H = 64, 48
     WB, DB = abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND
     prims = tg.all_primitives_scene(W, H)
