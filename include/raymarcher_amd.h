@@ -48,12 +48,12 @@ enum { RM_LIGHT_POINT = 0, RM_LIGHT_DIRECTIONAL = 1, RM_LIGHT_SPOT = 2, RM_LIGHT
 /* Compile-time #defines of the reference shader (frag:4-15) as a runtime feature mask. */
 enum {
   RM_FEAT_SKY_BACKGROUND = 1u << 0,      /* frag:5  */
-  RM_FEAT_NIGHTSKY_BACKGROUND = 1u << 1, /* frag:6  (needs noise texture: not implemented, rejected) */
+  RM_FEAT_NIGHTSKY_BACKGROUND = 1u << 1, /* frag:6  (samples RmResources.noise) */
   RM_FEAT_DARK_BACKGROUND = 1u << 2,     /* frag:8  */
   RM_FEAT_WHITE_BACKGROUND = 1u << 3,    /* frag:9  */
   RM_FEAT_CLOUD = 1u << 4,               /* frag:12 */
   RM_FEAT_TERRAIN = 1u << 5,             /* frag:13 */
-  RM_FEAT_SEA = 1u << 6,                 /* frag:14 (not implemented, rejected) */
+  RM_FEAT_SEA = 1u << 6,                 /* frag:14 (samples RmResources.noise) */
   RM_FEAT_PERLIN_BUMP = 1u << 7          /* frag:15 */
 };
 /* The checked-in shader's state: WHITE_BACKGROUND + PERLIN_BUMP (frag:9,15). */
@@ -63,7 +63,7 @@ typedef enum rm_status {
   RM_OK = 0,
   RM_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad size, rows out of range */
   RM_ERR_CAPACITY = 2,         /* > RM_MAX_OBJECTS / RM_MAX_LIGHTS (reference silently drops: realtimerender.cpp:662,737) */
-  RM_ERR_UNSUPPORTED = 3,      /* feature outside the hot-path scope (area light, texture, skybox, SEA, NIGHTSKY, CUSTOM) */
+  RM_ERR_UNSUPPORTED = 3,      /* CUSTOM objects; a feature whose resource (texture, noise, skybox, LTC table) was not supplied */
   RM_ERR_DEVICE = 4,           /* HIP runtime error; see rm_last_error() */
   RM_ERR_IO = 5,               /* file missing / unreadable */
   RM_ERR_PARSE = 6             /* scenefile schema violation */
@@ -99,7 +99,7 @@ typedef struct RmLight {
   float func[3];         /* attenuation (c0, c1, c2) */
   float angle;           /* spot outer angle, radians */
   float penumbra;        /* radians */
-  float points[4][3];    /* area light corners (unused: area lights are out of scope) */
+  float points[4][3];    /* area light corners tl,tr,br,bl in world space (realtimerender.cpp:688-693) */
   float intensity;
   int32_t twoSided;
 } RmLight;
@@ -112,6 +112,27 @@ typedef struct RmTexture {
   const uint8_t *pixels;
   int32_t width, height;
 } RmTexture;
+
+/*
+ * Every sampler the shader reads, as the reference leaves them in GPU memory.  All images are RGBA8 with
+ * GL_LINEAR filtering in binary32 weights; `pixels` are DEVICE pointers, rows in glTexImage2D order (row 0 = t 0).
+ * A member with pixels == NULL is "not supplied"; rendering a scene that needs it fails with RM_ERR_UNSUPPORTED.
+ */
+#define RM_LTC_SIZE 64 /* LUT_SIZE, frag:47 */
+typedef struct RmResources {
+  const RmTexture *textures; /* objTextures[] (frag:265), GL_REPEAT */
+  int32_t numTextures;
+  RmTexture noise;           /* `noise` (frag:270; realtimerender.cpp:378-395: noise_texture_1.png, 256×256), GL_REPEAT;
+                              * read by noiseV (frag:591-598) for NIGHTSKY_BACKGROUND and SEA */
+  RmTexture skybox[6];       /* `skybox` cube map faces +X,−X,+Y,−Y,+Z,−Z (frag:267; initCubeMap,
+                              * realtimerender.cpp:557-589), GL_CLAMP_TO_EDGE, filtered within a face
+                              * (GL_TEXTURE_CUBE_MAP_SEAMLESS is never enabled); used when enableSkyBox */
+  const uint8_t *ltc1;       /* LTC1 / LTC2 (frag:268-269): RM_LTC_SIZE² RGBA8 texels each.  The reference uploads   */
+  const uint8_t *ltc2;       /* float tables with the unsized GL_RGBA internal format (realtimerender.cpp:908, 925), */
+                             /* i.e. clamped to [0,1] and stored as 8-bit; rm_ltc_quantise() does that conversion.   */
+} RmResources;
+/* clamp(x,0,1)·255 rounded to nearest: float RGBA table → the 8-bit texels the reference's upload leaves. */
+void rm_ltc_quantise(const float *table, uint8_t *out, int texels);
 
 /* Camera uniforms — configureCameraUniforms, realtimerender.cpp:596-615. */
 typedef struct RmCamera {
@@ -135,7 +156,7 @@ typedef struct RmSettings {
   int32_t enableReflection;
   int32_t enableRefraction;
   int32_t enableAmbientOcclusion;
-  int32_t enableSkyBox;  /* must be 0 (cubemap out of scope) */
+  int32_t enableSkyBox;  /* frag:281, 2327: rays that miss every object sample RmResources.skybox */
   int32_t maxSteps;      /* MAX_STEPS, frag:28 (reference 256) */
   int32_t fractalIters;  /* MAX_STEPS_FRACTALS, frag:29 (reference 20) */
   int32_t mengerLevels;  /* loop bound of frag:1056 (reference 4) */
@@ -150,7 +171,7 @@ void rm_settings_default(RmSettings *s);
 /* ---- library / device ---------------------------------------------------------------------- */
 int rm_abi_version(void);
 /* sizeof() of ABI struct `which` as compiled into the library (0 RmObject, 1 RmLight, 2 RmCamera, 3 RmGlobals,
- * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData, 8 RmTexture, 9 RmPostSettings; -1 otherwise) so bindings can verify layout. */
+ * 4 RmSettings, 5 RmCounters, 6 RmHostSettings, 7 RmCameraData, 8 RmTexture, 9 RmPostSettings, 10 RmResources; -1 otherwise) so bindings can verify layout. */
 int rm_abi_sizeof(int which);
 const char *rm_status_string(int status);
 /* Thread-local text of the last failure in this thread ("" if none). */
@@ -181,6 +202,14 @@ int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const R
 int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                  const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
                  int rowBegin, int rowEnd, float *d_rgba, float *d_bright, void *stream);
+
+/*
+ * rm_render_res — rm_render with every sampler the shader can read (RmResources): object textures, the noise
+ * texture of the night sky / sea, the sky-box cube map and the LTC tables of area lights.  `res` may be NULL.
+ */
+int rm_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                  const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int rowBegin,
+                  int rowEnd, float *d_rgba, float *d_bright, void *stream);
 
 /*
  * rm_render_tiles — the multi-GPU shard of the same frame (no reference counterpart; the reference

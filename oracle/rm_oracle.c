@@ -97,6 +97,8 @@ typedef struct {
   RmSettings s;
   const RmTexture *tex;
   int numTex;
+  const RmResources *res; /* noise / skybox / LTC tables (host pointers); never NULL inside the renderer */
+  int W;                  /* screenDimensions.x (frag:246, realtimerender.cpp:622-629) */
   uint64_t nEval, nIter, nHit; /* per-thread work counters */
 } Ctx;
 
@@ -515,21 +517,70 @@ static inline int wrapi(float f, int n) {
   int i = (int)f % n;
   return i < 0 ? i + n : i;
 }
-static v3 sampleTexture(const RmTexture *t, v2 uv) {
-  float u = rm_fma(uv.x, (float)t->width, -0.5f), v = rm_fma(uv.y, (float)t->height, -0.5f);
+typedef struct { float c[3][3]; } m3;   /* c[col][row] */
+static inline v3 m3_mul_v3(const m3 *M, v3 v) {
+  return V3(rm_fma(M->c[2][0], v.z, rm_fma(M->c[1][0], v.y, M->c[0][0] * v.x)),
+            rm_fma(M->c[2][1], v.z, rm_fma(M->c[1][1], v.y, M->c[0][1] * v.x)),
+            rm_fma(M->c[2][2], v.z, rm_fma(M->c[1][2], v.y, M->c[0][2] * v.x)));
+}
+static inline m3 m3_mul_m3(const m3 *A, const m3 *B) {
+  m3 R;
+  for (int c = 0; c < 3; c++) {
+    v3 col = m3_mul_v3(A, V3(B->c[c][0], B->c[c][1], B->c[c][2]));
+    R.c[c][0] = col.x; R.c[c][1] = col.y; R.c[c][2] = col.z;
+  }
+  return R;
+}
+static inline m3 m3_scale(const m3 *A, float f) {
+  m3 R;
+  for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) R.c[c][r] = f * A->c[c][r];
+  return R;
+}
+static inline v3 cross3(v3 a, v3 b) {
+  return V3(rm_fma(a.y, b.z, -(a.z * b.y)), rm_fma(a.z, b.x, -(a.x * b.z)), rm_fma(a.x, b.y, -(a.y * b.x)));
+}
+/* One RGBA8 GL_LINEAR fetch.  clampEdge = 0: GL_REPEAT, 1: GL_CLAMP_TO_EDGE. */
+static v4 sampleRGBA8(const RmTexture *t, float su, float sv, int clampEdge) {
+  const int W = t->width, H = t->height;
+  float u = rm_fma(su, (float)W, -0.5f), v = rm_fma(sv, (float)H, -0.5f);
   float fu = rm_floor(u), fv = rm_floor(v);
   float a = u - fu, b = v - fv;
-  int i0 = wrapi(fu, t->width), j0 = wrapi(fv, t->height);
-  int i1 = (i0 + 1 == t->width) ? 0 : i0 + 1, j1 = (j0 + 1 == t->height) ? 0 : j0 + 1;
-  const uint8_t *p00 = t->pixels + ((size_t)j0 * t->width + i0) * 4, *p10 = t->pixels + ((size_t)j0 * t->width + i1) * 4;
-  const uint8_t *p01 = t->pixels + ((size_t)j1 * t->width + i0) * 4, *p11 = t->pixels + ((size_t)j1 * t->width + i1) * 4;
-  float c[3];
-  for (int k = 0; k < 3; k++) {
+  int i0, i1, j0, j1;
+  if (clampEdge) {
+    if (!(rm_abs(fu) < 1.0e9f)) fu = 0.0f;
+    if (!(rm_abs(fv) < 1.0e9f)) fv = 0.0f;
+    int iu = (int)fu, iv = (int)fv;
+    i0 = iu < 0 ? 0 : (iu > W - 1 ? W - 1 : iu); i1 = iu + 1 < 0 ? 0 : (iu + 1 > W - 1 ? W - 1 : iu + 1);
+    j0 = iv < 0 ? 0 : (iv > H - 1 ? H - 1 : iv); j1 = iv + 1 < 0 ? 0 : (iv + 1 > H - 1 ? H - 1 : iv + 1);
+  } else {
+    i0 = wrapi(fu, W); j0 = wrapi(fv, H);
+    i1 = (i0 + 1 == W) ? 0 : i0 + 1; j1 = (j0 + 1 == H) ? 0 : j0 + 1;
+  }
+  const uint8_t *p00 = t->pixels + ((size_t)j0 * W + i0) * 4, *p10 = t->pixels + ((size_t)j0 * W + i1) * 4;
+  const uint8_t *p01 = t->pixels + ((size_t)j1 * W + i0) * 4, *p11 = t->pixels + ((size_t)j1 * W + i1) * 4;
+  float c[4];
+  for (int k = 0; k < 4; k++) {
     float lo = rm_mix((float)p00[k] / 255.0f, (float)p10[k] / 255.0f, a);
     float hi = rm_mix((float)p01[k] / 255.0f, (float)p11[k] / 255.0f, a);
     c[k] = rm_mix(lo, hi, b);
   }
-  return V3(c[0], c[1], c[2]);
+  return V4(c[0], c[1], c[2], c[3]);
+}
+static v3 sampleTexture(const RmTexture *t, v2 uv) {
+  v4 c = sampleRGBA8(t, uv.x, uv.y, 0);
+  return V3(c.x, c.y, c.z);
+}
+/* texture(samplerCube, r): major-axis face selection and (s,t) of GL 3.3 §3.8.10 table 3.19; equal magnitudes
+ * resolve x before y before z (the spec leaves ties to the implementation).  Filtering stays inside the face
+ * (GL_CLAMP_TO_EDGE, seamless filtering is off by default in a GL 4.1 core context and never enabled). */
+static v3 sampleCube(const RmTexture *faces, v3 r) {
+  float ax = rm_abs(r.x), ay = rm_abs(r.y), az = rm_abs(r.z), sc, tc, ma;
+  int face;
+  if (ax >= ay && ax >= az) { ma = ax; if (r.x >= 0.0f) { face = 0; sc = -r.z; tc = -r.y; } else { face = 1; sc = r.z; tc = -r.y; } }
+  else if (ay >= az)        { ma = ay; if (r.y >= 0.0f) { face = 2; sc = r.x; tc = r.z; } else { face = 3; sc = r.x; tc = -r.z; } }
+  else                      { ma = az; if (r.z >= 0.0f) { face = 4; sc = r.x; tc = -r.y; } else { face = 5; sc = -r.x; tc = -r.y; } }
+  v4 c = sampleRGBA8(&faces[face], rm_fma(sc / ma, 0.5f, 0.5f), rm_fma(tc / ma, 0.5f, 0.5f), 1);
+  return V3(c.x, c.y, c.z);
 }
 /* frag:1746-1781 */
 static v3 getDiffuse(const Ctx *c, const RmObject *obj, v3 p) {
@@ -547,6 +598,69 @@ static v3 getDiffuse(const Ctx *c, const RmObject *obj, v3 p) {
             rm_fma(obj->blend, t.z, k * obj->cDiffuse[2]));
 }
 
+/* ---- area lights: linearly transformed cosines (frag:349-424, 1794-1822) ----
+ * LTC1/LTC2 are RM_LTC_SIZE² RGBA8 tables with GL_CLAMP_TO_EDGE.  The reference sets MIN = NEAREST, MAG = LINEAR
+ * (realtimerender.cpp:910-913); which one applies depends on screen-space derivatives taken inside divergent
+ * control flow (undefined in GLSL) — the smooth uv of a 64² table magnifies, so GL_LINEAR is used throughout. */
+#define LUT_SCALE ((64.0f - 1.0f) / 64.0f) /* frag:48 */
+#define LUT_BIAS (0.5f / 64.0f)            /* frag:49 */
+static v4 sampleLTC(const uint8_t *table, float u, float v) {
+  RmTexture t; t.pixels = table; t.width = RM_LTC_SIZE; t.height = RM_LTC_SIZE;
+  return sampleRGBA8(&t, u, v, 1);
+}
+static v3 IntegrateEdgeVec(v3 v1, v3 v2) { /* frag:349-361 */
+  float x = dot3(v1, v2), y = rm_abs(x);
+  float a = rm_fma(rm_fma(0.0145206f, y, 0.4965155f), y, 0.8543985f);
+  float b = rm_fma(4.1616724f + y, y, 3.4175940f);
+  float v = a / b;
+  float ts = (x > 0.0f) ? v : rm_fma(0.5f, 1.0f / rm_sqrt(rm_max(rm_fma(-x, x, 1.0f), 1e-7f)), -v);
+  return v3_scale(cross3(v1, v2), ts);
+}
+static float LTC_Evaluate(const Ctx *c, v3 N, v3 V, v3 P, const m3 *MinvIn, const RmLight *li) { /* frag:368-424 */
+  v3 T1 = normalize3(v3_madd(N, -dot3(V, N), V));
+  v3 T2 = cross3(N, T1);
+  m3 B = {{{T1.x, T2.x, N.x}, {T1.y, T2.y, N.y}, {T1.z, T2.z, N.z}}}; /* transpose(mat3(T1,T2,N)) */
+  m3 Minv = m3_mul_m3(MinvIn, &B);
+  v3 pts[4], L[4];
+  for (int k = 0; k < 4; k++) {
+    pts[k] = V3(li->points[k][0], li->points[k][1], li->points[k][2]);
+    L[k] = m3_mul_v3(&Minv, v3_sub(pts[k], P));
+  }
+  v3 dir = v3_sub(pts[0], P);
+  v3 lightNormal = cross3(v3_sub(pts[1], pts[0]), v3_sub(pts[3], pts[0]));
+  int behind = dot3(dir, lightNormal) < 0.0f;
+  for (int k = 0; k < 4; k++) L[k] = normalize3(L[k]);
+  v3 vsum = IntegrateEdgeVec(L[0], L[1]);
+  vsum = v3_add(vsum, IntegrateEdgeVec(L[1], L[2]));
+  vsum = v3_add(vsum, IntegrateEdgeVec(L[2], L[3]));
+  vsum = v3_add(vsum, IntegrateEdgeVec(L[3], L[0]));
+  float len = len3(vsum);
+  float z = vsum.z / len;
+  if (behind) z = -z;
+  float scale = sampleLTC(c->res->ltc2, rm_fma(rm_fma(z, 0.5f, 0.5f), LUT_SCALE, LUT_BIAS), rm_fma(len, LUT_SCALE, LUT_BIAS)).w;
+  float sum = len * scale;
+  if (!behind && !li->twoSided) sum = 0.0f;
+  return sum;
+}
+static v3 getAreaLight(const Ctx *c, v3 N, v3 V, v3 P, const RmLight *li, const RmObject *obj) { /* frag:1795-1822 */
+  float dotNV = rm_clamp(dot3(N, V), 0.0f, 1.0f);
+  float u = rm_fma(0.0f, LUT_SCALE, LUT_BIAS), v = rm_fma(rm_sqrt(1.0f - dotNV), LUT_SCALE, LUT_BIAS);
+  v4 t1 = sampleLTC(c->res->ltc1, u, v), t2 = sampleLTC(c->res->ltc2, u, v);
+  const m3 Minv = {{{t1.x, 0.0f, t1.y}, {0.0f, 1.0f, 0.0f}, {t1.z, 0.0f, t1.w}}};
+  const m3 I = {{{1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, 0.0f, 1.0f}}};
+  float diffuse = LTC_Evaluate(c, N, V, P, &I, li);
+  float specular = LTC_Evaluate(c, N, V, P, &Minv, li);
+  v3 dif = getDiffuse(c, obj, P);
+  float col[3];
+  const float difk[3] = {dif.x, dif.y, dif.z};
+  for (int k = 0; k < 3; k++) {
+    float cS = obj->cSpecular[k];
+    float sp = specular * rm_fma(li->intensity - cS, t2.y, cS * t2.x);
+    col[k] = (li->color[k] * 1.0f) * rm_fma(difk[k], diffuse, sp);
+  }
+  return V3(col[0], col[1], col[2]);
+}
+
 /* frag:1842-1933 (texLoc == -1 path of getDiffuse, frag:1749-1752; getSpecular frag:1787-1792) */
 static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
   const RmObject *obj = &c->objs[intersectObj];
@@ -559,7 +673,7 @@ static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
     float fAtt = 1.0f, aFall = 1.0f;
     v3 lpos = V3(li->pos[0], li->pos[1], li->pos[2]);
     float d = len3(v3_sub(p, lpos));
-    v3 L; float maxT;
+    v3 L = V3(0.0f, 0.0f, 0.0f); float maxT = 0.0f;
     if (li->type == RM_LIGHT_POINT) {
       L = normalize3(v3_sub(lpos, p));
       fAtt = attenuationFactor(d, li->func);
@@ -567,13 +681,28 @@ static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
     } else if (li->type == RM_LIGHT_DIRECTIONAL) {
       L = normalize3(V3(-li->dir[0], -li->dir[1], -li->dir[2]));
       maxT = far;
-    } else { /* SPOT */
+    } else if (li->type == RM_LIGHT_SPOT) {
       L = normalize3(v3_sub(lpos, p));
       fAtt = attenuationFactor(d, li->func);
       maxT = len3(v3_sub(lpos, p));
       aFall = angularFalloff(li, L);
     }
     v3 V = normalize3(v3_neg(rd));
+    if (li->type == RM_LIGHT_AREA) { /* frag:1884-1905, AREA_LIGHT_SAMPLES = 1: the "random" uv is rd.xy */
+      v3 p1 = V3(li->points[0][0], li->points[0][1], li->points[0][2]);
+      v3 side1 = v3_sub(V3(li->points[1][0], li->points[1][1], li->points[1][2]), p1);
+      v3 side2 = v3_sub(V3(li->points[3][0], li->points[3][1], li->points[3][2]), p1);
+      v3 randomP = v3_madd(side2, rd.y + 0.0f, v3_madd(side1, rd.x + 0.0f, p1));
+      L = normalize3(v3_sub(randomP, p));
+      if (dot3(N, L) <= 0.005f) continue;
+      maxT = len3(v3_sub(randomP, p));
+      v3 so = V3(rm_fma(N.x * SURFACE_DIST, 5.0f, p.x), rm_fma(N.y * SURFACE_DIST, 5.0f, p.y),
+                 rm_fma(N.z * SURFACE_DIST, 5.0f, p.z));
+      RayMarchRes sh = softshadow(c, so, L, 0.0f, maxT, 8.0f);
+      if (sh.intersectObj != -1 && c->objs[sh.intersectObj].lightIdx != i) continue;
+      total = v3_add(total, getAreaLight(c, N, V, p, li, obj));
+      continue;
+    }
     /* frag:1908: origin p + N*SURFACE_DIST*5 */
     v3 so = V3(rm_fma(N.x * SURFACE_DIST, 5.0f, p.x), rm_fma(N.y * SURFACE_DIST, 5.0f, p.y),
                rm_fma(N.z * SURFACE_DIST, 5.0f, p.z));
@@ -601,25 +730,6 @@ static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
 /* ---------------------------------------------------------------- procedural layers (frag:464-746, 1519-1584, 1950-2158)
  * Compile-time #defines TERRAIN / CLOUD / SKY_BACKGROUND of the shader (frag:4-15) are runtime feature bits.
  * GLSL evaluates `f*m2*x` left to right: (f*m2)*x — the scaled constant matrices are formed first. */
-typedef struct { float c[3][3]; } m3;   /* c[col][row] */
-static inline v3 m3_mul_v3(const m3 *M, v3 v) {
-  return V3(rm_fma(M->c[2][0], v.z, rm_fma(M->c[1][0], v.y, M->c[0][0] * v.x)),
-            rm_fma(M->c[2][1], v.z, rm_fma(M->c[1][1], v.y, M->c[0][1] * v.x)),
-            rm_fma(M->c[2][2], v.z, rm_fma(M->c[1][2], v.y, M->c[0][2] * v.x)));
-}
-static inline m3 m3_mul_m3(const m3 *A, const m3 *B) {
-  m3 R;
-  for (int c = 0; c < 3; c++) {
-    v3 col = m3_mul_v3(A, V3(B->c[c][0], B->c[c][1], B->c[c][2]));
-    R.c[c][0] = col.x; R.c[c][1] = col.y; R.c[c][2] = col.z;
-  }
-  return R;
-}
-static inline m3 m3_scale(const m3 *A, float f) {
-  m3 R;
-  for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) R.c[c][r] = f * A->c[c][r];
-  return R;
-}
 static const m3 kM3 = {{{0.00f, 0.80f, 0.60f}, {-0.80f, 0.36f, -0.48f}, {-0.60f, -0.48f, 0.64f}}};   /* frag:118-120 */
 static const m3 kM3i = {{{0.00f, -0.80f, -0.60f}, {0.80f, 0.36f, -0.48f}, {0.60f, -0.48f, 0.64f}}};  /* frag:121-123 */
 
@@ -887,11 +997,133 @@ static int terrainRender(const Ctx *c, v3 ro, v3 rd, float maxT, v3 bgCol, v3 *c
   *colOut = v3_mul(col, lin);
   return 1;
 }
-/* The env layers applied after a render() (frag:2444-2456, 2506-2518, 2555-2567): terrain then cloud. */
-static void envLayers(const Ctx *c, v3 ro, v3 rd, float d, v3 bgCol, int *terrainHit, int *cloudHit, v3 *tcol, v3 *ccol) {
-  float td = d;
-  *terrainHit = 0; *cloudHit = 0;
-  if (c->s.features & RM_FEAT_TERRAIN) *terrainHit = terrainRender(c, ro, rd, d, bgCol, tcol, &td);
+/* ---- night sky and sea (frag:476-516, 591-598, 1562-1573, 2160-2310); both read the `noise` texture ---- */
+static float hashSin2(float px, float py) { /* frag:481-483 */
+  return rm_fract(rm_sin(dot2(px, py, 12.9898f, 78.233f)) * 43758.5453f);
+}
+static float noiseW(float px, float py) { /* frag:504-518 */
+  float ix = rm_floor(px), iy = rm_floor(py), fx = rm_fract(px), fy = rm_fract(py);
+  float ux = (fx * fx) * rm_fma(-2.0f, fx, 3.0f), uy = (fy * fy) * rm_fma(-2.0f, fy, 3.0f);
+  float a = hashSin2(ix + 0.0f, iy + 0.0f), b = hashSin2(ix + 1.0f, iy + 0.0f);
+  float cc = hashSin2(ix + 0.0f, iy + 1.0f), d = hashSin2(ix + 1.0f, iy + 1.0f);
+  float result = rm_mix(rm_mix(a, b, ux), rm_mix(cc, d, ux), uy);
+  return rm_fma(2.0f, result, -1.0f);
+}
+static float noiseV(const Ctx *c, v3 x) { /* frag:591-598; textureLod(noise, ·, 0).yx */
+  v3 p = V3(rm_floor(x.x), rm_floor(x.y), rm_floor(x.z));
+  v3 f = V3(rm_fract(x.x), rm_fract(x.y), rm_fract(x.z));
+  f = V3((f.x * f.x) * rm_fma(-2.0f, f.x, 3.0f), (f.y * f.y) * rm_fma(-2.0f, f.y, 3.0f), (f.z * f.z) * rm_fma(-2.0f, f.z, 3.0f));
+  float u = rm_fma(37.0f, p.z, p.x) + f.x, v = rm_fma(239.0f, p.z, p.y) + f.y;
+  v4 t = sampleRGBA8(&c->res->noise, (u + 0.5f) / 256.0f, (v + 0.5f) / 256.0f, 0);
+  return rm_fma(rm_mix(t.y, t.x, f.z), 2.0f, -1.0f);
+}
+static v3 getMoonColor(const Ctx *c, v3 rd) { /* frag:1562-1573, MOON = normalize(-0.4, 0.4, 0.3) (frag:107) */
+  const v3 MOON = normalize3(V3(-0.4f, 0.4f, 0.3f));
+  float ms = noiseV(c, v3_scale(rd, 20.0f));
+  float q = (0.1f * ms) * ms; /* 0.1*ms*ms*ms associates left to right */
+  v3 mCol = V3(rm_fma(-q, ms, 0.5f), rm_fma(-q, ms, 0.5f), rm_fma(-q, ms, 0.3f));
+  float moonDot = dot3(MOON, rd);
+  float moonA = rm_smoothstep(0.9985f, 0.999f, moonDot);
+  v3 col = v3_scale(mCol, moonA);
+  float halo = rm_smoothstep(0.91f, 0.9985f, moonDot);
+  col = V3(rm_fma(0.15f, halo, col.x), rm_fma(0.15f, halo, col.y), rm_fma(0.15f, halo, col.z));
+  float sh = 6.0f * rm_sin(c->g.iTime / 2.0f);
+  float star = rm_smoothstep(0.99f, 0.999f, noiseV(c, V3(rm_floor(rm_fma(rd.x, 202.0f, -sh)), rm_floor(rm_fma(rd.y, 202.0f, -sh)),
+                                                        rm_floor(rm_fma(rd.z, 202.0f, -sh)))));
+  float sc = rm_clamp(star, 0.0f, 1.0f);
+  return V3(rm_fma(sc, 0.4f, col.x), rm_fma(sc, 0.4f, col.y), rm_fma(sc, 0.4f, col.z));
+}
+#define SEA_HEIGHT 0.2f /* frag:96-99 */
+#define SEA_CHOPPY 1.0f
+#define SEA_SPEED 0.5f
+#define SEA_FREQ 0.16f
+static float sea_octave(float ux, float uy, float choppy) { /* frag:2162-2169 */
+  float n = noiseW(ux, uy);
+  ux += n; uy += n;
+  float wx = 1.0f - rm_abs(rm_sin(ux)), wy = 1.0f - rm_abs(rm_sin(uy));
+  float sx = rm_abs(rm_cos(ux)), sy = rm_abs(rm_cos(uy));
+  wx = rm_mix(wx, sx, wx); wy = rm_mix(wy, sy, wy);
+  return rm_pow(1.0f - rm_pow(wx * wy, 0.65f), choppy);
+}
+/* seaMap (ITER_GEOMETRY = 3) / seaMapD (ITER_FRAGMENT = 5), frag:2195-2241.  SEA_TIME = 1 + iTime·SEA_SPEED is a
+ * global initialised from a uniform (frag:2192; not valid GLSL 3.30 — the evident meaning is taken). */
+static float seaMap(const Ctx *c, v3 p, int iters) {
+  const float seaTime = rm_fma(c->g.iTime, SEA_SPEED, 1.0f);
+  float freq = SEA_FREQ, amp = SEA_HEIGHT, choppy = SEA_CHOPPY, ux = p.x, uy = p.z, h = 0.0f;
+  for (int i = 0; i < iters; i++) {
+    float d = sea_octave((ux + seaTime) * freq, (uy + seaTime) * freq, choppy);
+    d += sea_octave((ux - seaTime) * freq, (uy - seaTime) * freq, choppy);
+    h = rm_fma(d, amp, h);
+    float nx = dot2(ux, uy, 1.6f, 1.2f), ny = dot2(ux, uy, -1.2f, 1.6f); /* uv *= octave_m (row vector × mat2, frag:103) */
+    ux = nx; uy = ny;
+    freq *= 2.0f; amp *= 0.2f;
+    choppy = rm_mix(choppy, 1.0f, 0.2f);
+  }
+  return p.y - h;
+}
+static v3 getSeaNormal(const Ctx *c, v3 p, float eps) { /* frag:2243-2250 */
+  float ny = seaMap(c, p, 5);
+  float nx = seaMap(c, V3(p.x + eps, p.y, p.z), 5) - ny;
+  float nz = seaMap(c, V3(p.x, p.y, p.z + eps), 5) - ny;
+  return normalize3(V3(nx, eps, nz));
+}
+static float seaMapHeight(const Ctx *c, v3 ro, v3 rd, v3 *p, float maxT) { /* frag:2252-2282 */
+  float tm = 0.0f, tx = 1000.0f;
+  float hx = seaMap(c, v3_madd(rd, tx, ro), 3);
+  if (hx > 0.0f) { *p = V3(0.0f, 0.0f, 0.0f); return tx; }
+  float hm = seaMap(c, v3_madd(rd, tm, ro), 3);
+  float tmid = 0.0f;
+  for (int i = 0; i < 8; i++) {
+    float f = hm / (hm - hx);
+    tmid = rm_mix(tm, tx, f);
+    *p = v3_madd(rd, tmid, ro);
+    if (tmid > maxT) return -1.0f;
+    float hmid = seaMap(c, *p, 3);
+    if (hmid < 0.0f) { tx = tmid; hx = hmid; } else { tm = tmid; hm = hmid; }
+  }
+  return tmid;
+}
+static v3 getSeaColor(const Ctx *c, v3 p, v3 n, v3 l, v3 eye, v3 dist) { /* frag:2171-2190 */
+  const v3 SEA_BASE = V3(0.4f, 0.49f, 0.48f), SEA_WATER = V3(0.8f, 0.9f, 0.6f); /* frag:101-102 */
+  float fresnel = rm_clamp(1.0f - dot3(n, v3_neg(eye)), 0.0f, 1.0f);
+  fresnel = rm_pow(fresnel, 3.0f) * 0.65f;
+  v3 refl = reflect3(eye, n);
+  v3 reflected = getMoonColor(c, refl);
+  float pw = rm_pow(rm_fma(dot3(n, l), 0.4f, 0.6f), 80.0f);
+  v3 refracted = V3(rm_fma(pw * SEA_WATER.x, 0.12f, SEA_BASE.x), rm_fma(pw * SEA_WATER.y, 0.12f, SEA_BASE.y),
+                    rm_fma(pw * SEA_WATER.z, 0.12f, SEA_BASE.z));
+  v3 color = mix3(refracted, reflected, fresnel);
+  float atten = rm_max(rm_fma(-dot3(dist, dist), 0.001f, 1.0f), 0.0f);
+  float dh = p.y - SEA_HEIGHT;
+  color = V3(rm_fma((SEA_WATER.x * dh) * 0.18f, atten, color.x), rm_fma((SEA_WATER.y * dh) * 0.18f, atten, color.y),
+             rm_fma((SEA_WATER.z * dh) * 0.18f, atten, color.z));
+  const float nrm = (60.0f + 8.0f) / (3.14159265f * 8.0f);
+  float spec = rm_pow(rm_max(dot3(refl, l), 0.0f), 60.0f) * nrm;
+  return V3(color.x + spec, color.y + spec, color.z + spec);
+}
+/* frag:2284-2310.  The miss path is a bare `return;` in a non-void function (frag:2290, UB7): taken as returning
+ * `ri` as filled so far (colour = bgCol, d = maxT, no hit). */
+static int seaRender(const Ctx *c, v3 ro, v3 rd, float maxT, v3 bgCol, v3 *colOut, float *dOut) {
+  *colOut = bgCol; *dOut = maxT;
+  v3 p;
+  float t = seaMapHeight(c, ro, rd, &p, maxT);
+  if (len3(p) == 0.0f || t == -1.0f) return 0;
+  *dOut = t;
+  v3 d = v3_sub(p, ro);
+  v3 n = getSeaNormal(c, p, (dot3(d, d) * 0.1f) / (float)c->W);
+  v3 s = getSky(rd);
+  v3 sc = getSeaColor(c, p, n, getSunDir(), rd, d);
+  float t2 = rm_pow(rm_smoothstep(0.0f, -0.05f, rd.y), 0.3f);
+  *colOut = fog(mix3(s, sc, t2), t);
+  return 1;
+}
+/* The env layers applied after a render() (frag:2444-2456, 2506-2518, 2555-2567): sea, terrain, then cloud. */
+static void envLayers(const Ctx *c, v3 ro, v3 rd, float d, v3 bgCol, int *terrainHit, int *cloudHit, int *seaHit, v3 *tcol,
+                      v3 *ccol, v3 *scol) {
+  float sd = d, td = d; /* sr.d = tr.d = ri.d (frag:2444); the cloud layer is bounded by tr.d, not sr.d */
+  *terrainHit = 0; *cloudHit = 0; *seaHit = 0;
+  if (c->s.features & RM_FEAT_SEA) *seaHit = seaRender(c, ro, rd, d, bgCol, scol, &sd);
+  if (c->s.features & RM_FEAT_TERRAIN) *terrainHit = terrainRender(c, ro, rd, sd, bgCol, tcol, &td);
   if (c->s.features & RM_FEAT_CLOUD) *ccol = cloudRender(c, ro, rd, bgCol, cloudHit, td);
 }
 
@@ -902,6 +1134,10 @@ static RenderInfo render(Ctx *c, v3 ro, v3 rd, IntersectionInfo *info, float sid
   RayMarchRes res = raymarch(c, ro, rd, maxT, side);
   if (res.intersectObj == -1) {
     ri.fragColor = V4(bgCol.x, bgCol.y, bgCol.z, 1.0f);
+    if (c->s.enableSkyBox) { /* frag:2327 */
+      v3 sk = sampleCube(c->res->skybox, rd);
+      ri.fragColor = V4(sk.x, sk.y, sk.z, 1.0f);
+    }
     ri.isEnv = 1; ri.d = maxT;
     return ri;
   }
@@ -911,6 +1147,10 @@ static RenderInfo render(Ctx *c, v3 ro, v3 rd, IntersectionInfo *info, float sid
   if (c->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p, 10.0f, 2.0f);
   const RmObject *obj = &c->objs[res.intersectObj];
   v3 col;
+  if (obj->isEmissive) { /* frag:2339-2342: the rectangle of an area light; `info` keeps intersectObj = -1 */
+    ri.fragColor = V4(obj->color[0], obj->color[1], obj->color[2], 1.0f);
+    return ri;
+  }
   if (obj->type == RM_MANDELBULB) { /* frag:2354-2361 */
     col = V3(0.2f, 0.2f, 0.2f);
     col = mix3(col, V3(0.10f, 0.20f, 0.30f), rm_clamp(res.trap.y, 0.0f, 1.0f));
@@ -961,17 +1201,18 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
     /* frag:2405-2419 (later #ifdefs override earlier ones) */
     v3 bgCol = V3(0.0f, 0.0f, 0.0f);
     if (c->s.features & RM_FEAT_SKY_BACKGROUND) bgCol = getSky(rd);
+    if (c->s.features & RM_FEAT_NIGHTSKY_BACKGROUND) bgCol = getMoonColor(c, rd);
     if (c->s.features & RM_FEAT_WHITE_BACKGROUND) bgCol = V3(1.0f, 1.0f, 1.0f);
     if (c->s.features & RM_FEAT_DARK_BACKGROUND) bgCol = V3(0.0f, 0.0f, 0.0f);
-    const int env = (c->s.features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD)) != 0;
+    const int env = (c->s.features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SEA)) != 0;
     float far = (c->s.features & RM_FEAT_CLOUD) ? 2000.0f : c->cam->initialFar; /* frag:2422-2426 */
 
     IntersectionInfo info, oi;
     RenderInfo ri = render(c, ro, rd, &info, OUTSIDE, far, bgCol); /* frag:2443 */
-    int terrainHit = 0, cloudHit = 0;
-    v3 tcol = bgCol, ccol = bgCol;
-    if (env) envLayers(c, ro, rd, ri.d, bgCol, &terrainHit, &cloudHit, &tcol, &ccol); /* frag:2444-2456 */
-    if (ri.isEnv && !cloudHit && !terrainHit) { /* frag:2459-2465 */
+    int terrainHit = 0, cloudHit = 0, seaHit = 0;
+    v3 tcol = bgCol, ccol = bgCol, scol = bgCol;
+    if (env) envLayers(c, ro, rd, ri.d, bgCol, &terrainHit, &cloudHit, &seaHit, &tcol, &ccol, &scol); /* frag:2444-2456 */
+    if (ri.isEnv && !cloudHit && !terrainHit && !seaHit) { /* frag:2459-2465 */
       fragColor = ri.fragColor;
       goto done;
     } else if (cloudHit) { /* frag:2466-2468 */
@@ -982,12 +1223,19 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
       fragColor = V4(tcol.x, tcol.y, tcol.z, 1.0f);
       bright = brightOf(tcol);
       goto done;
+    } else if (seaHit) { /* frag:2472-2474 */
+      fragColor = V4(scol.x, scol.y, scol.z, 1.0f);
+      bright = brightOf(scol);
+      goto done;
     }
     c->nHit++;
     v4 phong = ri.fragColor;
     v4 refl = V4(0, 0, 0, 0), refr = V4(0, 0, 0, 0);
     oi = info; /* frag:2481 */
-    const RmObject *obj = &c->objs[info.intersectObj];
+    /* UB5: an emissive hit leaves info.intersectObj = -1 and the shader reads objects[-1] (frag:2341, 2483); an
+     * out-of-range uniform read is taken as zeros (robust-access behaviour): no secondary rays. */
+    static const RmObject kZeroObject;
+    const RmObject *obj = info.intersectObj >= 0 ? &c->objs[info.intersectObj] : &kZeroObject;
     v3 cRefl = V3(obj->cReflective[0], obj->cReflective[1], obj->cReflective[2]);
     v3 cRefr = V3(obj->cTransparent[0], obj->cTransparent[1], obj->cTransparent[2]);
     if (c->s.enableReflection && len3(cRefl) != 0.0f) { /* frag:2491-2524 */
@@ -999,8 +1247,9 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
         fil = v3_mul(fil, cRefl);
         RenderInfo res = render(c, sro, r, &info, OUTSIDE, far, bgCol);
         if (env) { /* frag:2506-2518: terrain, then cloud, override the bounce colour and end the loop */
-          int th, ch; v3 tc, cc;
-          envLayers(c, sro, r, res.d, bgCol, &th, &ch, &tc, &cc);
+          int th, ch, sh; v3 tc, cc, sc;
+          envLayers(c, sro, r, res.d, bgCol, &th, &ch, &sh, &tc, &cc, &sc);
+          if (sh) res.fragColor = V4(sc.x, sc.y, sc.z, 1.0f); /* frag:2509 sets sr.isEnv, not res.isEnv: the loop goes on */
           if (th) { res.fragColor = V4(tc.x, tc.y, tc.z, 1.0f); res.isEnv = 1; }
           if (ch) { res.fragColor = V4(cc.x, cc.y, cc.z, 1.0f); res.isEnv = 1; }
         }
@@ -1029,8 +1278,9 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
                     rm_fma(-(nExit.z * SURFACE_DIST), 5.0f, pExit.z));
         RenderInfo res = render(c, sro, rdOut, &info, OUTSIDE, far, bgCol);
         if (env) { /* frag:2555-2567 */
-          int th, ch; v3 tc, cc;
-          envLayers(c, sro, rdOut, res.d, bgCol, &th, &ch, &tc, &cc);
+          int th, ch, sh; v3 tc, cc, sc;
+          envLayers(c, sro, rdOut, res.d, bgCol, &th, &ch, &sh, &tc, &cc, &sc);
+          if (sh) res.fragColor = V4(sc.x, sc.y, sc.z, 1.0f);
           if (th) res.fragColor = V4(tc.x, tc.y, tc.z, 1.0f);
           if (ch) res.fragColor = V4(cc.x, cc.y, cc.z, 1.0f);
         }
@@ -1225,41 +1475,57 @@ int rmo_post_process(const float *frag, const float *bright, float *out, int W, 
 }
 
 /* ---------------------------------------------------------------- public oracle API */
+static int texOk(const RmTexture *t) { return t->pixels && t->width > 0 && t->height > 0; }
 static int validate(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
-                    int numLights, const RmGlobals *g, const RmSettings *s, const RmTexture *tex, int numTex) {
+                    int numLights, const RmGlobals *g, const RmSettings *s, const RmResources *res) {
   if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights)) return RM_ERR_INVALID_ARGUMENT;
   if (numObjects < 0 || numLights < 0) return RM_ERR_INVALID_ARGUMENT;
   if (numObjects > RM_MAX_OBJECTS || numLights > RM_MAX_LIGHTS) return RM_ERR_CAPACITY;
-  if (s->features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) return RM_ERR_UNSUPPORTED;
-  if (s->enableSkyBox) return RM_ERR_UNSUPPORTED;
+  if (res->numTextures < 0 || res->numTextures > RM_MAX_TEXTURES) return RM_ERR_CAPACITY;
+  if ((s->features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) && !texOk(&res->noise)) return RM_ERR_UNSUPPORTED;
+  if (s->enableSkyBox)
+    for (int f = 0; f < 6; f++)
+      if (!texOk(&res->skybox[f])) return RM_ERR_UNSUPPORTED;
   for (int i = 0; i < numObjects; i++) {
     if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM) return RM_ERR_UNSUPPORTED;
-    if (objs[i].isEmissive) return RM_ERR_UNSUPPORTED;
     if (objs[i].texLoc != -1) {
-      if (objs[i].texLoc < 0 || objs[i].texLoc >= numTex || !tex) return RM_ERR_UNSUPPORTED;
+      if (objs[i].texLoc < 0 || objs[i].texLoc >= res->numTextures || !res->textures) return RM_ERR_UNSUPPORTED;
       if (objs[i].type != RM_CUBE && objs[i].type != RM_CONE && objs[i].type != RM_CYLINDER && objs[i].type != RM_SPHERE)
         return RM_ERR_UNSUPPORTED;
-      if (!tex[objs[i].texLoc].pixels || tex[objs[i].texLoc].width <= 0 || tex[objs[i].texLoc].height <= 0)
-        return RM_ERR_INVALID_ARGUMENT;
+      if (!texOk(&res->textures[objs[i].texLoc])) return RM_ERR_INVALID_ARGUMENT;
     }
   }
-  for (int i = 0; i < numLights; i++)
-    if (lights[i].type < 0 || lights[i].type > RM_LIGHT_SPOT) return RM_ERR_UNSUPPORTED;
+  for (int i = 0; i < numLights; i++) {
+    if (lights[i].type < 0 || lights[i].type > RM_LIGHT_AREA) return RM_ERR_UNSUPPORTED;
+    if (lights[i].type == RM_LIGHT_AREA && (!res->ltc1 || !res->ltc2)) return RM_ERR_UNSUPPORTED;
+  }
   return RM_OK;
 }
 
 int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *rgba,
                float *bright, RmCounters *counters, int threads) {
-  return rmo_render_tex(cam, objs, numObjects, lights, numLights, g, s, NULL, 0, W, H, rowBegin, rowEnd, rgba, bright,
+  return rmo_render_res(cam, objs, numObjects, lights, numLights, g, s, NULL, W, H, rowBegin, rowEnd, rgba, bright,
                         counters, threads);
 }
 
 int rmo_render_tex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                    const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
                    int rowBegin, int rowEnd, float *rgba, float *bright, RmCounters *counters, int threads) {
-  if (numTextures < 0 || numTextures > RM_MAX_TEXTURES) return RM_ERR_CAPACITY;
-  int st = validate(cam, objs, numObjects, lights, numLights, g, s, textures, numTextures);
+  RmResources r;
+  memset(&r, 0, sizeof r);
+  r.textures = textures; r.numTextures = numTextures;
+  return rmo_render_res(cam, objs, numObjects, lights, numLights, g, s, &r, W, H, rowBegin, rowEnd, rgba, bright,
+                        counters, threads);
+}
+
+int rmo_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                   const RmGlobals *g, const RmSettings *s, const RmResources *resIn, int W, int H, int rowBegin,
+                   int rowEnd, float *rgba, float *bright, RmCounters *counters, int threads) {
+  RmResources none;
+  memset(&none, 0, sizeof none);
+  const RmResources *res = resIn ? resIn : &none;
+  int st = validate(cam, objs, numObjects, lights, numLights, g, s, res);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || rowBegin < 0 || rowEnd > H || rowBegin > rowEnd || !rgba) return RM_ERR_INVALID_ARGUMENT;
   uint64_t nEval = 0, nIter = 0, nHit = 0;
@@ -1268,7 +1534,8 @@ int rmo_render_tex(const RmCamera *cam, const RmObject *objs, int numObjects, co
   for (int y = rowBegin; y < rowEnd; y++) {
     Ctx c;
     c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
-    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = textures; c.numTex = numTextures;
+    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = res->textures; c.numTex = res->numTextures;
+    c.res = res; c.W = W;
     for (int x = 0; x < W; x++) {
       size_t o = ((size_t)(y - rowBegin) * W + x) * 4;
       shadePixel(&c, x, y, W, H, rgba + o, bright ? bright + o : NULL);
@@ -1277,6 +1544,15 @@ int rmo_render_tex(const RmCamera *cam, const RmObject *objs, int numObjects, co
   }
   if (counters) { counters->sceneEvals = nEval; counters->bulbIters = nIter; counters->hitPixels = nHit; }
   return RM_OK;
+}
+
+void rmo_ltc_quantise(const float *table, uint8_t *out, int texels) {
+  for (int i = 0; i < texels * 4; i++) {
+    float v = table[i];
+    v = (v < 0.0f) ? 0.0f : ((v > 1.0f) ? 1.0f : v);
+    if (v != v) v = 0.0f;
+    out[i] = (uint8_t)rintf(v * 255.0f);
+  }
 }
 
 /* element-wise probes of the numeric contract (same fn ids as rm_probe_math) */
@@ -1326,6 +1602,27 @@ int rmo_probe_env(int kind, float iTime, const float *pts, float *out, int n) {
     if (kind == 0) r = cloudsFbm(&c, p);
     else if (kind == 1) { float nnd; v4 m = cloudsMap(&c, p, &nnd); r = V4(m.x, m.z, nnd, 0.0f); }
     else if (kind == 2) { v2 t = sdTerrain(p.x, p.z); r = V4(t.x, t.y, 0.0f, 0.0f); }
+    else return RM_ERR_INVALID_ARGUMENT;
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+  }
+  return RM_OK;
+}
+/* kind 3: (seaMap, seaMapD, noiseW(p.xz), sea_octave(p.xz, 1)); 4: (getMoonColor(normalize(p)), noiseV(p));
+ * 5: (sin(p.x), cos(p.x), hash(p.xy), 0).  `noise` (host pixels) is needed by kind 4. */
+int rmo_probe_env2(int kind, float iTime, const RmTexture *noise, const float *pts, float *out, int n) {
+  Ctx c;
+  RmResources res;
+  memset(&c, 0, sizeof c);
+  memset(&res, 0, sizeof res);
+  if (noise) res.noise = *noise;
+  c.res = &res;
+  c.g.iTime = iTime;
+  for (int i = 0; i < n; i++) {
+    v3 p = V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    v4 r = V4(0, 0, 0, 0);
+    if (kind == 3) r = V4(seaMap(&c, p, 3), seaMap(&c, p, 5), noiseW(p.x, p.z), sea_octave(p.x, p.z, 1.0f));
+    else if (kind == 4) { v3 m = getMoonColor(&c, normalize3(p)); r = V4(m.x, m.y, m.z, noiseV(&c, p)); }
+    else if (kind == 5) r = V4(rm_sin(p.x), rm_cos(p.x), hashSin2(p.x, p.y), 0.0f);
     else return RM_ERR_INVALID_ARGUMENT;
     out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
   }

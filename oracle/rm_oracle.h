@@ -17,12 +17,18 @@ int rmo_render(const RmCamera *cam, const RmObject *objs, int numObjects, const 
 int rmo_render_tex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                    const RmGlobals *g, const RmSettings *s, const RmTexture *textures, int numTextures, int W, int H,
                    int rowBegin, int rowEnd, float *rgba, float *bright, RmCounters *counters, int threads);
+/* Same with every sampler (HOST pointers throughout RmResources); res may be NULL. */
+int rmo_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                   const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int rowBegin,
+                   int rowEnd, float *rgba, float *bright, RmCounters *counters, int threads);
+void rmo_ltc_quantise(const float *table, uint8_t *out, int texels);
 /* Post passes on host buffers (see rm_post_process). */
 int rmo_post_process(const float *frag, const float *bright, float *out, int W, int H, const RmPostSettings *ps);
 int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float *out, int n);
 int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s,
                       const float *pts, float *out, int n);
 int rmo_probe_env(int kind, float iTime, const float *pts, float *out, int n);
+int rmo_probe_env2(int kind, float iTime, const RmTexture *noise, const float *pts, float *out, int n);
 uint32_t rmo_const_bits(int which);
 #ifdef __cplusplus
 }

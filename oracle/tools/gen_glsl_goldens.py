@@ -36,9 +36,17 @@ def pack(scene, settings):
                 settings=raw(settings))
 
 
-def frame_case(name, scene, settings, W, H, texture=None):
-    rgba, bright = run_ref.render(scene, settings, W, H, texture)
+def frame_case(name, scene, settings, W, H, texture=None, **res):
+    """res: noise= / skybox= (six faces) / ltc1=, ltc2= — the sampler inputs of tg.resource_case, stored in the fixture."""
+    ltc = (res["ltc1"], res["ltc2"]) if "ltc1" in res else None
+    rgba, bright = run_ref.render(scene, settings, W, H, texture, noise=res.get("noise"), skybox=res.get("skybox"), ltc=ltc)
     extra = {} if texture is None else {"texture": texture}
+    for k, v in res.items():
+        if k == "noise":  # 256 KB of random bytes: stored once, shared by every fixture that samples it
+            np.save(os.path.join(OUT, "noise_synthetic.npy"), v)
+            extra["uses_noise"] = 1
+        else:
+            extra["res_" + k] = np.stack(v) if k == "skybox" else v
     np.savez_compressed(os.path.join(OUT, f"frame_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, **extra, **pack(scene, settings))
     print("frame", name, rgba.shape, float(np.nanmax(rgba)))
 
@@ -121,8 +129,34 @@ def post_cases():
         print("post", name, out.shape, {k: float(v.mean()) for k, v in extra.items() if k == "tie"})
 
 
+def resource_cases(only=None):
+    """Night sky, sea, sky box and area lights: the reference shader with its noise / cube-map / LTC samplers bound to
+    the synthetic inputs of tests/test_gpu_parity.py."""
+    W, H = 64, 40
+    for name in tg.RESOURCE_CASES:
+        if only and name not in only:
+            continue
+        scene, s, res = tg.resource_case(name, W, H)
+        if s.enableSoftShadow or (s.features & abi.RM_FEAT_CLOUD):
+            continue  # UB1 (soft shadow reads an unset variable) / UB10 (cloud density sample): covered by the env cases
+        frame_case("res_" + name, scene, s, W, H, **res)
+    if only:
+        return
+    # function-level probes of the sea and the night sky
+    rng = np.random.default_rng(3)
+    scene, s = tg.sea_scene(8, 8), abi.default_settings()
+    pts = rng.uniform(-30, 30, (4096, 3)).astype(np.float32)
+    noise = tg.synthetic_noise()
+    for kind in ("sea", "moon", "sinhash"):
+        out = run_ref.probe(kind, scene, s, pts, noise=noise)
+        np.savez_compressed(os.path.join(OUT, f"probe_{kind}.npz"), kind=kind, pts=pts, out=out, uses_noise=1, **pack(scene, s))
+        print("probe", kind, out.shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "res":
+        return resource_cases(sys.argv[2:])
     if len(sys.argv) > 1 and sys.argv[1] == "post":
         return post_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "env":
@@ -132,6 +166,7 @@ def main():
     texture_cases()
     env_cases()
     post_cases()
+    resource_cases()
     W, H = 64, 48
     WB, DB = abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND
     prims = tg.all_primitives_scene(W, H)

@@ -80,6 +80,9 @@ PROBE_MAIN = {
     "cloudsfbm": "fragColor = cloudsFbm(q.xyz);",
     "cloudsmap": "float nn = 0.0; vec4 r = cloudsMap(q.xyz, nn); fragColor = vec4(r.x, r.z, nn, 0.0);",
     "terrain": "vec2 e = sdTerrain(q.xz); fragColor = vec4(e.x, e.y, 0.0, 0.0);",
+    "sea": "fragColor = vec4(seaMap(q.xyz), seaMapD(q.xyz), noiseW(q.xz), sea_octave(q.xz, 1.0));",
+    "sinhash": "fragColor = vec4(sin(q.x), cos(q.x), hash(q.xy), 0.0);",
+    "moon": "fragColor = vec4(getMoonColor(normalize(q.xyz)), noiseV(q.xyz));",
 }
 
 

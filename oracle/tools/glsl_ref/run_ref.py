@@ -44,7 +44,7 @@ def build_program(defines, consts, max_objects=6, max_lights=4, spec=None, probe
     return prog
 
 
-def set_uniforms(prog, cam, objs, no, lights, nl, g, s):
+def set_uniforms(prog, cam, objs, no, lights, nl, g, s, W=0, H=0):
     """What configure{Screen,Camera,Shapes,Lights,Settings}Uniforms upload (realtimerender.cpp:596-811)."""
     gl = ctx().gl
     gl.glUseProgram(prog)
@@ -64,6 +64,7 @@ def set_uniforms(prog, cam, objs, no, lights, nl, g, s):
     m = (C.c_float * 16)(*list(cam.invProjView))
     gl.glUniformMatrix4fv(loc("invProjViewMatrix"), 1, 0, m)
     f1("initialFar", cam.initialFar)
+    gl.glUniform2f(loc("screenDimensions"), float(W), float(H))  # configureScreenUniforms, realtimerender.cpp:621-629
     i1("isTwoD", g.isTwoD)
     f1("iTime", g.iTime)
     for k in ("ka", "kd", "ks", "kt"):
@@ -93,11 +94,21 @@ def set_uniforms(prog, cam, objs, no, lights, nl, g, s):
         f3(b + "lightFunc", li.func)
         f1(b + "lightAngle", li.angle)
         f1(b + "lightPenumbra", li.penumbra)
+        if li.type == 3:  # LIGHT_AREA: realtimerender.cpp:682-694
+            f1(b + "intensity", li.intensity)
+            i1(b + "twoSided", li.twoSided)
+            for k in range(4):
+                f3(b + f"points[{k}]", li.points[k])
     i1("enableSoftShadow", s.enableSoftShadow)
     i1("enableReflection", s.enableReflection)
     i1("enableRefraction", s.enableRefraction)
     i1("enableAmbientOcculusion", s.enableAmbientOcclusion)
-    i1("enableSkyBox", 0)
+    i1("enableSkyBox", s.enableSkyBox)
+    # texture units of src/realtime.h:17-27 (every objTextures[i] reads unit 0 here)
+    i1("noise", 13)
+    i1("bluenoise", 14)
+    i1("LTC1", 11)
+    i1("LTC2", 12)
     # samplers of different types may not share a texture unit: the cubemap goes to the reference's unit 10
     # (src/realtime.h:17-27); nothing is bound (incomplete textures sample as 0, as in the reference when
     # a texture file is missing, realtimerender.cpp:405-408).
@@ -121,19 +132,63 @@ def bind_object_texture(tex):
     return t
 
 
-def render(scene, settings, W, H, texture=None):
+def _tex2d(unit, a, wrap, min_filter=0x2601, mag_filter=0x2601):
+    gl = ctx().gl
+    t = C.c_uint()
+    gl.glGenTextures(1, C.byref(t))
+    gl.glActiveTexture(0x84C0 + unit)
+    gl.glBindTexture(gles.GL_TEXTURE_2D, t)
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    gl.glTexImage2D(gles.GL_TEXTURE_2D, 0, 0x8058, a.shape[1], a.shape[0], 0, 0x1908, 0x1401, a.ctypes.data_as(C.c_void_p))
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, gles.GL_TEXTURE_MIN_FILTER, min_filter)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, gles.GL_TEXTURE_MAG_FILTER, mag_filter)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, 0x2802, wrap)
+    gl.glTexParameteri(gles.GL_TEXTURE_2D, 0x2803, wrap)
+    gl.glActiveTexture(0x84C0)
+    return t
+
+
+def bind_noise(noise):
+    """`noise` sampler: RGBA8, GL_LINEAR, wrap left at the default GL_REPEAT (realtimerender.cpp:378-395)."""
+    return _tex2d(13, noise, 0x2901)
+
+
+def bind_ltc(ltc1, ltc2):
+    """LTC1/LTC2: 8-bit texels (unsized GL_RGBA upload), CLAMP_TO_EDGE, MIN NEAREST / MAG LINEAR (realtimerender.cpp:902-930)."""
+    return _tex2d(11, ltc1, 0x812F, min_filter=0x2600), _tex2d(12, ltc2, 0x812F, min_filter=0x2600)
+
+
+def bind_skybox(faces):
+    """initCubeMap (realtimerender.cpp:557-589): six RGBA8 faces, GL_LINEAR, GL_CLAMP_TO_EDGE, unit 10."""
+    gl = ctx().gl
+    t = C.c_uint()
+    gl.glGenTextures(1, C.byref(t))
+    gl.glActiveTexture(0x84C0 + 10)
+    gl.glBindTexture(0x8513, t)
+    for i, a in enumerate(faces):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        gl.glTexImage2D(0x8515 + i, 0, 0x8058, a.shape[1], a.shape[0], 0, 0x1908, 0x1401, a.ctypes.data_as(C.c_void_p))
+    for pname, v in ((gles.GL_TEXTURE_MIN_FILTER, 0x2601), (gles.GL_TEXTURE_MAG_FILTER, 0x2601), (0x2802, 0x812F), (0x2803, 0x812F),
+                     (0x8072, 0x812F)):
+        gl.glTexParameteri(0x8513, pname, v)
+    gl.glActiveTexture(0x84C0)
+    return t
+
+
+def render(scene, settings, W, H, texture=None, noise=None, skybox=None, ltc=None):
     """scene = (cam, objs, numObjects, lights, numLights, globals); returns (fragColor, BrightColor) float32 HxWx4,
-    row 0 = bottom (GL read-back order).  `texture`: optional RGBA8 array bound as objTextures[0]."""
+    row 0 = bottom (GL read-back order).  `texture`: optional RGBA8 array bound as objTextures[0]; `noise`: RGBA8 array
+    for the `noise` sampler; `skybox`: six RGBA8 faces; `ltc`: (ltc1, ltc2) uint8 (64,64,4) tables."""
     from raymarcher_amd import abi
     cam, objs, no, lights, nl, g = scene
     f = settings.features
-    defines = {"SKY_BACKGROUND": bool(f & abi.RM_FEAT_SKY_BACKGROUND), "NIGHTSKY_BACKGROUND": False,
+    defines = {"SKY_BACKGROUND": bool(f & abi.RM_FEAT_SKY_BACKGROUND), "NIGHTSKY_BACKGROUND": bool(f & abi.RM_FEAT_NIGHTSKY_BACKGROUND),
                "DARK_BACKGROUND": bool(f & abi.RM_FEAT_DARK_BACKGROUND), "WHITE_BACKGROUND": bool(f & abi.RM_FEAT_WHITE_BACKGROUND),
-               "CLOUD": bool(f & abi.RM_FEAT_CLOUD), "TERRAIN": bool(f & abi.RM_FEAT_TERRAIN), "SEA": False,
+               "CLOUD": bool(f & abi.RM_FEAT_CLOUD), "TERRAIN": bool(f & abi.RM_FEAT_TERRAIN), "SEA": bool(f & abi.RM_FEAT_SEA),
                "PERLIN_BUMP": bool(f & abi.RM_FEAT_PERLIN_BUMP)}
     consts = {"MAX_STEPS": settings.maxSteps, "MAX_STEPS_FRACTALS": settings.fractalIters,
               "NUM_REFLECTION": settings.numReflection, "MENGER_LEVELS": settings.mengerLevels}
-    false_u = ["enableSkyBox"]
+    false_u = [] if settings.enableSkyBox else ["enableSkyBox"]
     if not settings.enableReflection:
         false_u.append("enableReflection")
     if not settings.enableRefraction:
@@ -147,17 +202,23 @@ def render(scene, settings, W, H, texture=None):
     prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec)
     c = ctx()
     c.target(W, H, 2)
-    set_uniforms(prog, cam, objs, no, lights, nl, g, settings)
+    set_uniforms(prog, cam, objs, no, lights, nl, g, settings, W, H)
     if texture is not None:
         bind_object_texture(texture)
+    if noise is not None:
+        bind_noise(noise)
+    if skybox is not None:
+        bind_skybox(skybox)
+    if ltc is not None:
+        bind_ltc(*ltc)
     c.draw_fullscreen(prog)
     err = c.error()
     assert err == 0, f"GL error {err:#x}"
     return c.read(W, H, 0).copy(), c.read(W, H, 1).copy()
 
 
-def probe(kind, scene, settings, pts):
-    """Evaluate one reference function ('sdscene' | 'pnoise' | 'normal') at pts (N,3) → (N,4) float32."""
+def probe(kind, scene, settings, pts, noise=None):
+    """Evaluate one reference function (a key of essl_adapt.PROBE_MAIN) at pts (N,3) → (N,4) float32."""
     from raymarcher_amd import abi
     cam, objs, no, lights, nl, g = scene
     pts = np.asarray(pts, dtype=np.float32)
@@ -175,6 +236,8 @@ def probe(kind, scene, settings, pts):
     gl = c.gl
     c.target(W, H, 2)
     set_uniforms(prog, cam, objs, no, lights, nl, g, settings)
+    if noise is not None:
+        bind_noise(noise)
     tex = C.c_uint()
     gl.glGenTextures(1, C.byref(tex))
     gl.glActiveTexture(0x84C0 + 1)

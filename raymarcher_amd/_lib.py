@@ -28,6 +28,9 @@ SIGNATURES = {
     "rm_render": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rm_render_ex": (C.c_int, _SCENE_ARGS + [_P(abi.RmTexture), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
+    "rm_render_res": (C.c_int, _SCENE_ARGS + [_P(abi.RmResources), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
+    "rm_ltc_quantise": (None, [C.c_void_p, C.c_void_p, C.c_int]),
     "rm_image_load": (C.c_int, [C.c_char_p, C.c_int, _P(C.c_void_p), _P(C.c_int), _P(C.c_int)]),
     "rm_image_free": (None, [C.c_void_p]),
     "rm_render_tiles": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

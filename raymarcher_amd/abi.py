@@ -61,6 +61,14 @@ class RmTexture(C.Structure):
     _fields_ = [("pixels", C.c_void_p), ("width", i32), ("height", i32)]
 
 
+RM_LTC_SIZE = 64
+
+
+class RmResources(C.Structure):
+    _fields_ = [("textures", C.POINTER(RmTexture)), ("numTextures", i32), ("noise", RmTexture), ("skybox", RmTexture * 6),
+                ("ltc1", C.c_void_p), ("ltc2", C.c_void_p)]
+
+
 class RmCamera(C.Structure):
     _fields_ = [("invProjView", f32 * 16), ("initialFar", f32), ("eyePosition", f32 * 4)]
 

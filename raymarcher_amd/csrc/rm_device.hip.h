@@ -46,6 +46,7 @@ RM_DEV V3 mix(V3 a, V3 b, float t) { return v3(mix_(a.x, b.x, t), mix_(a.y, b.y,
 constexpr float kSurfaceDist = 0.001f;  // frag:32
 
 }  // namespace rm
+#include "rm_sampler.hip.h"
 #include "rm_env.hip.h"
 namespace rm {
 
@@ -61,6 +62,9 @@ struct SceneBlock {
   RmLight lights[RM_MAX_LIGHTS];
   RmTexture tex[RM_MAX_TEXTURES];  // device pixel pointers
   int32_t numTextures;
+  RmTexture noise;                 // `noise` (night sky, sea)
+  RmTexture skybox[6];             // cube-map faces +X,-X,+Y,-Y,+Z,-Z
+  const uint8_t *ltc1, *ltc2;      // RM_LTC_SIZE² RGBA8 tables of the area lights
 };
 
 struct SceneMin { int idx; float d; V4 trap; };
@@ -424,27 +428,6 @@ RM_DEV void uvMap(int type, V3 p, float rU, float rV, float &su, float &sv) {
   su = u * rU;
   sv = v * rV;
 }
-RM_DEV int wrapIndex(float f, int n) {
-  f = (fabs_(f) < 1.0e9f) ? f : 0.0f;
-  int i = (int)f % n;
-  return i < 0 ? i + n : i;
-}
-// texture(sampler2D, uv): RGBA8, GL_LINEAR, GL_REPEAT (GL 3.3 §3.8.11), weights in binary32.
-RM_DEV V3 sampleTexture(const RmTexture &t, float su, float sv) {
-  const int W = t.width, H = t.height;
-  float u = fma(su, (float)W, -0.5f), v = fma(sv, (float)H, -0.5f);
-  float fu = floor_(u), fv = floor_(v);
-  float a = u - fu, b = v - fv;
-  int i0 = wrapIndex(fu, W), j0 = wrapIndex(fv, H);
-  int i1 = (i0 + 1 == W) ? 0 : i0 + 1, j1 = (j0 + 1 == H) ? 0 : j0 + 1;
-  const uchar4 *px = reinterpret_cast<const uchar4 *>(t.pixels);
-  uchar4 p00 = px[(size_t)j0 * W + i0], p10 = px[(size_t)j0 * W + i1], p01 = px[(size_t)j1 * W + i0], p11 = px[(size_t)j1 * W + i1];
-  V3 lo = v3(mix_((float)p00.x / 255.0f, (float)p10.x / 255.0f, a), mix_((float)p00.y / 255.0f, (float)p10.y / 255.0f, a),
-             mix_((float)p00.z / 255.0f, (float)p10.z / 255.0f, a));
-  V3 hi = v3(mix_((float)p01.x / 255.0f, (float)p11.x / 255.0f, a), mix_((float)p01.y / 255.0f, (float)p11.y / 255.0f, a),
-             mix_((float)p01.z / 255.0f, (float)p11.z / 255.0f, a));
-  return v3(mix_(lo.x, hi.x, b), mix_(lo.y, hi.y, b), mix_(lo.z, hi.z, b));
-}
 // frag:1746-1781.  `o` is the per-lane object record (LDS copy).
 template <bool TEX>
 RM_DEV V3 getDiffuse(const SceneBlock *sb, const RmObject &o, V3 p) {
@@ -460,6 +443,68 @@ RM_DEV V3 getDiffuse(const SceneBlock *sb, const RmObject &o, V3 p) {
   V3 t = sampleTexture(sb->tex[o.texLoc], su, sv);
   float k = (1.0f - o.blend) * kd;
   return v3(fma(o.blend, t.x, k * o.cDiffuse[0]), fma(o.blend, t.y, k * o.cDiffuse[1]), fma(o.blend, t.z, k * o.cDiffuse[2]));
+}
+
+// ---- area lights: linearly transformed cosines (frag:349-424, 1794-1822) ---------------------------------------
+// LTC tables are GL_CLAMP_TO_EDGE; GL_LINEAR is used for every fetch (the reference's MIN = NEAREST / MAG = LINEAR
+// split hangs on derivatives taken in divergent control flow, undefined in GLSL; a smooth uv over a 64² table magnifies).
+constexpr float kLutScale = (64.0f - 1.0f) / 64.0f, kLutBias = 0.5f / 64.0f;  // frag:47-49
+RM_DEV V3 cross(V3 a, V3 b) {
+  return v3(fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x)));
+}
+RM_DEV V3 integrateEdgeVec(V3 v1, V3 v2) {  // frag:349-361
+  float x = dot(v1, v2), y = fabs_(x);
+  float a = fma(fma(0.0145206f, y, 0.4965155f), y, 0.8543985f);
+  float b = fma(4.1616724f + y, y, 3.4175940f);
+  float v = a / b;
+  float ts = (x > 0.0f) ? v : fma(0.5f, 1.0f / sqrt_(max_(fma(-x, x, 1.0f), 1e-7f)), -v);
+  return scale(cross(v1, v2), ts);
+}
+RM_DEV float ltcEvaluate(const SceneBlock *sb, V3 N, V3 V, V3 P, const M3 &MinvIn, const RmLight &li) {  // frag:368-424
+  V3 T1 = normalize(madd(N, -dot(V, N), V));
+  V3 T2 = cross(N, T1);
+  M3 B;  // transpose(mat3(T1, T2, N))
+  B.c[0][0] = T1.x; B.c[0][1] = T2.x; B.c[0][2] = N.x;
+  B.c[1][0] = T1.y; B.c[1][1] = T2.y; B.c[1][2] = N.y;
+  B.c[2][0] = T1.z; B.c[2][1] = T2.z; B.c[2][2] = N.z;
+  M3 Minv = mulMM(MinvIn, B);
+  V3 pts[4], L[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    pts[k] = v3(li.points[k][0], li.points[k][1], li.points[k][2]);
+    L[k] = normalize(mulMV(Minv, sub(pts[k], P)));
+  }
+  V3 lightNormal = cross(sub(pts[1], pts[0]), sub(pts[3], pts[0]));
+  bool behind = dot(sub(pts[0], P), lightNormal) < 0.0f;
+  V3 vsum = integrateEdgeVec(L[0], L[1]);
+  vsum = add(vsum, integrateEdgeVec(L[1], L[2]));
+  vsum = add(vsum, integrateEdgeVec(L[2], L[3]));
+  vsum = add(vsum, integrateEdgeVec(L[3], L[0]));
+  float l = len(vsum);
+  float z = vsum.z / l;
+  z = behind ? -z : z;
+  float sc = sampleRGBA8<true>(sb->ltc2, RM_LTC_SIZE, RM_LTC_SIZE, fma(fma(z, 0.5f, 0.5f), kLutScale, kLutBias),
+                               fma(l, kLutScale, kLutBias)).w;
+  float sum = l * sc;
+  return (!behind && !li.twoSided) ? 0.0f : sum;
+}
+RM_DEV V3 getAreaLight(const SceneBlock *sb, V3 N, V3 V, V3 P, const RmLight &li, const Material &mat) {  // frag:1795-1822
+  float dotNV = clamp_(dot(N, V), 0.0f, 1.0f);
+  float u = fma(0.0f, kLutScale, kLutBias), v = fma(sqrt_(1.0f - dotNV), kLutScale, kLutBias);
+  V4 t1 = sampleRGBA8<true>(sb->ltc1, RM_LTC_SIZE, RM_LTC_SIZE, u, v), t2 = sampleRGBA8<true>(sb->ltc2, RM_LTC_SIZE, RM_LTC_SIZE, u, v);
+  M3 Minv, I;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) { Minv.c[c][r] = (c == 1 && r == 1) ? 1.0f : 0.0f; I.c[c][r] = (c == r) ? 1.0f : 0.0f; }
+  Minv.c[0][0] = t1.x; Minv.c[0][2] = t1.y; Minv.c[2][0] = t1.z; Minv.c[2][2] = t1.w;
+  float diffuse = ltcEvaluate(sb, N, V, P, I, li);
+  float specular = ltcEvaluate(sb, N, V, P, Minv, li);
+  float spx = specular * fma(li.intensity - mat.spec.x, t2.y, mat.spec.x * t2.x);
+  float spy = specular * fma(li.intensity - mat.spec.y, t2.y, mat.spec.y * t2.x);
+  float spz = specular * fma(li.intensity - mat.spec.z, t2.y, mat.spec.z * t2.x);
+  return v3((li.color[0] * 1.0f) * fma(mat.dif.x, diffuse, spx), (li.color[1] * 1.0f) * fma(mat.dif.y, diffuse, spy),
+            (li.color[2] * 1.0f) * fma(mat.dif.z, diffuse, spz));
 }
 
 // Per-light geometry of getPhong (frag:1864-1880): direction to the light, shadow-march range, attenuation,
@@ -505,8 +550,9 @@ RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat
 }
 
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
-template <bool BULB, bool COUNT>
-RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
+// RES = true adds the area-light branch (frag:1884-1905); `objs` is only read there.
+template <bool BULB, bool COUNT, bool RES>
+RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
   const float ka = sb->g.ka, ks = sb->g.ks;
   float ao = 1.0f;
   if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT>(sb, p, N, cnt);
@@ -517,6 +563,18 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const Material &mat, V3 N, V3 p, V3 rd,
   const bool soft = sb->s.enableSoftShadow != 0;
   for (int i = 0; i < nl; i++) {
     const RmLight &li = sb->lights[i];  // uniform index → scalar loads
+    if (RES && li.type == RM_LIGHT_AREA) {  // AREA_LIGHT_SAMPLES = 1; the "random" uv is rd.xy (frag:1889)
+      V3 p1 = v3(li.points[0][0], li.points[0][1], li.points[0][2]);
+      V3 side1 = sub(v3(li.points[1][0], li.points[1][1], li.points[1][2]), p1);
+      V3 side2 = sub(v3(li.points[3][0], li.points[3][1], li.points[3][2]), p1);
+      V3 toL = sub(madd(side2, rd.y + 0.0f, madd(side1, rd.x + 0.0f, p1)), p);
+      V3 L = normalize(toL);
+      if (dot(N, L) <= 0.005f) continue;
+      MarchRes sh = march<BULB, COUNT, true>(sb, so, L, len(toL), 1.0f, cnt);
+      if (sh.obj != -1 && objs[sh.obj].lightIdx != i) continue;  // only the light's own rectangle may be "in the way"
+      total = add(total, getAreaLight(sb, N, V, p, li, mat));
+      continue;
+    }
     LightGeom g = lightSetup(li, p, far);
     // The reference marches the shadow ray first and only then drops lights with N·L <= 0.005 (frag:1908-1912);
     // the march result of such a light is never read, so it is not marched here (COUNT keeps the reference's
@@ -547,7 +605,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   info.obj = -1;
   MarchRes res = march<BULB, COUNT, false>(sb, ro, rd, maxT, side, cnt);
   if (res.obj == -1) {
-    out.col = bg;
+    out.col = (TEX && sb->s.enableSkyBox) ? sampleCube(sb->skybox, rd) : bg;  // frag:2325-2327
     out.isEnv = 1;
     out.d = maxT;  // frag:2328
     return out;
@@ -558,13 +616,17 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   V3 pn = getNormal<BULB, COUNT>(sb, p, cnt);
   if (sb->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p);
   const RmObject &o = objs[BULB ? 0 : res.obj];
+  if (TEX && o.isEmissive) {  // frag:2339-2342: the rectangle of an area light; info.obj stays -1
+    out.col = v3(o.color[0], o.color[1], o.color[2]);
+    return out;
+  }
   Material mat;
   mat.amb = v3(o.cAmbient[0], o.cAmbient[1], o.cAmbient[2]);
   mat.dif = getDiffuse<TEX>(sb, o, p);
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   const int type = BULB ? (int)RM_MANDELBULB : o.type;
-  V3 ph = getPhong<BULB, COUNT>(sb, mat, pn, p, rd, maxT, cnt);
+  V3 ph = getPhong<BULB, COUNT, TEX>(sb, objs, mat, pn, p, rd, maxT, cnt);
   V3 col = ph;
   if (type == RM_MANDELBULB) {  // frag:2354-2361
     V3 c = bulbTrapColor(res.trap.y, res.trap.z, res.trap.w);
@@ -605,6 +667,7 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb) {  // frag:2405-2419 without SKY
 RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
   V3 bg = v3(0.0f, 0.0f, 0.0f);
   if (sb->s.features & RM_FEAT_SKY_BACKGROUND) bg = getSky(rd);
+  if (sb->s.features & RM_FEAT_NIGHTSKY_BACKGROUND) bg = getMoonColor(sb->noise, sb->g.iTime, rd);
   if (sb->s.features & RM_FEAT_WHITE_BACKGROUND) bg = v3(1.0f, 1.0f, 1.0f);
   if (sb->s.features & RM_FEAT_DARK_BACKGROUND) bg = v3(0.0f, 0.0f, 0.0f);
   return bg;
@@ -629,21 +692,21 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   primaryRay(sb, ndcx, ndcy, ro, rd);
   const V3 bg = ENV ? backgroundColor(sb, rd) : backgroundColor(sb);
   const uint32_t feat = sb->s.features;
-  const bool env = ENV && (feat & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD)) != 0;
+  const bool env = ENV && (feat & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SEA)) != 0;
   const float far = (ENV && (feat & RM_FEAT_CLOUD)) ? 2000.0f : sb->cam.initialFar;  // frag:2422-2426
   const float iTime = sb->g.iTime;
 
   Hit info;
   RenderOut ri = render<BULB, COUNT, TEX>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
-  bool terrainHit = false, cloudHit = false;
-  V3 tcol = bg, ccol = bg;
-  if (env) envLayers(feat, iTime, ro, rd, ri.d, bg, terrainHit, cloudHit, tcol, ccol);  // frag:2444-2456
-  if (ri.isEnv && !cloudHit && !terrainHit) {  // frag:2459-2465
+  EnvOut e;
+  e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
+  if (env) e = envLayers(feat, sb->noise, iTime, W, ro, rd, ri.d, bg);  // frag:2444-2456
+  if (ri.isEnv && !e.cloudHit && !e.terrainHit && !e.seaHit) {  // frag:2459-2465
     fragColor = v4(ri.col.x, ri.col.y, ri.col.z, 1.0f);
     return;
   }
-  if (cloudHit || terrainHit) {  // frag:2466-2471: cloud wins over terrain
-    V3 c = cloudHit ? ccol : tcol;
+  if (e.cloudHit || e.terrainHit || e.seaHit) {  // frag:2466-2474: cloud wins over terrain, terrain over sea
+    V3 c = e.cloudHit ? e.ccol : (e.terrainHit ? e.tcol : e.scol);
     fragColor = v4(c.x, c.y, c.z, 1.0f);
     if (dot(c, v3(0.2126f, 0.7152f, 0.0722f)) > 1.0f) bright = v4(c.x, c.y, c.z, 1.0f);
     return;
@@ -652,9 +715,12 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   V4 phong = v4(ri.col.x, ri.col.y, ri.col.z, 1.0f);
   V4 refl = v4(0.0f, 0.0f, 0.0f, 0.0f), refr = v4(0.0f, 0.0f, 0.0f, 0.0f);
   const Hit oi = info;  // frag:2481
-  const RmObject &o = objs[BULB ? 0 : info.obj];
-  const V3 cRefl = v3(o.cReflective[0], o.cReflective[1], o.cReflective[2]);
-  const V3 cRefr = v3(o.cTransparent[0], o.cTransparent[1], o.cTransparent[2]);
+  // UB5: an emissive hit leaves info.obj = -1 and the shader reads objects[-1] (frag:2341, 2483); that read is
+  // taken as zeros (robust-access behaviour), i.e. no secondary rays.
+  const bool noObj = TEX && info.obj < 0;
+  const RmObject &o = objs[(BULB || noObj) ? 0 : info.obj];
+  const V3 cRefl = noObj ? v3(0.0f, 0.0f, 0.0f) : v3(o.cReflective[0], o.cReflective[1], o.cReflective[2]);
+  const V3 cRefr = noObj ? v3(0.0f, 0.0f, 0.0f) : v3(o.cTransparent[0], o.cTransparent[1], o.cTransparent[2]);
   const float ior = o.ior;
   if (sb->s.enableReflection && len(cRefl) != 0.0f) {  // frag:2491-2524
     V3 fil = v3(1.0f, 1.0f, 1.0f);
@@ -665,11 +731,11 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
                   fma(r.z * kSurfaceDist, 3.0f, info.p.z));
       fil = mul(fil, cRefl);
       RenderOut res = render<BULB, COUNT, TEX>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
-      if (env) {  // frag:2506-2518
-        bool th, ch; V3 tc, cc;
-        envLayers(feat, iTime, sro, r, res.d, bg, th, ch, tc, cc);
-        if (th) { res.col = tc; res.isEnv = 1; }
-        if (ch) { res.col = cc; res.isEnv = 1; }
+      if (env) {  // frag:2506-2518 (a sea hit sets sr.isEnv, not res.isEnv: the bounce loop goes on)
+        EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, r, res.d, bg);
+        if (b.seaHit) res.col = b.scol;
+        if (b.terrainHit) { res.col = b.tcol; res.isEnv = 1; }
+        if (b.cloudHit) { res.col = b.ccol; res.isEnv = 1; }
       }
       refl.x += (sb->g.ks * fil.x) * res.col.x;
       refl.y += (sb->g.ks * fil.y) * res.col.y;
@@ -691,10 +757,10 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
                   fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
       RenderOut res = render<BULB, COUNT, TEX>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2555-2567
-        bool th, ch; V3 tc, cc;
-        envLayers(feat, iTime, sro, rdOut, res.d, bg, th, ch, tc, cc);
-        if (th) res.col = tc;
-        if (ch) res.col = cc;
+        EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, rdOut, res.d, bg);
+        if (b.seaHit) res.col = b.scol;
+        if (b.terrainHit) res.col = b.tcol;
+        if (b.cloudHit) res.col = b.ccol;
       }
       refr.x += (sb->g.kt * cRefr.x) * res.col.x;
       refr.y += (sb->g.kt * cRefr.y) * res.col.y;

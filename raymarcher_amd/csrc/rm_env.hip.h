@@ -6,6 +6,7 @@
 // evaluates `f*m3*x` as (f*m3)*x, so the scaled constant matrices are formed first.
 #pragma once
 #include "rm_math.hip.h"
+#include "rm_sampler.hip.h"
 
 namespace rm {
 
@@ -281,14 +282,132 @@ RM_DEV bool terrainRender(float iTime, V3 ro, V3 rd, float maxT, V3 bg, V3 &colO
   colOut = mul(col, lin);
   return true;
 }
-// Terrain then cloud after a render() (frag:2444-2456, 2506-2518, 2555-2567).
-RM_DEV void envLayers(uint32_t features, float iTime, V3 ro, V3 rd, float d, V3 bg, bool &terrainHit, bool &cloudHit, V3 &tcol,
-                      V3 &ccol) {
-  float td = d;
-  terrainHit = false; cloudHit = false;
-  tcol = bg; ccol = bg;
-  if (features & RM_FEAT_TERRAIN) terrainHit = terrainRender(iTime, ro, rd, d, bg, tcol, td);
-  if (features & RM_FEAT_CLOUD) ccol = cloudRender(iTime, ro, rd, bg, cloudHit, td);
+// ---- night sky and sea (frag:476-516, 591-598, 1562-1573, 2160-2310): both read the `noise` texture -------------
+RM_DEV float hashSin2(float px, float py) {  // frag:481-483
+  return fract_(sin_(dot2(px, py, 12.9898f, 78.233f)) * 43758.5453f);
+}
+RM_DEV float hermite(float f) { return (f * f) * fma(-2.0f, f, 3.0f); }
+RM_DEV float noiseW(float px, float py) {  // frag:504-518
+  float ix = floor_(px), iy = floor_(py);
+  float ux = hermite(fract_(px)), uy = hermite(fract_(py));
+  float a = hashSin2(ix + 0.0f, iy + 0.0f), b = hashSin2(ix + 1.0f, iy + 0.0f);
+  float c = hashSin2(ix + 0.0f, iy + 1.0f), d = hashSin2(ix + 1.0f, iy + 1.0f);
+  return fma(2.0f, mix_(mix_(a, b, ux), mix_(c, d, ux), uy), -1.0f);
+}
+RM_DEV float noiseV(const RmTexture &noise, V3 x) {  // frag:591-598; textureLod(noise, ·, 0).yx
+  V3 p = v3(floor_(x.x), floor_(x.y), floor_(x.z));
+  V3 f = v3(hermite(fract_(x.x)), hermite(fract_(x.y)), hermite(fract_(x.z)));
+  float u = fma(37.0f, p.z, p.x) + f.x, v = fma(239.0f, p.z, p.y) + f.y;
+  V4 t = sampleRGBA8<false>(noise.pixels, noise.width, noise.height, (u + 0.5f) / 256.0f, (v + 0.5f) / 256.0f);
+  return fma(mix_(t.y, t.x, f.z), 2.0f, -1.0f);
+}
+RM_DEV V3 getMoonColor(const RmTexture &noise, float iTime, V3 rd) {  // frag:1562-1573, MOON of frag:107
+  const V3 MOON = normalize(v3(-0.4f, 0.4f, 0.3f));
+  float ms = noiseV(noise, scale(rd, 20.0f));
+  float q = (0.1f * ms) * ms;
+  V3 mCol = v3(fma(-q, ms, 0.5f), fma(-q, ms, 0.5f), fma(-q, ms, 0.3f));
+  float moonDot = dot(MOON, rd);
+  V3 col = scale(mCol, smoothstep_(0.9985f, 0.999f, moonDot));
+  float halo = smoothstep_(0.91f, 0.9985f, moonDot);
+  col = v3(fma(0.15f, halo, col.x), fma(0.15f, halo, col.y), fma(0.15f, halo, col.z));
+  float sh = 6.0f * sin_(iTime / 2.0f);
+  float star = smoothstep_(0.99f, 0.999f, noiseV(noise, v3(floor_(fma(rd.x, 202.0f, -sh)), floor_(fma(rd.y, 202.0f, -sh)),
+                                                          floor_(fma(rd.z, 202.0f, -sh)))));
+  float sc = clamp_(star, 0.0f, 1.0f);
+  return v3(fma(sc, 0.4f, col.x), fma(sc, 0.4f, col.y), fma(sc, 0.4f, col.z));
+}
+constexpr float kSeaHeight = 0.2f, kSeaChoppy = 1.0f, kSeaSpeed = 0.5f, kSeaFreq = 0.16f;  // frag:96-99
+RM_DEV float sea_octave(float ux, float uy, float choppy) {  // frag:2162-2169
+  float n = noiseW(ux, uy);
+  ux += n; uy += n;
+  float sx, cx, sy, cy;
+  sincos_(ux, sx, cx);
+  sincos_(uy, sy, cy);
+  float wx = 1.0f - fabs_(sx), wy = 1.0f - fabs_(sy);
+  wx = mix_(wx, fabs_(cx), wx); wy = mix_(wy, fabs_(cy), wy);
+  return pow_(1.0f - pow_(wx * wy, 0.65f), choppy);
+}
+// seaMap (ITER_GEOMETRY = 3) / seaMapD (ITER_FRAGMENT = 5), frag:2195-2241; SEA_TIME of frag:2192.
+RM_DEV float seaMap(float iTime, V3 p, int iters) {
+  const float seaTime = fma(iTime, kSeaSpeed, 1.0f);
+  float freq = kSeaFreq, amp = kSeaHeight, choppy = kSeaChoppy, ux = p.x, uy = p.z, h = 0.0f;
+  for (int i = 0; i < iters; i++) {
+    float d = sea_octave((ux + seaTime) * freq, (uy + seaTime) * freq, choppy);
+    d += sea_octave((ux - seaTime) * freq, (uy - seaTime) * freq, choppy);
+    h = fma(d, amp, h);
+    float nx = dot2(ux, uy, 1.6f, 1.2f), ny = dot2(ux, uy, -1.2f, 1.6f);  // uv *= octave_m (row vector × mat2)
+    ux = nx; uy = ny;
+    freq *= 2.0f; amp *= 0.2f;
+    choppy = mix_(choppy, 1.0f, 0.2f);
+  }
+  return p.y - h;
+}
+RM_DEV V3 getSeaNormal(float iTime, V3 p, float eps) {  // frag:2243-2250
+  float ny = seaMap(iTime, p, 5);
+  float nx = seaMap(iTime, v3(p.x + eps, p.y, p.z), 5) - ny;
+  float nz = seaMap(iTime, v3(p.x, p.y, p.z + eps), 5) - ny;
+  return normalize(v3(nx, eps, nz));
+}
+RM_DEV float seaMapHeight(float iTime, V3 ro, V3 rd, V3 &p, float maxT) {  // frag:2252-2282
+  float tm = 0.0f, tx = 1000.0f;
+  float hx = seaMap(iTime, madd(rd, tx, ro), 3);
+  if (hx > 0.0f) { p = v3(0.0f, 0.0f, 0.0f); return tx; }
+  float hm = seaMap(iTime, madd(rd, tm, ro), 3);
+  float tmid = 0.0f;
+  for (int i = 0; i < 8; i++) {
+    float f = hm / (hm - hx);
+    tmid = mix_(tm, tx, f);
+    p = madd(rd, tmid, ro);
+    if (tmid > maxT) return -1.0f;
+    float hmid = seaMap(iTime, p, 3);
+    if (hmid < 0.0f) { tx = tmid; hx = hmid; } else { tm = tmid; hm = hmid; }
+  }
+  return tmid;
+}
+RM_DEV V3 getSeaColor(const RmTexture &noise, float iTime, V3 p, V3 n, V3 l, V3 eye, V3 dist) {  // frag:2171-2190
+  const V3 base = v3(0.4f, 0.49f, 0.48f), water = v3(0.8f, 0.9f, 0.6f);  // frag:101-102
+  float fresnel = clamp_(1.0f - dot(n, neg(eye)), 0.0f, 1.0f);
+  fresnel = pow_(fresnel, 3.0f) * 0.65f;
+  V3 refl = reflect(eye, n);
+  V3 reflected = getMoonColor(noise, iTime, refl);
+  float pw = pow_(fma(dot(n, l), 0.4f, 0.6f), 80.0f);
+  V3 refracted = v3(fma(pw * water.x, 0.12f, base.x), fma(pw * water.y, 0.12f, base.y), fma(pw * water.z, 0.12f, base.z));
+  V3 color = mix(refracted, reflected, fresnel);
+  float atten = max_(fma(-dot(dist, dist), 0.001f, 1.0f), 0.0f);
+  float dh = p.y - kSeaHeight;
+  color = v3(fma((water.x * dh) * 0.18f, atten, color.x), fma((water.y * dh) * 0.18f, atten, color.y),
+             fma((water.z * dh) * 0.18f, atten, color.z));
+  const float nrm = (60.0f + 8.0f) / (3.14159265f * 8.0f);
+  float spec = pow_(max_(dot(refl, l), 0.0f), 60.0f) * nrm;
+  return v3(color.x + spec, color.y + spec, color.z + spec);
+}
+// frag:2284-2310; the bare `return;` of the miss path (UB7) returns colour = bg, d = maxT, no hit.
+RM_DEV bool seaRender(const RmTexture &noise, float iTime, int W, V3 ro, V3 rd, float maxT, V3 bg, V3 &colOut, float &dOut) {
+  colOut = bg; dOut = maxT;
+  V3 p;
+  float t = seaMapHeight(iTime, ro, rd, p, maxT);
+  if (len(p) == 0.0f || t == -1.0f) return false;
+  dOut = t;
+  V3 d = sub(p, ro);
+  V3 n = getSeaNormal(iTime, p, (dot(d, d) * 0.1f) / (float)W);
+  V3 s = getSky(rd);
+  V3 sc = getSeaColor(noise, iTime, p, n, getSunDir(), rd, d);
+  float t2 = pow_(smoothstep_(0.0f, -0.05f, rd.y), 0.3f);
+  colOut = fog(mix(s, sc, t2), t);
+  return true;
+}
+// Sea, terrain, then cloud after a render() (frag:2444-2456, 2506-2518, 2555-2567).  The cloud layer is bounded by
+// tr.d, which starts at the render's d — not at the sea's — when TERRAIN is off.
+struct EnvOut { bool terrainHit, cloudHit, seaHit; V3 tcol, ccol, scol; };
+RM_DEV EnvOut envLayers(uint32_t features, const RmTexture &noise, float iTime, int W, V3 ro, V3 rd, float d, V3 bg) {
+  EnvOut e;
+  float sd = d, td = d;
+  e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
+  e.tcol = bg; e.ccol = bg; e.scol = bg;
+  if (features & RM_FEAT_SEA) e.seaHit = seaRender(noise, iTime, W, ro, rd, d, bg, e.scol, sd);
+  if (features & RM_FEAT_TERRAIN) e.terrainHit = terrainRender(iTime, ro, rd, sd, bg, e.tcol, td);
+  if (features & RM_FEAT_CLOUD) e.ccol = cloudRender(iTime, ro, rd, bg, e.cloudHit, td);
+  return e;
 }
 
 }  // namespace rm

@@ -90,6 +90,15 @@ extern "C" {
 
 int rm_abi_version(void) { return RM_ABI_VERSION; }
 
+void rm_ltc_quantise(const float *table, uint8_t *out, int texels) {
+  for (int i = 0; i < texels * 4; i++) {
+    float v = table[i];
+    v = (v < 0.0f) ? 0.0f : ((v > 1.0f) ? 1.0f : v);
+    if (v != v) v = 0.0f;
+    out[i] = (uint8_t)std::nearbyintf(v * 255.0f);
+  }
+}
+
 const char *rm_status_string(int status) {
   switch (status) {
     case RM_OK: return "RM_OK";

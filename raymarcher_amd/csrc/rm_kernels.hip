@@ -215,8 +215,13 @@ int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, B
   return RM_OK;
 }
 
+bool tex_ok(const RmTexture &t) { return t.pixels && t.width > 0 && t.height > 0; }
+const RmResources kNoResources{};
+
 int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                   const RmGlobals *g, const RmSettings *s, const RmTexture *tex = nullptr, int numTex = 0) {
+                   const RmGlobals *g, const RmSettings *s, const RmResources &res) {
+  const RmTexture *tex = res.textures;
+  const int numTex = res.numTextures;
   if (numTex < 0 || (numTex > 0 && !tex)) { set_error("bad texture table"); return RM_ERR_INVALID_ARGUMENT; }
   if (numTex > RM_MAX_TEXTURES) { set_error("more than RM_MAX_TEXTURES textures"); return RM_ERR_CAPACITY; }
   if (!cam || !g || !s || (numObjects > 0 && !objs) || (numLights > 0 && !lights) || numObjects < 0 || numLights < 0) {
@@ -231,14 +236,20 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
     set_error("negative loop bound in RmSettings");
     return RM_ERR_INVALID_ARGUMENT;
   }
-  const uint32_t unsupported = RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA;
-  if ((s->features & unsupported) || s->enableSkyBox) {
-    set_error("feature mask / skybox outside the implemented hot-path scope");
+  if ((s->features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) && !tex_ok(res.noise)) {
+    set_error("NIGHTSKY_BACKGROUND / SEA read the noise texture: supply RmResources.noise (rm_render_res)");
     return RM_ERR_UNSUPPORTED;
   }
+  if (s->enableSkyBox) {
+    for (int f = 0; f < 6; f++)
+      if (!tex_ok(res.skybox[f])) {
+        set_error("enableSkyBox without six cube-map faces in RmResources.skybox (rm_render_res)");
+        return RM_ERR_UNSUPPORTED;
+      }
+  }
   for (int i = 0; i < numObjects; i++) {
-    if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM || objs[i].isEmissive) {
-      set_error("object " + std::to_string(i) + ": CUSTOM type or emissive (area light) not supported");
+    if (objs[i].type < 0 || objs[i].type >= RM_CUSTOM) {
+      set_error("object " + std::to_string(i) + ": CUSTOM / unknown type (the reference's sdCUSTOM returns an unset value)");
       return RM_ERR_UNSUPPORTED;
     }
     if (objs[i].texLoc != -1) {
@@ -251,15 +262,19 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
         set_error("object " + std::to_string(i) + ": textures are only defined for cube, cone, cylinder, sphere");
         return RM_ERR_UNSUPPORTED;
       }
-      if (!tex[t].pixels || tex[t].width <= 0 || tex[t].height <= 0) {
+      if (!tex_ok(tex[t])) {
         set_error("texture " + std::to_string(t) + ": null pixels or empty size");
         return RM_ERR_INVALID_ARGUMENT;
       }
     }
   }
   for (int i = 0; i < numLights; i++) {
-    if (lights[i].type < 0 || lights[i].type > RM_LIGHT_SPOT) {
-      set_error("light " + std::to_string(i) + ": area / unknown light type not supported");
+    if (lights[i].type < 0 || lights[i].type > RM_LIGHT_AREA) {
+      set_error("light " + std::to_string(i) + ": unknown light type");
+      return RM_ERR_UNSUPPORTED;
+    }
+    if (lights[i].type == RM_LIGHT_AREA && (!res.ltc1 || !res.ltc2)) {
+      set_error("light " + std::to_string(i) + ": area lights read the LTC tables: supply RmResources.ltc1/ltc2 (rm_render_res)");
       return RM_ERR_UNSUPPORTED;
     }
   }
@@ -267,8 +282,7 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
 }
 
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut,
-                const RmTexture *tex = nullptr, int numTex = 0) {
+                const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut, const RmResources &res) {
   Slot *slot;
   int st = acquire_slot(&slot);
   if (st != RM_OK) return st;
@@ -277,8 +291,11 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   h->numObjects = numObjects; h->numLights = numLights;
   for (int i = 0; i < numObjects; i++) h->objs[i] = objs[i];
   for (int i = 0; i < numLights; i++) h->lights[i] = lights[i];
-  h->numTextures = numTex;
-  for (int i = 0; i < numTex; i++) h->tex[i] = tex[i];
+  h->numTextures = res.numTextures;
+  for (int i = 0; i < res.numTextures; i++) h->tex[i] = res.textures[i];
+  h->noise = res.noise;
+  for (int f = 0; f < 6; f++) h->skybox[f] = res.skybox[f];
+  h->ltc1 = res.ltc1; h->ltc2 = res.ltc2;
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   *slotOut = slot;
   return RM_OK;
@@ -287,15 +304,15 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                   const RmGlobals *g, const RmSettings *s, int W, int H, RowMap map, int nRows, float *d_rgba,
                   float *d_bright, hipStream_t stream, bool count, RmCounters *countersOut,
-                  const RmTexture *tex = nullptr, int numTex = 0) {
+                  const RmResources &res = kNoResources) {
   std::lock_guard<std::mutex> lock(g_mu);
-  int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s, tex, numTex);
+  int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s, res);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || nRows < 0) { set_error("bad frame size"); return RM_ERR_INVALID_ARGUMENT; }
   if (nRows == 0) return RM_OK;  // empty row range: nothing to write, a null buffer is fine
   if (!d_rgba) { set_error("null output buffer"); return RM_ERR_INVALID_ARGUMENT; }
   Slot *slot;
-  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot, tex, numTex);
+  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot, res);
   if (st != RM_OK) return st;
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -309,8 +326,12 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
   int path = g_kernelPath ? g_kernelPath : envPath;
   if (path == 0) path = kAutoBulbPath;
-  const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND)) != 0;
-  const bool pipeline = bulb && !count && path != 1 && !envFeatures && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
+  const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND | RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) != 0;
+  // anything that reads a sampler or takes the area-light branches: object textures, sky box, emissive rectangles, area lights
+  bool textured = s->enableSkyBox != 0;
+  for (int i = 0; i < numObjects; i++) textured = textured || objs[i].texLoc != -1 || objs[i].isEmissive;
+  for (int i = 0; i < numLights; i++) textured = textured || lights[i].type == RM_LIGHT_AREA;
+  const bool pipeline = bulb && !count && path != 1 && !envFeatures && !textured && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
   TimedLaunch tl{};
@@ -380,8 +401,6 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
     // procedural layers or textures; the generic kernel with either or both.  Features a launch does not need are
     // compiled out so the common kernels keep their register budget.
-    bool textured = false;
-    for (int i = 0; i < numObjects; i++) textured = textured || objs[i].texLoc != -1;
 #define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
       if (envFeatures && textured) RM_LAUNCH(false, false, true, true);
@@ -441,8 +460,20 @@ int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, cons
   if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
   int n = rowEnd - rowBegin;
   RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  RmResources res{};
+  res.textures = textures; res.numTextures = numTextures;
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
-                       static_cast<hipStream_t>(stream), false, nullptr, textures, numTextures);
+                       static_cast<hipStream_t>(stream), false, nullptr, res);
+}
+
+int rm_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                  const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int rowBegin, int rowEnd,
+                  float *d_rgba, float *d_bright, void *stream) {
+  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
+  int n = rowEnd - rowBegin;
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
+                       static_cast<hipStream_t>(stream), false, nullptr, res ? *res : kNoResources);
 }
 
 int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -545,13 +576,13 @@ int rm_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, c
                      float *d_out, int n, void *stream) {
   std::lock_guard<std::mutex> lock(g_mu);
   RmCamera cam{};
-  int st = validate_scene(&cam, objs, numObjects, nullptr, 0, g, s);
+  int st = validate_scene(&cam, objs, numObjects, nullptr, 0, g, s, kNoResources);
   if (st != RM_OK) return st;
   if (!d_pts || !d_out || n < 0) { set_error("bad probe arguments"); return RM_ERR_INVALID_ARGUMENT; }
   if (n == 0) return RM_OK;
   Slot *slot;
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  st = stage_scene(&cam, objs, numObjects, nullptr, 0, g, s, hs, &slot);
+  st = stage_scene(&cam, objs, numObjects, nullptr, 0, g, s, hs, &slot, kNoResources);
   if (st != RM_OK) return st;
   hipLaunchKernelGGL(probe_sdscene_kernel, dim3((n + 255) / 256), dim3(256), 0, hs, slot->dev, d_pts, d_out, n);
   HIP_OK(hipGetLastError());

@@ -680,6 +680,7 @@ int rm_abi_sizeof(int which) {
     case 7: return (int)sizeof(RmCameraData);
     case 8: return (int)sizeof(RmTexture);
     case 9: return (int)sizeof(RmPostSettings);
+    case 10: return (int)sizeof(RmResources);
     default: return -1;
   }
 }

@@ -22,6 +22,10 @@ class SceneTables:
     num_lights: int
     globals_: abi.RmGlobals
     textures: list = None  # host uint8 arrays (H, W, 4), rows bottom-up, indexed by RmObject.texLoc
+    noise: object = None   # uint8 (H, W, 4): the `noise` sampler of NIGHTSKY_BACKGROUND / SEA (noise_texture_1.png, mirrored)
+    skybox: list = None    # six uint8 (H, W, 4) cube-map faces +X,-X,+Y,-Y,+Z,-Z as uploaded (mirrored at load)
+    ltc1: object = None    # uint8 (64, 64, 4) LTC tables of the area lights (ltc_quantise of the float tables)
+    ltc2: object = None
 
     def args(self, settings):
         return (C.byref(self.camera), self.objects, self.num_objects, self.lights, self.num_lights,
@@ -39,6 +43,16 @@ def load_image(path, flip_vertical=True):
     finally:
         lib().rm_image_free(px)
     return arr
+
+
+def ltc_quantise(table):
+    """Float RGBA table → the 8-bit texels the reference's glTexImage2D(GL_RGBA, …, GL_FLOAT, LTC) upload leaves
+    (realtimerender.cpp:908, 925)."""
+    import numpy as np
+    t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1, 4)
+    out = np.empty(t.shape, dtype=np.uint8)
+    lib().rm_ltc_quantise(C.c_void_p(t.ctypes.data), C.c_void_p(out.ctypes.data), t.shape[0])
+    return out.reshape(np.shape(table))
 
 
 def build_camera(pos, look, up, height_angle_rad, W, H, near=0.1, far=100.0):
@@ -138,24 +152,50 @@ class Renderer:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _textures(self, tables):
-        """Upload (once per array) the host textures of `tables`; returns (RmTexture array, count, keep-alive)."""
-        host = tables.textures or []
-        if not host:
-            return None, 0, None
+    def _upload(self, a):
+        """Host uint8 array → device tensor, cached per array object."""
         if not hasattr(self, "_tex_cache"):
             self._tex_cache = {}
-        arr = (abi.RmTexture * len(host))()
+        key = id(a)
+        if key not in self._tex_cache:
+            self._tex_cache[key] = (a, self.torch.from_numpy(a).contiguous().to(self.device))
+        return self._tex_cache[key][1]
+
+    def _resources(self, tables):
+        """RmResources with device pointers for everything `tables` carries; returns (struct, keep-alive list)."""
+        res = abi.RmResources()
         keep = []
-        for i, a in enumerate(host):
-            key = id(a)
-            if key not in self._tex_cache:
-                self._tex_cache[key] = (a, self.torch.from_numpy(a).contiguous().to(self.device))
-            dev = self._tex_cache[key][1]
+
+        def fill(slot, a):
+            dev = self._upload(a)
             keep.append(dev)
-            arr[i].pixels = dev.data_ptr()
-            arr[i].height, arr[i].width = a.shape[0], a.shape[1]
-        return arr, len(host), keep
+            slot.pixels = dev.data_ptr()
+            slot.height, slot.width = a.shape[0], a.shape[1]
+
+        host = tables.textures or []
+        if host:
+            arr = (abi.RmTexture * len(host))()
+            for i, a in enumerate(host):
+                fill(arr[i], a)
+            keep.append(arr)
+            res.textures = arr
+            res.numTextures = len(host)
+        if tables.noise is not None:
+            fill(res.noise, tables.noise)
+        if tables.skybox:
+            if len(tables.skybox) != 6:
+                raise ValueError("skybox needs six faces (+X,-X,+Y,-Y,+Z,-Z)")
+            for f in range(6):
+                fill(res.skybox[f], tables.skybox[f])
+        for name in ("ltc1", "ltc2"):
+            a = getattr(tables, name)
+            if a is not None:
+                if a.shape != (abi.RM_LTC_SIZE, abi.RM_LTC_SIZE, 4) or str(a.dtype) != "uint8":
+                    raise ValueError(f"{name} must be uint8 (64, 64, 4); see ltc_quantise")
+                dev = self._upload(a)
+                keep.append(dev)
+                setattr(res, name, dev.data_ptr())
+        return res, keep
 
     def render(self, tables, settings, W, H, row_begin=0, row_end=None, bright=False, out=None):
         """rm_render: rows [row_begin,row_end) → float32 tensor (rows, W, 4), row 0 = bottom."""
@@ -165,9 +205,9 @@ class Renderer:
         if out is None:
             out = t.empty((max(n, 0), W, 4), dtype=t.float32, device=self.device)
         br = t.empty_like(out) if bright else None
-        tex, ntex, _keep = self._textures(tables)
-        check(lib().rm_render_ex(*tables.args(settings), tex, ntex, W, H, row_begin, row_end, C.c_void_p(out.data_ptr()),
-                                 C.c_void_p(br.data_ptr()) if bright else None, self._stream()))
+        res, _keep = self._resources(tables)
+        check(lib().rm_render_res(*tables.args(settings), C.byref(res), W, H, row_begin, row_end, C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(br.data_ptr()) if bright else None, self._stream()))
         return (out, br) if bright else out
 
     def render_counted(self, tables, settings, W, H):

@@ -133,30 +133,63 @@ def scene_mandelbulb(W, H):
     return cam, objs, 1, lights, 3, make_globals()
 
 
-def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=False, counters=False, textures=None):
-    """textures: list of uint8 (H, W, 4) arrays, rows bottom-up, indexed by RmObject.texLoc."""
+def host_resources(textures=None, noise=None, skybox=None, ltc1=None, ltc2=None):
+    """RmResources over HOST arrays (for the oracle); returns (struct, keep-alive)."""
+    res = abi.RmResources()
+    keep = []
+
+    def fill(slot, a):
+        assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"] and a.shape[2] == 4
+        slot.pixels = a.ctypes.data
+        slot.height, slot.width = a.shape[0], a.shape[1]
+        keep.append(a)
+
+    if textures:
+        tex = (abi.RmTexture * len(textures))()
+        for i, a in enumerate(textures):
+            fill(tex[i], a)
+        res.textures = tex
+        res.numTextures = len(textures)
+        keep.append(tex)
+    if noise is not None:
+        fill(res.noise, noise)
+    if skybox:
+        for f in range(6):
+            fill(res.skybox[f], skybox[f])
+    for name, a in (("ltc1", ltc1), ("ltc2", ltc2)):
+        if a is not None:
+            assert a.dtype == np.uint8 and a.shape == (64, 64, 4) and a.flags["C_CONTIGUOUS"]
+            setattr(res, name, a.ctypes.data)
+            keep.append(a)
+    return res, keep
+
+
+def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=False, counters=False, textures=None,
+                  expect=0, **resources):
+    """textures: list of uint8 (H, W, 4) arrays, rows bottom-up, indexed by RmObject.texLoc; resources: noise=, skybox=,
+    ltc1=, ltc2= (see host_resources)."""
     cam, objs, no, lights, nl, g = scene[:6]
     row1 = H if row1 is None else row1
     out = np.zeros((row1 - row0, W, 4), dtype=np.float32)
     br = np.zeros_like(out) if bright else None
     cnt = abi.RmCounters()
-    tex, ntex = None, 0
-    if textures:
-        ntex = len(textures)
-        tex = (abi.RmTexture * ntex)()
-        for i, a in enumerate(textures):
-            assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"] and a.shape[2] == 4
-            tex[i].pixels = a.ctypes.data
-            tex[i].height, tex[i].width = a.shape[0], a.shape[1]
-    st = oracle().rmo_render_tex(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(settings), tex, ntex, W, H,
+    res, _keep = host_resources(textures=textures, **resources)
+    st = oracle().rmo_render_res(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(settings), C.byref(res), W, H,
                                  row0, row1, fptr(out), fptr(br) if bright else None, C.byref(cnt), threads)
-    assert st == 0, f"oracle status {st}"
+    assert st == expect, f"oracle status {st}"
     res = [out]
     if bright:
         res.append(br)
     if counters:
         res.append(cnt)
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def oracle_ltc_quantise(table):
+    t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1, 4)
+    out = np.empty(t.shape, dtype=np.uint8)
+    oracle().rmo_ltc_quantise(fptr(t), out.ctypes.data_as(C.c_void_p), t.shape[0])
+    return out.reshape(np.shape(table))
 
 
 def oracle_post(frag, bright, post):

@@ -429,6 +429,160 @@ def test_post_full_size_4k(renderer):
     assert torch.isfinite(c).all() and float(c[..., :3].max()) <= 1.0 and float(c[..., :3].min()) >= 0.0
 
 
+# ---------------------------------------------------------------- samplers beyond object textures: noise (night sky, sea),
+# sky box, LTC tables (area lights).  All inputs are synthetic — the ABI takes them as data.
+def synthetic_noise():
+    """256×256 RGBA8 with DIFFERENT channels (the reference's noise_texture_1.png is grey; distinct channels also
+    exercise noiseV's .yx swizzle).  A few texels are pushed to 255 so that stars (noise > 0.99) exist."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (256, 256, 4), dtype=np.uint8)
+    a[rng.integers(0, 256, 900), rng.integers(0, 256, 900), :2] = 255
+    a[..., 3] = 255
+    return np.ascontiguousarray(a)
+
+
+def synthetic_skybox(n=24):
+    """Six n×n RGBA8 faces, each a different two-colour gradient with a bright spot (bloom source)."""
+    yy, xx = np.mgrid[0:n, 0:n]
+    faces = []
+    for f in range(6):
+        c0 = np.array([(f * 40) % 256, (255 - f * 30) % 256, (f * 90 + 30) % 256])
+        c1 = np.array([(200 + f * 10) % 256, (f * 50) % 256, (120 + f * 20) % 256])
+        t = ((xx + (f + 1) * yy) / ((f + 2) * (n - 1.0)))[..., None]
+        img = c0 * (1 - t) + c1 * t
+        img[(xx - n // 3) ** 2 + (yy - n // 2) ** 2 < 6] = 255
+        faces.append(np.ascontiguousarray(np.concatenate([img, np.full((n, n, 1), 255)], -1).astype(np.uint8)))
+    return faces
+
+
+def synthetic_ltc():
+    """Smooth stand-ins for the LTC tables (float, 64×64×4; u = column): t1 ≈ the inverse-matrix parameters,
+    t2 = (fresnel scale, fresnel bias, unused, horizon-clipping form factor)."""
+    v, u = np.mgrid[0:64, 0:64] / 63.0
+    t1 = np.stack([0.55 + 0.45 * v, 0.25 * u * v, 0.15 * (1 - v), 0.5 + 0.5 * np.sqrt(v)], -1)
+    t2 = np.stack([0.9 - 0.5 * v, 0.1 + 0.3 * u, 0 * u, np.clip(0.35 + 0.65 * u + 0.1 * v, 0, 1.2)], -1)
+    return t1.astype(np.float32), t2.astype(np.float32)
+
+
+def night_scene(W, H):
+    cam = h.make_camera((1.6, 0.4, -5), (-0.42, 0.36, 1), (0, 1, 0), 60.0, W, H)  # looks toward MOON (frag:107)
+    objs = (abi.RmObject * 2)(
+        h.make_object(abi.RM_SPHERE, model=h.translate(-0.9, 0, 0) @ h.scale(1.5, 1.5, 1.5), scale_factor=1.5, ambient=(.1, .1, .15),
+                      diffuse=(.5, .5, .7), specular=(1, 1, 1), shininess=25, reflective=(.9, .9, .9)),
+        h.make_object(abi.RM_CUBE, model=h.translate(1.3, -0.2, 0.4) @ h.scale(1.1, 1.1, 1.1), scale_factor=1.1, ambient=(.1, .1, .1),
+                      diffuse=(.7, .4, .3), specular=(.5, .5, .5), shininess=10))
+    lights = (abi.RmLight * 1)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (.9, .9, 1), (0.4, -0.4, -0.3)))
+    return cam, objs, 2, lights, 1, h.make_globals(itime=1.3)
+
+
+def sea_scene(W, H):
+    cam = h.make_camera((0, 3.5, 6), (0, -0.35, -1), (0, 1, 0), 50.0, W, H, far=100.0)
+    objs = (abi.RmObject * 1)(
+        h.make_object(abi.RM_SPHERE, model=h.translate(0, 1.8, -1.5) @ h.scale(2, 2, 2), scale_factor=2.0, ambient=(.2, .2, .2),
+                      diffuse=(.8, .3, .2), specular=(1, 1, 1), shininess=20, reflective=(.6, .6, .6)))
+    lights = (abi.RmLight * 1)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.4, -1, -0.3)))
+    return cam, objs, 1, lights, 1, h.make_globals(itime=0.7)
+
+
+def area_light_scene(W, H):
+    """A floor, a sphere and a torus under one rectangular area light with its emissive rectangle
+    (RayMarchScene::initScene appends one per area light, raymarchscene.cpp:121-133) plus a point light."""
+    cam = h.make_camera((0, 1.6, 5.5), (0, -0.2, -1), (0, 1, 0), 45.0, W, H)
+    ctm = h.translate(0.3, 2.2, -1.0) @ rot_x(np.deg2rad(65.0)) @ h.scale(2.4, 1.4, 1.0)
+    rect = h.make_object(abi.RM_RECTANGLE, model=ctm, scale_factor=1.0)
+    rect.isEmissive, rect.lightIdx = 1, 0
+    rect.color[0], rect.color[1], rect.color[2] = 1.0, 0.9, 0.6
+    objs = (abi.RmObject * 4)(
+        h.make_object(abi.RM_CUBE, model=h.translate(0, -1.0, 0) @ h.scale(9, 0.4, 9), scale_factor=0.4, ambient=(.1, .1, .1),
+                      diffuse=(.7, .7, .7), specular=(.6, .6, .6), shininess=12, reflective=(.25, .25, .25)),
+        h.make_object(abi.RM_SPHERE, model=h.translate(-1.2, 0, 0.2) @ h.scale(1.5, 1.5, 1.5), scale_factor=1.5, ambient=(.1, .1, .1),
+                      diffuse=(.3, .5, .9), specular=(1, 1, 1), shininess=40),
+        h.make_object(abi.RM_TORUS, model=h.translate(1.4, -0.2, 0) @ h.scale(1.8, 1.8, 1.8), scale_factor=1.8, ambient=(.1, .1, .1),
+                      diffuse=(.9, .5, .2), specular=(.8, .8, .8), shininess=20),
+        rect)
+    area = h.make_light(abi.RM_LIGHT_AREA, (1.0, 0.9, 0.6), func=(1, 0, 0))
+    area.intensity, area.twoSided = 0.0, 1  # sceneparser.cpp:18-30 drops the parsed intensity; twoSided is always set
+    corners = [(-0.5, 0.5, 0), (0.5, 0.5, 0), (0.5, -0.5, 0), (-0.5, -0.5, 0)]  # realtime.h:136-141
+    for k, c in enumerate(corners):
+        w = ctm @ np.array([*c, 1.0])
+        for j in range(3):
+            area.points[k][j] = float(np.float32(w[j]))
+    lights = (abi.RmLight * 2)(area, h.make_light(abi.RM_LIGHT_POINT, (.5, .5, .6), pos=(-3, 3, 3), func=(0.8, 0.05, 0)))
+    return cam, objs, 4, lights, 2, h.make_globals()
+
+
+def rot_x(a):
+    M = np.eye(4)
+    M[1, 1], M[1, 2], M[2, 1], M[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    return M
+
+
+def resource_case(name, W, H):
+    """name → (scene, settings, resources dict) of the sampler-driven cases."""
+    WB = abi.RM_FEAT_WHITE_BACKGROUND
+    if name == "night_sky":
+        return night_scene(W, H), abi.default_settings(features=abi.RM_FEAT_NIGHTSKY_BACKGROUND, enableReflection=1), {"noise": synthetic_noise()}
+    if name == "sea_sky":
+        return sea_scene(W, H), abi.default_settings(features=abi.RM_FEAT_SEA | abi.RM_FEAT_SKY_BACKGROUND, enableReflection=1), \
+            {"noise": synthetic_noise()}
+    if name == "sea_terrain_cloud":
+        sc = sea_scene(W, H)
+        sc = (h.make_camera((0, 700, 6), (0, -0.2, -1), (0, 1, 0), 50.0, W, H),) + sc[1:]
+        return sc, abi.default_settings(features=ENV_ALL | abi.RM_FEAT_SEA), {"noise": synthetic_noise()}
+    if name == "sea_terrain":
+        sc = sea_scene(W, H)
+        sc = (h.make_camera((0, 700, 6), (0, -0.2, -1), (0, 1, 0), 50.0, W, H, far=2000.0),) + sc[1:]
+        return sc, abi.default_settings(features=abi.RM_FEAT_SKY_BACKGROUND | abi.RM_FEAT_TERRAIN | abi.RM_FEAT_SEA), {"noise": synthetic_noise()}
+    if name == "skybox_reflect":
+        return reflect_refract_scene(W, H), abi.default_settings(features=WB, enableSkyBox=1, enableReflection=1, enableRefraction=1), \
+            {"skybox": synthetic_skybox()}
+    if name == "area_light":
+        t1, t2 = synthetic_ltc()
+        return area_light_scene(W, H), abi.default_settings(features=WB, enableReflection=1), \
+            {"ltc1": h.oracle_ltc_quantise(t1), "ltc2": h.oracle_ltc_quantise(t2)}
+    if name == "area_light_soft_bump":
+        t1, t2 = synthetic_ltc()
+        return area_light_scene(W, H), abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1), \
+            {"ltc1": h.oracle_ltc_quantise(t1), "ltc2": h.oracle_ltc_quantise(t2)}
+    if name == "area_light_bump_ao":
+        t1, t2 = synthetic_ltc()
+        return area_light_scene(W, H), abi.default_settings(enableAmbientOcclusion=1), \
+            {"ltc1": h.oracle_ltc_quantise(t1), "ltc2": h.oracle_ltc_quantise(t2)}
+    raise KeyError(name)
+
+
+RESOURCE_CASES = ["night_sky", "sea_sky", "sea_terrain", "sea_terrain_cloud", "skybox_reflect", "area_light", "area_light_soft_bump",
+                  "area_light_bump_ao"]
+
+
+@pytest.mark.parametrize("name", RESOURCE_CASES)
+def test_resource_frames_bit_exact(renderer, name):
+    W, H = 96, 64
+    scene, s, res = resource_case(name, W, H)
+    ref, ref_b = h.oracle_render(scene, s, W, H, bright=True, **res)
+    t = tables_of(scene)
+    for k, v in res.items():
+        setattr(t, k, v)
+    out, br = renderer.render(t, s, W, H, bright=True)
+    assert_bit_equal(out.cpu().numpy(), ref, name)
+    assert_bit_equal(br.cpu().numpy(), ref_b, name + " bright")
+    assert np.isfinite(ref).all()
+
+
+def test_resource_errors(renderer):
+    """A feature whose sampler was not supplied is refused, on both sides, with RM_ERR_UNSUPPORTED."""
+    from raymarcher_amd import RaymarcherError
+    W, H = 16, 16
+    for name in ("night_sky", "sea_sky", "skybox_reflect", "area_light"):
+        scene, s, _res = resource_case(name, W, H)
+        with pytest.raises(RaymarcherError) as e:
+            renderer.render(tables_of(scene), s, W, H)
+        assert e.value.status == abi.RM_ERR_UNSUPPORTED, name
+        h.oracle_render(scene, s, W, H, expect=abi.RM_ERR_UNSUPPORTED)
+    assert (renderer.torch.from_numpy(h.oracle_ltc_quantise(synthetic_ltc()[0])).numpy() ==
+            __import__("raymarcher_amd").render.ltc_quantise(synthetic_ltc()[0])).all()
+
+
 # ---------------------------------------------------------------- edge cases of the boundary
 def test_row_ranges_and_ragged_sizes(renderer):
     W, H = 37, 29  # not multiples of the 8×8 wave tile

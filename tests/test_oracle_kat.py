@@ -267,3 +267,49 @@ def test_invalid_inputs_are_rejected():
     assert st == abi.RM_ERR_CAPACITY
     st = h.oracle().rmo_render(C.byref(cam), objs, no, lights, nl, C.byref(g), C.byref(s), W, Hh, 4, 12, h.fptr(out), None, None, 1)
     assert st == abi.RM_ERR_INVALID_ARGUMENT
+
+
+def test_sea_height_matches_an_independent_float64_model():
+    """seaMap (frag:2195-2217) restated in vectorised float64 numpy, with the hash argument rounded to binary32 as GLSL
+    does: the oracle must agree point by point up to its binary32 arithmetic (the residual comes from hash values that
+    sit next to a fract() wrap)."""
+    import ctypes as C
+    f32 = np.float32
+
+    def hash2(x, y):
+        a = (x.astype(f32) * f32(12.9898) + y.astype(f32) * f32(78.233)).astype(np.float64)
+        v = np.sin(a) * 43758.5453
+        return v - np.floor(v)
+
+    def noise_w(px, py):
+        ix, iy = np.floor(px), np.floor(py)
+        fx, fy = px - ix, py - iy
+        ux, uy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+        a, b, c, d = hash2(ix, iy), hash2(ix + 1, iy), hash2(ix, iy + 1), hash2(ix + 1, iy + 1)
+        return 2 * ((a * (1 - ux) + b * ux) * (1 - uy) + (c * (1 - ux) + d * ux) * uy) - 1
+
+    def sea_octave(ux, uy, choppy):
+        n = noise_w(ux, uy)
+        ux, uy = ux + n, uy + n
+        wx, wy = 1 - np.abs(np.sin(ux)), 1 - np.abs(np.sin(uy))
+        wx, wy = wx * (1 - wx) + np.abs(np.cos(ux)) * wx, wy * (1 - wy) + np.abs(np.cos(uy)) * wy
+        return (1 - (wx * wy) ** 0.65) ** choppy
+
+    def sea_map(p, iters, itime):
+        st, freq, amp, ch = 1 + itime * 0.5, 0.16, 0.2, 1.0
+        ux, uy, hh = p[:, 0].copy(), p[:, 2].copy(), 0.0
+        for _ in range(iters):
+            hh = hh + (sea_octave((ux + st) * freq, (uy + st) * freq, ch) + sea_octave((ux - st) * freq, (uy - st) * freq, ch)) * amp
+            ux, uy = ux * 1.6 + uy * 1.2, ux * -1.2 + uy * 1.6
+            freq, amp, ch = freq * 2, amp * 0.2, ch * 0.8 + 0.2
+        return p[:, 1] - hh
+
+    rng = np.random.default_rng(8)
+    pts = np.ascontiguousarray(rng.uniform(-40, 40, (3000, 3)).astype(np.float32))
+    out = np.zeros((len(pts), 4), np.float32)
+    for itime in (0.0, 2.3):
+        assert h.oracle().rmo_probe_env2(3, C.c_float(itime), None, h.fptr(pts), h.fptr(out), len(pts)) == 0
+        for k, iters in ((0, 3), (1, 5)):
+            d = np.abs(sea_map(pts.astype(np.float64), iters, itime) - out[:, k])
+            # a binary32 hash has a granularity of ulp(43758) = 0.004, hence the floor on the agreement
+            assert np.median(d) < 4e-3 and d.mean() < 1e-2, (itime, iters, np.median(d), d.mean())
