@@ -146,8 +146,8 @@ def main():
         _, cnt = r.render_counted(tables, settings, W, H)
     if rank == 0:
         path = int(os.environ.get("RM_KERNEL_PATH", "0"))
-        kernel_name = {0: "rm::render_kernel<true,false> (one lane per pixel, 8x8 tile per wave)",
-                       1: "rm::render_kernel<true,false> (one lane per pixel, 8x8 tile per wave)",
+        kernel_name = {0: "rm::render_kernel<BULB=true,COUNT=false,ENV=false,TEX=false> (one lane per pixel, 8x8 tile per wave)",
+                       1: "rm::render_kernel<BULB=true,COUNT=false,ENV=false,TEX=false> (one lane per pixel, 8x8 tile per wave)",
                        2: "pipeline A: bulb_primary+surface+shadow+shade kernels (state machines + lane refill)",
                        3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)",
                        4: "pipeline C: pipeline B with step-budgeted march passes and re-compaction"}[path]

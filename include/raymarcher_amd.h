@@ -85,7 +85,7 @@ typedef struct RmObject {
   int32_t texLoc;        /* -1 = untextured (only value accepted in this ABI version) */
   float repeatU;
   float repeatV;
-  int32_t isEmissive;    /* area-light rectangle (must be 0 in this ABI version) */
+  int32_t isEmissive;    /* the rectangle drawn for an area light (raymarchscene.cpp:121-133): rendered as `color` */
   float color[3];
   int32_t lightIdx;
 } RmObject;
@@ -327,7 +327,7 @@ const RmObject *rm_scene_objects(const RmScene *scene);
 const RmLight *rm_scene_lights(const RmScene *scene);
 int rm_scene_globals(const RmScene *scene, const RmHostSettings *hs, RmGlobals *out);
 int rm_scene_camera_data(const RmScene *scene, RmCameraData *out);
-/* Texture file referenced by object i, or NULL (kept for callers; textures are not rendered yet). */
+/* Texture file referenced by object i, or NULL; load it with rm_image_load(path, 1, …) into RmResources.textures[texLoc]. */
 const char *rm_scene_object_texture(const RmScene *scene, int i);
 
 /* Image file → RGBA8 (stands in for QImage::load + convertToFormat(RGBA8888) + mirrored(), raymarchscene.cpp:198-209).
