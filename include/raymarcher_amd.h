@@ -54,7 +54,13 @@ enum {
   RM_FEAT_CLOUD = 1u << 4,               /* frag:12 */
   RM_FEAT_TERRAIN = 1u << 5,             /* frag:13 */
   RM_FEAT_SEA = 1u << 6,                 /* frag:14 (samples RmResources.noise) */
-  RM_FEAT_PERLIN_BUMP = 1u << 7          /* frag:15 */
+  RM_FEAT_PERLIN_BUMP = 1u << 7,         /* frag:15 */
+  /* Not a reference #define — an opt-in evaluation scheme.  When set and power == 8 exactly, the Mandelbulb step
+   * w ← c + r^8·(sin 8θ sin 8φ, cos 8θ, sin 8θ cos 8φ) (frag:789-793) is evaluated by three complex squarings of
+   * (y + iρ) and of (z + ix)/ρ, ρ = |w.xz|, instead of acos/atan/sin/cos/pow, and m^3.5 as m³·√m: the same function
+   * (angle-multiplication identities), different rounding (≈1e-6 relative per step), ≈3.5× fewer instructions.
+   * Oracle and kernels implement it identically, so CPU/GPU parity stays bit-exact.  Any other power ignores the bit. */
+  RM_FEAT_BULB_POWER8_ALGEBRAIC = 1u << 8
 };
 /* The checked-in shader's state: WHITE_BACKGROUND + PERLIN_BUMP (frag:9,15). */
 #define RM_FEAT_REFERENCE_DEFAULT (RM_FEAT_WHITE_BACKGROUND | RM_FEAT_PERLIN_BUMP)

@@ -197,6 +197,34 @@ static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
   /* frag:782-784 */
   if (len2(c->g.juliaSeed[0], c->g.juliaSeed[1]) != 0.0f) cc = V3(c->g.juliaSeed[0], c->g.juliaSeed[1], 0.0f);
   const float pexp = (power - 1.0f) / 2.0f;
+  if ((c->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) && power == 8.0f) {
+    /* Opt-in evaluation scheme of the same step (see RM_FEAT_BULB_POWER8_ALGEBRAIC): with θ = acos(y/r), φ = atan(x, z),
+     * ρ = |w.xz|:  (y + iρ)^8 = r^8·(cos 8θ + i sin 8θ),  ((z + ix)/ρ)^8 = cos 8φ + i sin 8φ;  m^3.5 = m³·√m. */
+    for (int i = 0; i < c->s.fractalIters; i++) {
+      c->nIter++;
+      float r = rm_sqrt(m);
+      dz = rm_fma(8.0f * (((m * m) * m) * r), dz, 1.0f);
+      float rho = rm_sqrt(dot2(w.x, w.z, w.x, w.z));
+      float inv = 1.0f / rho;
+      float cz = (rho == 0.0f) ? 1.0f : w.z * inv, sx = (rho == 0.0f) ? 0.0f : w.x * inv; /* atan(0,0) = 0 in the contract */
+      float re = w.y, im = rho;
+      for (int k = 0; k < 3; k++) {
+        float t = rm_fma(re, re, -(im * im));
+        im = 2.0f * (re * im);
+        re = t;
+        t = rm_fma(cz, cz, -(sx * sx));
+        sx = 2.0f * (cz * sx);
+        cz = t;
+      }
+      w = V3(rm_fma(im, sx, cc.x), re + cc.y, rm_fma(im, cz, cc.z));
+      trap = V4(rm_min(trap.x, rm_abs(w.x)), rm_min(trap.y, rm_abs(w.y)), rm_min(trap.z, rm_abs(w.z)),
+                rm_min(trap.w, m));
+      m = dot3(w, w);
+      if (m > 2.0f) break;
+    }
+    *resColor = V4(m, trap.y, trap.z, trap.w);
+    return ((0.25f * rm_log(m)) * rm_sqrt(m)) / dz;
+  }
   for (int i = 0; i < c->s.fractalIters; i++) {
     c->nIter++;
     /* frag:787 */

@@ -27,6 +27,7 @@ RM_FEAT_CLOUD = 1 << 4
 RM_FEAT_TERRAIN = 1 << 5
 RM_FEAT_SEA = 1 << 6
 RM_FEAT_PERLIN_BUMP = 1 << 7
+RM_FEAT_BULB_POWER8_ALGEBRAIC = 1 << 8  # opt-in evaluation scheme, see include/raymarcher_amd.h
 RM_FEAT_REFERENCE_DEFAULT = RM_FEAT_WHITE_BACKGROUND | RM_FEAT_PERLIN_BUMP
 
 RM_OK, RM_ERR_INVALID_ARGUMENT, RM_ERR_CAPACITY, RM_ERR_UNSUPPORTED, RM_ERR_DEVICE, RM_ERR_IO, RM_ERR_PARSE = range(7)

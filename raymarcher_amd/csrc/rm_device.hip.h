@@ -154,6 +154,34 @@ RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &
   V4 trap = v4(fabs_(w.x), fabs_(w.y), fabs_(w.z), m);
   float dz = 1.0f;
   V3 c = julia ? v3(sb->g.juliaSeed[0], sb->g.juliaSeed[1], 0.0f) : pos;
+  if ((sb->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) && power == 8.0f) {  // wave-uniform
+    // Opt-in evaluation scheme of the same step: (y + iρ)^8 = r^8·(cos 8θ + i sin 8θ), ((z + ix)/ρ)^8 = cos 8φ + i sin 8φ
+    // by three complex squarings each, m^3.5 = m³·√m — no acos/atan/sin/cos/pow in the loop.
+    for (int i = 0; i < iters; i++) {
+      if (COUNT) cnt.iters++;
+      float r = sqrt_fast_(m);
+      dz = fma(8.0f * (((m * m) * m) * r), dz, 1.0f);
+      float rho = sqrt_fast_(dot2(w.x, w.z, w.x, w.z));
+      float inv = 1.0f / rho;
+      float cz = (rho == 0.0f) ? 1.0f : w.z * inv, sx = (rho == 0.0f) ? 0.0f : w.x * inv;
+      float re = w.y, im = rho;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float t = fma(re, re, -(im * im));
+        im = 2.0f * (re * im);
+        re = t;
+        t = fma(cz, cz, -(sx * sx));
+        sx = 2.0f * (cz * sx);
+        cz = t;
+      }
+      w = v3(fma(im, sx, c.x), re + c.y, fma(im, cz, c.z));
+      trap = v4(min_(trap.x, fabs_(w.x)), min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
+      m = dot(w, w);
+      if (m > 2.0f) break;
+    }
+    resColor = v4(m, trap.y, trap.z, trap.w);
+    return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;
+  }
   for (int i = 0; i < iters; i++) {
     if (COUNT) cnt.iters++;
     dz = fma(power * pow_(m, pexp), dz, 1.0f);  // frag:787

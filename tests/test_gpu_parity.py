@@ -145,6 +145,35 @@ def test_sdscene_bit_exact_all_primitives(renderer):
     assert len(np.unique(ref[:, 1])) >= 10  # the points really exercise most object types
 
 
+def test_sdscene_algebraic_power8(renderer):
+    """RM_FEAT_BULB_POWER8_ALGEBRAIC: bit-exact CPU↔GPU like everything else, within 5e-5 of the trigonometric
+    formulation on ≥ 99.5 % of points (the rest sit on a bailout boundary), and ignored for any other power."""
+    import torch
+    rng = np.random.default_rng(12)
+    pts = np.ascontiguousarray(rng.normal(0, 0.8, (60000, 3)).astype(np.float32))
+    pts[:64, 0] = 0.0
+    pts[:64, 2] = 0.0  # the ρ = 0 axis (atan(0,0) branch)
+    alg = abi.default_settings(features=abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC)
+    trig = abi.default_settings()
+
+    def both(scene, s):
+        cam, objs, no, lights, nl, g = scene
+        ref = np.empty((len(pts), 4), dtype=np.float32)
+        assert h.oracle().rmo_probe_sdscene(objs, no, C.byref(g), C.byref(s), h.fptr(pts), h.fptr(ref), len(pts)) == 0
+        got = renderer.probe_sdscene(tables_of(scene), s, torch.from_numpy(pts).cuda()).cpu().numpy()
+        assert_bit_equal(got, ref, "sdScene")
+        return ref
+
+    bulb = h.scene_mandelbulb(8, 8)
+    a, t = both(bulb, alg), both(bulb, trig)
+    assert np.isfinite(a[:, 0]).all()
+    d = np.abs(a[:, 0] - t[:, 0])
+    assert np.median(d) < 5e-7 and (d < 5e-5).mean() > 0.995
+    assert (a != t).any()
+    p6 = bulb[:5] + (h.make_globals(power=6.0),)
+    assert_bit_equal(both(p6, alg), both(p6, trig), "the bit is ignored unless power == 8")
+
+
 def env_scene(W, H, pos=(0, 500, 5), look=(0.3, 0.12, -1)):
     """Terrain + volumetric cloud + sky (the shader's TERRAIN / CLOUD / SKY_BACKGROUND defines), with a reflective
     torus floating in front of the camera so secondary rays also see the layers (frag:2506-2518)."""
@@ -168,6 +197,11 @@ FRAME_CASES = {
     "bulb_reference_consts": (lambda W, H: h.scene_mandelbulb(W, H), {}, 96, 54),
     "bulb_bench_consts_12iters": (lambda W, H: h.scene_mandelbulb(W, H), {"fractalIters": 12}, 96, 54),
     "bulb_softshadow_ao": (lambda W, H: h.scene_mandelbulb(W, H), {"enableSoftShadow": 1, "enableAmbientOcclusion": 1}, 64, 36),
+    "bulb_algebraic_power8": (lambda W, H: h.scene_mandelbulb(W, H),
+                              {"fractalIters": 12, "features": abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC}, 96, 54),
+    "bulb_algebraic_julia_soft_ao": (lambda W, H: h.scene_mandelbulb(W, H)[:5] + (h.make_globals(julia=(0.35, -0.2)),),
+                                     {"enableSoftShadow": 1, "enableAmbientOcclusion": 1,
+                                      "features": abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC}, 64, 36),
     "primitives_phong": (lambda W, H: all_primitives_scene(W, H), {"maxSteps": 64}, 96, 64),
     "primitives_softshadow_ao_nobump": (lambda W, H: all_primitives_scene(W, H),
                                         {"enableSoftShadow": 1, "enableAmbientOcclusion": 1,
