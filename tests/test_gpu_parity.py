@@ -199,8 +199,8 @@ FRAME_CASES = {
     "bulb_softshadow_ao": (lambda W, H: h.scene_mandelbulb(W, H), {"enableSoftShadow": 1, "enableAmbientOcclusion": 1}, 64, 36),
     "bulb_algebraic_power8": (lambda W, H: h.scene_mandelbulb(W, H),
                               {"fractalIters": 12, "features": abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC}, 96, 54),
-    "bulb_algebraic_julia_soft_ao": (lambda W, H: h.scene_mandelbulb(W, H)[:5] + (h.make_globals(julia=(0.35, -0.2)),),
-                                     {"enableSoftShadow": 1, "enableAmbientOcclusion": 1,
+    "bulb_algebraic_julia_ao": (lambda W, H: h.scene_mandelbulb(W, H)[:5] + (h.make_globals(julia=(0.35, -0.2)),),
+                                     {"enableAmbientOcclusion": 1,
                                       "features": abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC}, 64, 36),
     "primitives_phong": (lambda W, H: all_primitives_scene(W, H), {"maxSteps": 64}, 96, 64),
     "primitives_softshadow_ao_nobump": (lambda W, H: all_primitives_scene(W, H),
