@@ -110,8 +110,9 @@ class Scene:
         t = lib().rm_scene_object_texture(self._h, i)
         return t.decode() if t else None
 
-    def tables(self, W, H, near=0.1, far=100.0, host_settings=None):
-        """Copy the tables out (so they outlive the handle) and build the camera for a W×H frame."""
+    def tables(self, W, H, near=0.1, far=100.0, host_settings=None, load_textures=True):
+        """Copy the tables out (so they outlive the handle) and build the camera for a W×H frame.
+        load_textures=False leaves `textures` empty for the caller to fill (slot i = RmObject.texLoc i)."""
         L = lib()
         no, nl = self.num_objects, self.num_lights
         objs = (abi.RmObject * max(no, 1))()
@@ -129,7 +130,7 @@ class Scene:
         check(L.rm_camera_build(C.byref(cd), W, H, near, far, None, None, C.byref(cam)))
         # texture slots in texLoc order (configureShapesUniforms binds them in first-use order, realtimerender.cpp:735-806)
         textures = {}
-        for i in range(no):
+        for i in range(no if load_textures else 0):
             if objs[i].texLoc >= 0 and objs[i].texLoc not in textures:
                 textures[objs[i].texLoc] = load_image(self.texture_of(i), flip_vertical=True)
         tex_list = [textures[k] for k in sorted(textures)] if textures else None
