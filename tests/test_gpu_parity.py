@@ -752,7 +752,7 @@ def test_config1_unit_sphere_256(renderer):
     s = abi.default_settings(maxSteps=64)
     ref = h.oracle_render(_scene_tuple(t), s, W, H, textures=t.textures)
     assert_bit_equal(renderer.render(t, s, W, H).cpu().numpy(), ref, "unit_sphere 256²")
-    assert 0.3 < (ref[..., :3] != 1.0).any(-1).mean() < 0.95
+    assert ref[..., :3].std() > 0.05 and np.isfinite(ref).all()  # the floor fills the view behind the sphere
 
 
 def test_config2_lighting_1080p_softshadow_ao(renderer):
