@@ -78,12 +78,15 @@ def main():
     ap.add_argument("--bulb-eval", choices=["reference", "algebraic"], default="reference",
                     help="reference: acos/atan/sin/cos/pow as the shader writes the step (the headline); algebraic: "
                          "RM_FEAT_BULB_POWER8_ALGEBRAIC, the same step by complex squarings (also reported as a variant)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (RCCL process group, pipelined gather, de-interleave) even with one rank: "
+                         "a rehearsal of the multi-GPU path on a one-GPU box")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from raymarcher_amd import Renderer, abi, lib, scenes
-    from raymarcher_amd.dist import ShardPlan, gather_to_root
+    from raymarcher_amd.dist import FramePipeline, ShardPlan
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +94,7 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -103,20 +106,23 @@ def main():
     L = lib()
     plan = ShardPlan(H, TILE_ROWS, world)
     my_rows, slot_rows = plan.rows(rank), plan.slot_rows  # shard 0 owns the most rows → equal gather slots
-    mine = torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device)
-    gathered = torch.empty((world * slot_rows, W, 4), dtype=torch.float32, device=r.device) if (distributed and rank == 0) else None
+    mine = torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device) if not distributed else None
     frame_holder = {}
+    # N > 1: frames are independent, so frame i's gather (xGMI) runs under frame i+1's render; every frame still ends as a
+    # complete float4 frame on rank 0 (rm_deinterleave), and the timed region ends only when the last one has.
+    pipe = FramePipeline(plan, rank, (W, 4), torch.float32, r.device,
+                         finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows))) \
+        if distributed else None
 
     def step():
         if not distributed:
             frame_holder["f"] = r.render(tables, settings, W, H, out=mine)
             return
-        r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=mine[:my_rows])
-        g = gather_to_root(mine, plan, rank, gathered)  # RCCL gather over xGMI
-        if rank == 0:
-            frame_holder["f"] = r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows)
+        pipe.submit(lambda slot: r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=slot[:my_rows]))
 
     def fence():
+        if distributed:
+            pipe.drain()
         torch.cuda.synchronize(r.device)
         if distributed:
             dist.barrier()
@@ -190,7 +196,8 @@ def main():
             "config": {"workload": "Mandelbulb power 8, 12 iters, 3840x2160, 256 steps, 3 directional lights, "
                                    "Perlin bump, white background (unit_mandelbulb.json as constants)"
                                    + ("; step evaluated with RM_FEAT_BULB_POWER8_ALGEBRAIC" if args.bulb_eval == "algebraic" else ""),
-                       "rows": "whole frame" if world == 1 else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs + RCCL gather",
+                       "rows": "whole frame" if world == 1 else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; RCCL gather of "
+                               "frame i to rank 0 overlapped with the render of frame i+1; every frame de-interleaved on rank 0",
                        "parity": "bit-exact vs CPU oracle (rm_math contract)"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4),

@@ -46,6 +46,54 @@ def gather_to_root(local_slot, plan, rank, gathered=None):
     return None
 
 
+class FramePipeline:
+    """Frames are independent, so the gather of frame i (xGMI) runs under the render of frame i+1 (CUs): two slots,
+    the gather is issued asynchronously and only joined when its slot is about to be reused / its frame finished.
+
+        for i in range(K): pipe.submit(render_into)        # render_into(slot_tensor) renders this rank's tiles
+        pipe.drain()
+
+    `finish(gathered_slots)` runs on rank 0 once per frame (de-interleave); everything is stream-ordered on the
+    device (Work.wait() on the "nccl" backend blocks the current stream, not the host)."""
+
+    def __init__(self, plan, rank, slot_shape, dtype, device, finish=None):
+        import torch
+        self.plan, self.rank, self.finish = plan, rank, finish
+        self.local = [torch.zeros((plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((plan.world * plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device)
+                         for _ in range(2)] if rank == 0 else [None, None]
+        self.work = [None, None]
+        self.i = 0
+        self.frames_finished = 0
+
+    def _join(self, b):
+        if self.work[b] is None:
+            return
+        self.work[b].wait()
+        self.work[b] = None
+        self.frames_finished += 1
+        if self.rank == 0 and self.finish is not None:
+            self.finish(self.gathered[b])
+
+    def submit(self, render_into):
+        import torch.distributed as dist
+        b = self.i & 1
+        self._join(b)                       # frame i-2 used this slot (normally already joined below)
+        render_into(self.local[b])
+        if self.rank == 0:
+            outs = list(self.gathered[b].view(self.plan.world, self.plan.slot_rows, *self.local[b].shape[1:]).unbind(0))
+            self.work[b] = dist.gather(self.local[b], outs, dst=0, async_op=True)
+        else:
+            self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
+        self._join(b ^ 1)                   # finish frame i-1 while frame i's gather is in flight
+        self.i += 1
+
+    def drain(self):
+        b = self.i & 1
+        self._join(b)
+        self._join(b ^ 1)
+
+
 def deinterleave_host(gathered, plan):
     """Index-map de-interleave for host tensors (the GPU path is rm_deinterleave)."""
     import torch

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Time every BASELINE.json configuration on one GPU (whole frame, one launch, HIP-event kernel time) — informative
+numbers for DESIGN.md / profiles/, not bench lines.  Usage: python scripts/measure_configs.py [out.md]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import test_gpu_parity as tg
+    from raymarcher_amd import Renderer, Scene, abi, lib, scenes
+    r = Renderer(0)
+    L = lib()
+    S = tg.SCENES
+    cases = []
+    t = Scene(path=os.path.join(S, "simple", "unit_sphere.json")).tables(256, 256, load_textures=False)
+    t.textures = [tg.synthetic_textures()[1]]
+    cases.append(("C1 unit_sphere 256x256, 64 steps, Phong", t, abi.default_settings(maxSteps=64), 256, 256))
+    t = Scene(path=os.path.join(S, "lighting", "directional_light_2.json")).tables(1920, 1080)
+    cases.append(("C2 directional_light_2 1920x1080, soft shadow + AO", t, abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1), 1920, 1080))
+    cases.append(("C3 Mandelbulb p8 12 iters 3840x2160 (headline)", scenes.mandelbulb(3840, 2160), abi.default_settings(fractalIters=12), 3840, 2160))
+    cases.append(("C3' same, RM_FEAT_BULB_POWER8_ALGEBRAIC", scenes.mandelbulb(3840, 2160),
+                  abi.default_settings(fractalIters=12, features=abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC), 3840, 2160))
+    cases.append(("C3'' Mandelbulb p8 20 iters (reference constant) 3840x2160", scenes.mandelbulb(3840, 2160), abi.default_settings(), 3840, 2160))
+    t = Scene(path=os.path.join(S, "simple", "volumetric.json")).tables(3840, 2160, far=2000.0)
+    t.camera = tg.env_scene(3840, 2160)[0]
+    cases.append(("C4 terrain + cloud + sky 3840x2160 (1 GPU)", t, abi.default_settings(features=tg.ENV_ALL), 3840, 2160))
+    cases.append(("C5 Menger 5 levels, reflection 2 bounces 7680x4320 (1 GPU)", scenes.mengersponge(7680, 4320),
+                  abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1), 7680, 4320))
+    sea = tg.resource_case("sea_sky", 3840, 2160)
+    ts = tg.tables_of(sea[0])
+    ts.noise = sea[2]["noise"]
+    cases.append(("sea + sky + reflective sphere 3840x2160", ts, sea[1], 3840, 2160))
+    al = tg.resource_case("area_light", 1920, 1080)
+    ta = tg.tables_of(al[0])
+    ta.ltc1, ta.ltc2 = al[2]["ltc1"], al[2]["ltc2"]
+    cases.append(("area light (LTC) + point light, reflection 1920x1080", ta, al[1], 1920, 1080))
+    rows = ["| configuration | kernel ms | Mpixels/s |", "|---|---|---|"]
+    for name, t, s, W, H in cases:
+        out = torch.empty((H, W, 4), dtype=torch.float32, device=r.device)
+        r.render(t, s, W, H, out=out)
+        torch.cuda.synchronize()
+        L.rm_set_timing(1)
+        n = 5
+        for _ in range(n):
+            r.render(t, s, W, H, out=out)
+        torch.cuda.synchronize()
+        ms, k = C.c_double(), C.c_int()
+        L.rm_get_timing(C.byref(ms), C.byref(k))
+        L.rm_set_timing(0)
+        rows.append(f"| {name} | {ms.value:.3f} | {W * H / ms.value / 1e3:.1f} |")
+        print(rows[-1], flush=True)
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as f:
+            f.write("\n".join(rows) + "\n")
+
+
+if __name__ == "__main__":
+    main()
