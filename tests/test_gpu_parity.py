@@ -817,3 +817,44 @@ def test_config5_menger_8k_reflection(renderer):
         assert_bit_equal(full[r0:r0 + 8].cpu().numpy(), ref, f"8K rows {r0}..{r0 + 8}")
     hit = float((full[..., :3] != 1.0).any(-1).float().mean())
     assert 0.1 < hit < 0.9
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from raymarcher_amd import Renderer, abi, scenes
+from raymarcher_amd.dist import FramePipeline, ShardPlan
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+r = Renderer(0)
+W, H, T = 320, 180, 8
+plan = ShardPlan(H, T, 1)
+frames = []
+pipe = FramePipeline(plan, 0, (W, 4), torch.float32, r.device,
+                     finish=lambda g: frames.append(r.deinterleave(g, W, H, T, 1, plan.slot_rows).clone()))
+want = []
+for k in range(4):
+    t = scenes.mandelbulb(W, H)
+    t.globals_.power = 8.0 - k                      # a different image per frame
+    s = abi.default_settings(fractalIters=12)
+    want.append(r.render(t, s, W, H).clone())
+    pipe.submit(lambda slot, t=t, s=s: r.render_tiles(t, s, W, H, T, 0, 1, out=slot[:plan.rows(0)]))
+pipe.drain()
+torch.cuda.synchronize()
+ok = len(frames) == 4 and all(bool((a.view(dtype=torch.int32) == b.view(dtype=torch.int32)).all()) for a, b in zip(frames, want))
+ok = ok and not bool((want[0] == want[1]).all())
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_frame_pipeline_over_rccl_single_rank(renderer, tmp_path):
+    """The N > 1 machinery of bench.py (RCCL process group, asynchronous gather into slot views, stream-ordered join,
+    rm_deinterleave) with one rank on this GPU, in a child process: every pipelined frame equals the direct render."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
