@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--bulb-eval", choices=["reference", "algebraic"], default="reference",
                     help="reference: acos/atan/sin/cos/pow as the shader writes the step (the headline); algebraic: "
                          "RM_FEAT_BULB_POWER8_ALGEBRAIC, the same step by complex squarings (also reported as a variant)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timing of the algebraic variant (profiling runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (RCCL process group, pipelined gather, de-interleave) even with one rank: "
                          "a rehearsal of the multi-GPU path on a one-GPU box")
@@ -152,7 +153,7 @@ def main():
 
     # the opt-in evaluation scheme of the same step, timed beside the headline (single GPU only; never `value`)
     variant = None
-    if not distributed and args.bulb_eval == "reference":
+    if not distributed and args.bulb_eval == "reference" and not args.no_variants:
         vs = abi.default_settings(fractalIters=FRACTAL_ITERS, features=feats | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC)
         r.render(tables, vs, W, H, out=mine)
         fence()
