@@ -193,7 +193,24 @@ RM_DEV float exp2_(float x) {
   r = (x >= 128.0f) ? __builtin_inff() : r;
   return (x > -125.0f) ? r : 0.0f;
 }
-RM_DEV float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+// pow(x, y): integer and half-integer exponents with |y| <= 128 by binary exponentiation (·sqrt(x) for the half,
+// reciprocal for y < 0), everything else exp2(y·log2(x)) — the contract of DESIGN.md §3.  The
+// exponents on the hot path (power, (power−1)/2, shininess) are wave-uniform: the loop is scalar-controlled and the
+// classification of y is loop-invariant in the Mandelbulb iteration.
+RM_DEV float pow_(float x, float y) {
+  float ay = fabs_(y), two = ay + ay;
+  if (two <= 256.0f && two == floor_(two)) {
+    int n = (int)ay;
+    float p = 1.0f, b = x;
+    for (int e = n; e != 0; e >>= 1) {
+      if (e & 1) p = p * b;
+      if (e > 1) b = b * b;
+    }
+    if (ay != (float)n) p = p * sqrt_fast_(x);
+    return (y < 0.0f) ? 1.0f / p : p;
+  }
+  return exp2_(y * log2_(x));
+}
 constexpr float kLn2 = 0.693147182f;   // 0x3f317218
 constexpr float kLog2e = 1.44269502f;  // 0x3fb8aa3b
 RM_DEV float log_(float x) { return log2_(x) * kLn2; }

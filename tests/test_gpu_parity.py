@@ -58,8 +58,13 @@ def _math_inputs(fn, n, rng):
                             [0, -125, -125.00001, -124.99999, 127.5, 127.99999, 128, 1e30, -1e30, np.inf, -np.inf, np.nan, 0.5, -0.5, 1.5, 2.5]])
         return x.astype(f), None
     if fn == abi.RM_FN_POW:
-        x = np.concatenate([np.exp(rng.uniform(-5, 5, n)), [0, 0, 0, 1, 2, -1, np.inf, 0.9, 1e-40]])
-        y = np.concatenate([rng.uniform(-20, 100, n), [0, 1, -1, 5, 0.5, 2, 2, 1e5, 2]])
+        # a third of the exponents are integers or half-integers (binary-exponentiation branch, |y| <= 128 and beyond),
+        # with negative and zero bases among them
+        k = n // 3
+        yi = rng.integers(-300, 301, k) / 2.0
+        xi = np.where(rng.uniform(size=k) < 0.2, -1.0, 1.0) * np.exp(rng.uniform(-1.5, 1.5, k))
+        x = np.concatenate([np.exp(rng.uniform(-5, 5, n - k)), xi, [0, 0, 0, 1, 2, -1, np.inf, 0.9, 1e-40, 0, 0, -2, -2, 3, 3, 1.5, np.nan, 2]])
+        y = np.concatenate([rng.uniform(-20, 100, n - k), yi, [0, 1, -1, 5, 0.5, 2, 2, 1e5, 2, -0.0, 3.5, 3, -3, 128, 128.5, -127.5, 0, np.nan]])
         return x.astype(f), y.astype(f)
     if fn == abi.RM_FN_Q16:
         x = np.concatenate([rng.normal(0, 1, n) * np.exp(rng.uniform(-25, 12, n)),

@@ -92,6 +92,16 @@ def test_log2_exp2_pow_accuracy():
     gp = probe(abi.RM_FN_POW, b, p)
     ep = np.power(b.astype(np.float64), p.astype(np.float64))
     assert (np.abs(gp - ep) / ep).max() < 3e-6
+    # integer / half-integer exponents (|y| <= 128) go by binary exponentiation: a handful of roundings
+    integral = np.isin(p, [3.5, 8.0, 6.0, 2.0, 3.0])
+    assert ulp_err(gp[integral], ep[integral]).max() < 6.0   # three squarings double the relative error each time
+    b2 = rng.uniform(0.5, 1.0, 50000).astype(np.float32)
+    for y in (100.0, 25.0, 60.0, 80.0, 32.0, -3.0, 127.5):      # shininess, the sea's and the sky's exponents
+        g2 = probe(abi.RM_FN_POW, b2, np.full_like(b2, y))
+        # x^n is conditioned like n·ε whatever the route (measured: max 69 ulp at n = 100 here, 93 through exp2/log2)
+        assert ulp_err(g2, np.power(b2.astype(np.float64), y)).max() < max(6.0, 0.8 * abs(y)), y
+    sp = probe(abi.RM_FN_POW, np.array([-2, -2, 0, 0, 5, 0, -1.5], dtype=np.float32), np.array([3, 2, 0, 2.5, 1, -1, 0.5], dtype=np.float32))
+    assert sp[0] == -8 and sp[1] == 4 and sp[2] == 1 and sp[3] == 0 and sp[4] == 5 and np.isinf(sp[5]) and np.isnan(sp[6])
     c = rng.uniform(0.0, 1.0, 100000).astype(np.float32)
     gs = probe(abi.RM_FN_POW, c, np.full_like(c, 100.0))
     assert np.abs(gs - np.power(c.astype(np.float64), 100.0)).max() < 2e-5
