@@ -140,26 +140,33 @@ RM_DEV float sdMandelBrot(const SceneBlock *sb, float px, float py) {
 }
 
 // frag:775-803.  r = length(w) is sqrt of the same dot product that produced m, so r = sqrt(m) bit for bit.
-template <bool COUNT>
-RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
+// The iteration loop is compiled three times and chosen once per call by wave-uniform tests on `power`:
+//   BULB_GENERIC    any power: pow through the contract's general evaluation (plan classified once, outside the loop);
+//   BULB_TRIG8      power == 8: the same contract, with the two pows written out — binary exponentiation of 8 is
+//                   ((r²)²)², of 3.5 is (m·(m·m))·√m — as straight-line code (identical bits, no bit loop);
+//   BULB_ALGEBRAIC8 power == 8 and RM_FEAT_BULB_POWER8_ALGEBRAIC: the step by complex squarings (see the header).
+enum BulbMode { BULB_GENERIC = 0, BULB_TRIG8 = 1, BULB_ALGEBRAIC8 = 2 };
+template <bool COUNT, int MODE>
+RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
   const float power = sb->g.power;
   const float pexp = (power - 1.0f) / 2.0f;
   const int iters = sb->s.fractalIters;
   const bool julia = len2(sb->g.juliaSeed[0], sb->g.juliaSeed[1]) != 0.0f;  // frag:782
   // angles are power·acos(·) ∈ [0, power·pi] and power·atan(·,·) ∈ [−power·pi, power·pi], always finite: for
   // |power| < 1e6 they stay inside the contract range of sin/cos and the range guard can be dropped
-  const bool angleSafe = fabs_(power) < 1.0e6f;
+  const bool angleSafe = (MODE != BULB_GENERIC) || fabs_(power) < 1.0e6f;
+  const PowPlan planPower = powPlanUniform(power), planPexp = powPlanUniform(pexp);  // uniforms: classified once
   V3 w = pos;
   float m = dot(w, w);
   V4 trap = v4(fabs_(w.x), fabs_(w.y), fabs_(w.z), m);
   float dz = 1.0f;
   V3 c = julia ? v3(sb->g.juliaSeed[0], sb->g.juliaSeed[1], 0.0f) : pos;
-  if ((sb->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) && power == 8.0f) {  // wave-uniform
-    // Opt-in evaluation scheme of the same step: (y + iρ)^8 = r^8·(cos 8θ + i sin 8θ), ((z + ix)/ρ)^8 = cos 8φ + i sin 8φ
-    // by three complex squarings each, m^3.5 = m³·√m — no acos/atan/sin/cos/pow in the loop.
-    for (int i = 0; i < iters; i++) {
-      if (COUNT) cnt.iters++;
-      float r = sqrt_fast_(m);
+  for (int i = 0; i < iters; i++) {
+    if (COUNT) cnt.iters++;
+    float r = sqrt_fast_(m);  // frag:789
+    if (MODE == BULB_ALGEBRAIC8) {
+      // (y + iρ)^8 = r^8·(cos 8θ + i sin 8θ), ((z + ix)/ρ)^8 = cos 8φ + i sin 8φ by three complex squarings each,
+      // m^3.5 = m³·√m — no acos/atan/sin/cos/pow in the loop
       dz = fma(8.0f * (((m * m) * m) * r), dz, 1.0f);
       float rho = sqrt_fast_(dot2(w.x, w.z, w.x, w.z));
       float inv = 1.0f / rho;
@@ -175,30 +182,38 @@ RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &
         cz = t;
       }
       w = v3(fma(im, sx, c.x), re + c.y, fma(im, cz, c.z));
-      trap = v4(min_(trap.x, fabs_(w.x)), min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
-      m = dot(w, w);
-      if (m > 2.0f) break;
+    } else {
+      float pm, pr;
+      if (MODE == BULB_TRIG8) {
+        pm = (m * (m * m)) * r;             // pow_(m, 3.5): p = m, b = m·m, p = p·b, then ·sqrt(m)
+        float r2 = r * r, r4 = r2 * r2;
+        pr = r4 * r4;                       // pow_(r, 8): three squarings
+      } else {
+        pm = powApply(m, pexp, planPexp);
+        pr = powApply(r, power, planPower);
+      }
+      dz = fma(power * pm, dz, 1.0f);       // frag:787
+      float b = power * acos_(w.y / r);     // frag:790
+      float a = power * atan2_(w.x, w.z);   // frag:791
+      float sb_, cb_, sa_, ca_;
+      if (angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
+      else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
+      w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
     }
-    resColor = v4(m, trap.y, trap.z, trap.w);
-    return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;
-  }
-  for (int i = 0; i < iters; i++) {
-    if (COUNT) cnt.iters++;
-    dz = fma(power * pow_(m, pexp), dz, 1.0f);  // frag:787
-    float r = sqrt_fast_(m);                    // frag:789
-    float b = power * acos_(w.y / r);           // frag:790
-    float a = power * atan2_(w.x, w.z);         // frag:791
-    float pr = pow_(r, power);
-    float sb_, cb_, sa_, ca_;
-    if (angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
-    else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
-    w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
     trap = v4(min_(trap.x, fabs_(w.x)), min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
     m = dot(w, w);
     if (m > 2.0f) break;  // frag:798 (FRACTALS_BAILOUT)
   }
   resColor = v4(m, trap.y, trap.z, trap.w);
   return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;  // frag:802
+}
+template <bool COUNT>
+RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
+  if (sb->g.power == 8.0f) {  // wave-uniform
+    if (sb->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) return bulbIterate<COUNT, BULB_ALGEBRAIC8>(sb, pos, resColor, cnt);
+    return bulbIterate<COUNT, BULB_TRIG8>(sb, pos, resColor, cnt);
+  }
+  return bulbIterate<COUNT, BULB_GENERIC>(sb, pos, resColor, cnt);
 }
 
 // frag:808-827

@@ -197,20 +197,39 @@ RM_DEV float exp2_(float x) {
 // reciprocal for y < 0), everything else exp2(y·log2(x)) — the contract of DESIGN.md §3.  The
 // exponents on the hot path (power, (power−1)/2, shininess) are wave-uniform: the loop is scalar-controlled and the
 // classification of y is loop-invariant in the Mandelbulb iteration.
-RM_DEV float pow_(float x, float y) {
+struct PowPlan { int n; bool fast, half, neg; };  // how pow(·, y) is evaluated for one exponent y
+RM_DEV PowPlan powPlan(float y) {
   float ay = fabs_(y), two = ay + ay;
-  if (two <= 256.0f && two == floor_(two)) {
-    int n = (int)ay;
+  PowPlan pl;
+  pl.fast = (two <= 256.0f) && (two == floor_(two));
+  pl.n = pl.fast ? (int)ay : 0;
+  pl.half = ay != (float)pl.n;
+  pl.neg = y < 0.0f;
+  return pl;
+}
+// The same plan for a WAVE-UNIFORM exponent (a uniform such as `power`): held in scalar registers, so the bit loop
+// and the branches of powApply are scalar control flow.  Hoist it out of loops that call pow with a fixed exponent.
+RM_DEV PowPlan powPlanUniform(float y) {
+  PowPlan pl = powPlan(y);
+  pl.n = __builtin_amdgcn_readfirstlane(pl.n);
+  pl.fast = __builtin_amdgcn_readfirstlane((int)pl.fast) != 0;
+  pl.half = __builtin_amdgcn_readfirstlane((int)pl.half) != 0;
+  pl.neg = __builtin_amdgcn_readfirstlane((int)pl.neg) != 0;
+  return pl;
+}
+RM_DEV float powApply(float x, float y, const PowPlan &pl) {
+  if (pl.fast) {
     float p = 1.0f, b = x;
-    for (int e = n; e != 0; e >>= 1) {
+    for (int e = pl.n; e != 0; e >>= 1) {
       if (e & 1) p = p * b;
       if (e > 1) b = b * b;
     }
-    if (ay != (float)n) p = p * sqrt_fast_(x);
-    return (y < 0.0f) ? 1.0f / p : p;
+    if (pl.half) p = p * sqrt_fast_(x);
+    return pl.neg ? 1.0f / p : p;
   }
   return exp2_(y * log2_(x));
 }
+RM_DEV float pow_(float x, float y) { return powApply(x, y, powPlan(y)); }
 constexpr float kLn2 = 0.693147182f;   // 0x3f317218
 constexpr float kLog2e = 1.44269502f;  // 0x3fb8aa3b
 RM_DEV float log_(float x) { return log2_(x) * kLn2; }
