@@ -226,6 +226,11 @@ int rm_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, con
 int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
                     int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int tileRows,
                     int shard, int numShards, float *d_rgba, float *d_bright, void *stream);
+/* rm_render_tiles with the samplers of rm_render_res (`res` may be NULL): every shard passes the same resources, each
+ * GPU holding its own copy of the images. */
+int rm_render_tiles_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                        const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int tileRows,
+                        int shard, int numShards, float *d_rgba, float *d_bright, void *stream);
 /* Rows owned by `shard` under the rm_render_tiles partition. */
 int rm_shard_rows(int H, int tileRows, int shard, int numShards);
 /* Frame row of the shard's packed row `localRow` (inverse map used when de-interleaving a gather). */
@@ -341,6 +346,13 @@ const char *rm_scene_object_texture(const RmScene *scene, int i);
  * rows the renderer expects.  *outPixels is malloc'ed host memory of w·h·4 bytes; free with rm_image_free. */
 int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *w, int *h);
 void rm_image_free(uint8_t *pixels);
+
+/* Sky-box selection of the GUI (settings.idxSkyBox → RayMarchScene::getCubeMapWithType, raymarchscene.cpp:50-86;
+ * enum CUBEMAP, scenedata.h:43-48): path of face `face` (0..5, the order of RmResources.skybox) of cube map `which`
+ * (1 BEACH, 2 NIGHTSKY, 3 ISLAND) relative to the scenefiles directory, or NULL.  Reproduced as written, including the
+ * NIGHTSKY list naming −x before +x and −y before +y.  The BEACH faces are JPEG files, which rm_image_load does not
+ * decode: the caller supplies decoded pixels. */
+const char *rm_skybox_face_path(int which, int face);
 
 /* PNG writer for RGBA8 rows (top row first) — stands in for QImage::save (realtime.cpp:346). */
 int rm_write_png(const char *path, const uint8_t *rgba, int W, int H);

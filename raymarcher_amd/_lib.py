@@ -30,6 +30,9 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p]),
     "rm_render_res": (C.c_int, _SCENE_ARGS + [_P(abi.RmResources), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
+    "rm_render_tiles_res": (C.c_int, _SCENE_ARGS + [_P(abi.RmResources), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]),
+    "rm_skybox_face_path": (C.c_char_p, [C.c_int, C.c_int]),
     "rm_ltc_quantise": (None, [C.c_void_p, C.c_void_p, C.c_int]),
     "rm_image_load": (C.c_int, [C.c_char_p, C.c_int, _P(C.c_void_p), _P(C.c_int), _P(C.c_int)]),
     "rm_image_free": (None, [C.c_void_p]),

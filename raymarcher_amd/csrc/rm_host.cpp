@@ -90,6 +90,19 @@ extern "C" {
 
 int rm_abi_version(void) { return RM_ABI_VERSION; }
 
+const char *rm_skybox_face_path(int which, int face) {
+  // RayMarchScene::getCubeMapWithType, raymarchscene.cpp:50-86 (lists as written there)
+  static const char *const kFaces[3][6] = {
+      {"texture_store/cube_map/beach/+x.jpg", "texture_store/cube_map/beach/-x.jpg", "texture_store/cube_map/beach/+y.jpg",
+       "texture_store/cube_map/beach/-y.jpg", "texture_store/cube_map/beach/+z.jpg", "texture_store/cube_map/beach/-z.jpg"},
+      {"texture_store/cube_map/night/-x.png", "texture_store/cube_map/night/+x.png", "texture_store/cube_map/night/-y.png",
+       "texture_store/cube_map/night/+y.png", "texture_store/cube_map/night/+z.png", "texture_store/cube_map/night/-z.png"},
+      {"texture_store/cube_map/island/+x.png", "texture_store/cube_map/island/-x.png", "texture_store/cube_map/island/+y.png",
+       "texture_store/cube_map/island/-y.png", "texture_store/cube_map/island/+z.png", "texture_store/cube_map/island/-z.png"}};
+  if (which < 1 || which > 3 || face < 0 || face > 5) return nullptr;
+  return kFaces[which - 1][face];
+}
+
 void rm_ltc_quantise(const float *table, uint8_t *out, int texels) {
   for (int i = 0; i < texels * 4; i++) {
     float v = table[i];

@@ -497,6 +497,18 @@ int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, c
                        d_rgba, d_bright, static_cast<hipStream_t>(stream), false, nullptr);
 }
 
+int rm_render_tiles_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                        const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int tileRows,
+                        int shard, int numShards, float *d_rgba, float *d_bright, void *stream) {
+  if (tileRows <= 0 || numShards <= 0 || shard < 0 || shard >= numShards) {
+    set_error("bad tile partition");
+    return RM_ERR_INVALID_ARGUMENT;
+  }
+  RowMap map{0, tileRows, shard, numShards};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards),
+                       d_rgba, d_bright, static_cast<hipStream_t>(stream), false, nullptr, res ? *res : kNoResources);
+}
+
 int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
                     int shardStrideRows, void *stream) {
   if (!d_gathered || !d_frame || W <= 0 || H <= 0 || tileRows <= 0 || numShards <= 0 || numShards > 64 ||

@@ -226,8 +226,9 @@ class Renderer:
         n = lib().rm_shard_rows(H, tile_rows, shard, num_shards)
         if out is None:
             out = t.empty((max(n, 0), W, 4), dtype=t.float32, device=self.device)
-        check(lib().rm_render_tiles(*tables.args(settings), W, H, tile_rows, shard, num_shards,
-                                    C.c_void_p(out.data_ptr()), None, self._stream()))
+        res, _keep = self._resources(tables)
+        check(lib().rm_render_tiles_res(*tables.args(settings), C.byref(res), W, H, tile_rows, shard, num_shards,
+                                        C.c_void_p(out.data_ptr()), None, self._stream()))
         return out
 
     def deinterleave(self, gathered, W, H, tile_rows, num_shards, shard_stride_rows=0):

@@ -149,3 +149,13 @@ def test_no_cpu_fallback_in_the_product_path():
                 text = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "oracle/" not in text, f"{fn} mentions oracle/"
                 assert "rm_oracle" not in text and "librm_oracle" not in text, fn
+
+
+def test_skybox_face_paths():
+    """getCubeMapWithType's lists (raymarchscene.cpp:50-86), including the NIGHTSKY order as written there."""
+    from raymarcher_amd import lib
+    L = lib()
+    assert L.rm_skybox_face_path(1, 0) == b"texture_store/cube_map/beach/+x.jpg"
+    assert [L.rm_skybox_face_path(2, f).decode()[-6:-4] for f in range(6)] == ["-x", "+x", "-y", "+y", "+z", "-z"]
+    assert [L.rm_skybox_face_path(3, f).decode()[-6:-4] for f in range(6)] == ["+x", "-x", "+y", "-y", "+z", "-z"]
+    assert L.rm_skybox_face_path(0, 0) is None and L.rm_skybox_face_path(4, 0) is None and L.rm_skybox_face_path(1, 6) is None

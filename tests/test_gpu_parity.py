@@ -609,6 +609,26 @@ def test_resource_frames_bit_exact(renderer, name):
     assert np.isfinite(ref).all()
 
 
+def test_resource_frames_in_row_tiles(renderer):
+    """rm_render_tiles_res: the sharded render of sampler-driven scenes equals the single launch."""
+    import torch
+    from raymarcher_amd import lib
+    W, H, T, N = 96, 70, 8, 3
+    for name in ("sea_sky", "area_light", "skybox_reflect"):
+        scene, s, res = resource_case(name, W, H)
+        t = tables_of(scene)
+        for k, v in res.items():
+            setattr(t, k, v)
+        full = renderer.render(t, s, W, H)
+        slot = lib().rm_shard_rows(H, T, 0, N)
+        gathered = torch.zeros((N * slot, W, 4), dtype=torch.float32, device=full.device)
+        for k in range(N):
+            mine = renderer.render_tiles(t, s, W, H, T, k, N)
+            gathered[k * slot:k * slot + mine.shape[0]] = mine
+        frame = renderer.deinterleave(gathered, W, H, T, N, slot)
+        assert (frame.view(dtype=torch.int32) == full.view(dtype=torch.int32)).all(), name
+
+
 def test_resource_errors(renderer):
     """A feature whose sampler was not supplied is refused, on both sides, with RM_ERR_UNSUPPORTED."""
     from raymarcher_amd import RaymarcherError
