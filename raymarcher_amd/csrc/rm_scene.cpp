@@ -20,6 +20,7 @@
 
 #include "../../include/raymarcher_amd.h"
 #include "rm_internal.h"
+#include "rm_mat4.h"
 
 namespace rm {
 namespace {
@@ -155,62 +156,11 @@ struct JParser {
 };
 
 // ------------------------------------------------------------------------------------------- math
-struct M4 {  // column-major, element (r,c) at m[c*4+r]
-  float m[16];
-};
-M4 identity() { M4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
-M4 mul(const M4 &A, const M4 &B) {
-  M4 R{};
-  for (int c = 0; c < 4; c++)
-    for (int r = 0; r < 4; r++) {
-      float acc = A.m[0 * 4 + r] * B.m[c * 4 + 0];
-      acc = acc + A.m[1 * 4 + r] * B.m[c * 4 + 1];
-      acc = acc + A.m[2 * 4 + r] * B.m[c * 4 + 2];
-      acc = acc + A.m[3 * 4 + r] * B.m[c * 4 + 3];
-      R.m[c * 4 + r] = acc;
-    }
-  return R;
-}
-void mulVec(const M4 &A, const float v[4], float out[4]) {
-  for (int r = 0; r < 4; r++) {
-    float acc = A.m[0 * 4 + r] * v[0];
-    acc = acc + A.m[1 * 4 + r] * v[1];
-    acc = acc + A.m[2 * 4 + r] * v[2];
-    acc = acc + A.m[3 * 4 + r] * v[3];
-    out[r] = acc;
-  }
-}
-M4 inverse(const M4 &M) {
-  auto m = [&](int c, int r) { return M.m[c * 4 + r]; };
-  float c00 = m(2, 2) * m(3, 3) - m(3, 2) * m(2, 3), c02 = m(1, 2) * m(3, 3) - m(3, 2) * m(1, 3),
-        c03 = m(1, 2) * m(2, 3) - m(2, 2) * m(1, 3);
-  float c04 = m(2, 1) * m(3, 3) - m(3, 1) * m(2, 3), c06 = m(1, 1) * m(3, 3) - m(3, 1) * m(1, 3),
-        c07 = m(1, 1) * m(2, 3) - m(2, 1) * m(1, 3);
-  float c08 = m(2, 1) * m(3, 2) - m(3, 1) * m(2, 2), c10 = m(1, 1) * m(3, 2) - m(3, 1) * m(1, 2),
-        c11 = m(1, 1) * m(2, 2) - m(2, 1) * m(1, 2);
-  float c12 = m(2, 0) * m(3, 3) - m(3, 0) * m(2, 3), c14 = m(1, 0) * m(3, 3) - m(3, 0) * m(1, 3),
-        c15 = m(1, 0) * m(2, 3) - m(2, 0) * m(1, 3);
-  float c16 = m(2, 0) * m(3, 2) - m(3, 0) * m(2, 2), c18 = m(1, 0) * m(3, 2) - m(3, 0) * m(1, 2),
-        c19 = m(1, 0) * m(2, 2) - m(2, 0) * m(1, 2);
-  float c20 = m(2, 0) * m(3, 1) - m(3, 0) * m(2, 1), c22 = m(1, 0) * m(3, 1) - m(3, 0) * m(1, 1),
-        c23 = m(1, 0) * m(2, 1) - m(2, 0) * m(1, 1);
-  const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
-  const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
-  const float v0[4] = {m(1, 0), m(0, 0), m(0, 0), m(0, 0)}, v1[4] = {m(1, 1), m(0, 1), m(0, 1), m(0, 1)};
-  const float v2[4] = {m(1, 2), m(0, 2), m(0, 2), m(0, 2)}, v3[4] = {m(1, 3), m(0, 3), m(0, 3), m(0, 3)};
-  M4 inv{};
-  for (int i = 0; i < 4; i++) {
-    const float sa = (i & 1) ? -1.0f : 1.0f, sb = -sa;
-    inv.m[0 * 4 + i] = ((v1[i] * f0[i] - v2[i] * f1[i]) + v3[i] * f2[i]) * sa;
-    inv.m[1 * 4 + i] = ((v0[i] * f0[i] - v2[i] * f3[i]) + v3[i] * f4[i]) * sb;
-    inv.m[2 * 4 + i] = ((v0[i] * f1[i] - v1[i] * f3[i]) + v3[i] * f5[i]) * sa;
-    inv.m[3 * 4 + i] = ((v0[i] * f2[i] - v1[i] * f4[i]) + v2[i] * f5[i]) * sb;
-  }
-  const float d0 = m(0, 0) * inv.m[0], d1 = m(0, 1) * inv.m[4], d2 = m(0, 2) * inv.m[8], d3 = m(0, 3) * inv.m[12];
-  const float ood = 1.0f / ((d0 + d1) + (d2 + d3));
-  for (float &x : inv.m) x = x * ood;
-  return inv;
-}
+using M4 = Mat4;  // rm_mat4.h
+inline M4 identity() { return mat_identity(); }
+inline M4 mul(const M4 &A, const M4 &B) { return mat_mul(A, B); }
+inline void mulVec(const M4 &A, const float v[4], float out[4]) { mat_mul_vec(A, v, out); }
+inline M4 inverse(const M4 &M) { return mat_inverse(M); }
 // Rodrigues rotation about normalize(axis) by `angle` radians.
 M4 rotation(float angle, const float axis[3]) {
   const float c = std::cos(angle), s = std::sin(angle);
