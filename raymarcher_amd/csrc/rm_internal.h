@@ -1,6 +1,8 @@
 // rm_internal.h — helpers shared by the launcher (rm_kernels.hip) and the host side (rm_host.cpp).
 #pragma once
+#include <initializer_list>
 #include <string>
+#include <utility>
 
 #ifndef __HIPCC__
 #define __host__
@@ -11,6 +13,13 @@ namespace rm {
 
 // Records the text returned by rm_last_error() for the calling thread.
 void set_error(const std::string &msg);
+
+// True if `p` is memory a kernel may dereference (device, managed or pinned host) according to the HIP runtime.
+// Every "device pointer" argument of the ABI is checked with it before a launch: a kernel that touches plain host
+// memory faults the GPU.
+bool device_accessible(const void *p);
+// RM_ERR_INVALID_ARGUMENT (+ rm_last_error text) unless every non-null pointer of the list is device-accessible.
+int require_device_pointers(std::initializer_list<std::pair<const char *, const void *>> ptrs);
 
 // Rows owned by `shard` when an H-row frame is cut into tiles of tileRows rows dealt round-robin.
 __host__ __device__ inline int shard_rows(int H, int tileRows, int shard, int numShards) {

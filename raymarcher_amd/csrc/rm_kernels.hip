@@ -17,6 +17,23 @@
 
 namespace rm {
 
+bool device_accessible(const void *p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // unknown (plain host) pointer: clear the sticky error
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeHost;  // Host = pinned
+}
+int require_device_pointers(std::initializer_list<std::pair<const char *, const void *>> ptrs) {
+  for (const auto &p : ptrs)
+    if (p.second && !device_accessible(p.second)) {
+      set_error(std::string(p.first) + " is not device-accessible memory");
+      return RM_ERR_INVALID_ARGUMENT;
+    }
+  return RM_OK;
+}
+
 // Block = 4 waves side by side, each wave an 8×8 pixel tile → the block covers 32×8 pixels.
 #ifndef RM_TILE_W
 #define RM_TILE_W 8   // pixels per wave tile, horizontally (RM_TILE_W × RM_TILE_H = 64)
@@ -216,6 +233,20 @@ int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, B
 }
 
 bool tex_ok(const RmTexture &t) { return t.pixels && t.width > 0 && t.height > 0; }
+
+int check_device_pointers(const RmResources &res, const float *d_rgba, const float *d_bright) {
+  auto bad = [](const char *what) { set_error(std::string(what) + " is not device-accessible memory"); return RM_ERR_INVALID_ARGUMENT; };
+  int st = require_device_pointers({{"d_rgba", d_rgba}, {"d_bright", d_bright}});
+  if (st != RM_OK) return st;
+  for (int i = 0; i < res.numTextures; i++)
+    if (res.textures[i].pixels && !device_accessible(res.textures[i].pixels)) return bad("a texture's pixels");
+  if (res.noise.pixels && !device_accessible(res.noise.pixels)) return bad("RmResources.noise.pixels");
+  for (int f = 0; f < 6; f++)
+    if (res.skybox[f].pixels && !device_accessible(res.skybox[f].pixels)) return bad("a sky-box face");
+  if (res.ltc1 && !device_accessible(res.ltc1)) return bad("RmResources.ltc1");
+  if (res.ltc2 && !device_accessible(res.ltc2)) return bad("RmResources.ltc2");
+  return RM_OK;
+}
 const RmResources kNoResources{};
 
 int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -311,6 +342,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (W <= 0 || H <= 0 || nRows < 0) { set_error("bad frame size"); return RM_ERR_INVALID_ARGUMENT; }
   if (nRows == 0) return RM_OK;  // empty row range: nothing to write, a null buffer is fine
   if (!d_rgba) { set_error("null output buffer"); return RM_ERR_INVALID_ARGUMENT; }
+  if ((st = check_device_pointers(res, d_rgba, d_bright)) != RM_OK) return st;
   Slot *slot;
   st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot, res);
   if (st != RM_OK) return st;
@@ -516,6 +548,7 @@ int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int t
     set_error("bad deinterleave arguments");
     return RM_ERR_INVALID_ARGUMENT;
   }
+  if (int st = require_device_pointers({{"d_gathered", d_gathered}, {"d_frame", d_frame}})) return st;
   dim3 grid((W + 255) / 256, H), block(256);
   hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4 *>(d_gathered), reinterpret_cast<float4 *>(d_frame), W, H, tileRows,
@@ -526,6 +559,7 @@ int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int t
 
 int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *stream) {
   if (!d_rgba || !d_out || W <= 0 || H <= 0) { set_error("bad frame arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (int st = require_device_pointers({{"d_rgba", d_rgba}, {"d_out", d_out}})) return st;
   dim3 grid((W + 255) / 256, H), block(256);
   hipLaunchKernelGGL(to_rgba8_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4 *>(d_rgba), reinterpret_cast<uchar4 *>(d_out), W, H);
@@ -577,6 +611,7 @@ int rm_set_kernel_path(int path) {
 
 int rm_probe_math(int fn, const float *d_x, const float *d_y, const float *d_z, float *d_out, int n, void *stream) {
   if (fn < 0 || fn >= RM_FN_COUNT || !d_x || !d_out || n < 0) { set_error("bad probe arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (int st = require_device_pointers({{"d_x", d_x}, {"d_y", d_y}, {"d_z", d_z}, {"d_out", d_out}})) return st;
   if (n == 0) return RM_OK;
   hipLaunchKernelGGL(probe_math_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), fn, d_x,
                      d_y, d_z, d_out, n);
@@ -591,6 +626,7 @@ int rm_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, c
   int st = validate_scene(&cam, objs, numObjects, nullptr, 0, g, s, kNoResources);
   if (st != RM_OK) return st;
   if (!d_pts || !d_out || n < 0) { set_error("bad probe arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (int st2 = require_device_pointers({{"d_pts", d_pts}, {"d_out", d_out}})) return st2;
   if (n == 0) return RM_OK;
   Slot *slot;
   hipStream_t hs = static_cast<hipStream_t>(stream);

@@ -201,6 +201,7 @@ extern "C" int rm_post_process(const float *d_frag, const float *d_bright, float
                                const RmPostSettings *ps, void *stream) {
   if (!d_frag || !d_out || !ps || W <= 0 || H <= 0) { set_error("bad post-process arguments"); return RM_ERR_INVALID_ARGUMENT; }
   if (ps->enableBloom && !d_bright) { set_error("bloom needs the BrightColor plane"); return RM_ERR_INVALID_ARGUMENT; }
+  if (int rc = require_device_pointers({{"d_frag", d_frag}, {"d_bright", d_bright}, {"d_out", d_out}})) return rc;
   std::lock_guard<std::mutex> lock(g_postMu);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t n = (size_t)W * H;

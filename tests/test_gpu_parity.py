@@ -629,6 +629,25 @@ def test_resource_frames_in_row_tiles(renderer):
         assert (frame.view(dtype=torch.int32) == full.view(dtype=torch.int32)).all(), name
 
 
+def test_host_pointers_are_refused(renderer):
+    """A host pointer where device memory is expected must come back as an error, never reach a kernel."""
+    from raymarcher_amd import RaymarcherError, lib
+    from raymarcher_amd._lib import check
+    W, H = 16, 16
+    t = tables_of(h.scene_mandelbulb(W, H))
+    s = abi.default_settings()
+    host = np.zeros((H, W, 4), np.float32)
+    with pytest.raises(RaymarcherError) as e:
+        check(lib().rm_render(*t.args(s), W, H, 0, H, C.c_void_p(host.ctypes.data), None, None))
+    assert e.value.status == abi.RM_ERR_INVALID_ARGUMENT and "device" in str(e.value)
+    scene, s2, res = resource_case("night_sky", W, H)
+    hres, _keep = h.host_resources(**res)          # HOST pixel pointers
+    out = renderer.torch.empty((H, W, 4), dtype=renderer.torch.float32, device=renderer.device)
+    with pytest.raises(RaymarcherError) as e:
+        check(lib().rm_render_res(*tables_of(scene).args(s2), C.byref(hres), W, H, 0, H, C.c_void_p(out.data_ptr()), None, None))
+    assert e.value.status == abi.RM_ERR_INVALID_ARGUMENT
+
+
 def test_resource_errors(renderer):
     """A feature whose sampler was not supplied is refused, on both sides, with RM_ERR_UNSUPPORTED."""
     from raymarcher_amd import RaymarcherError
