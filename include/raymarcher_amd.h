@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 1
+#define RM_ABI_VERSION 2
 
 /* Capacity limits — src/realtime.h:17-27 (MAX_NUM_LIGHTS 10, MAX_NUM_SHAPES 30). */
 #define RM_MAX_LIGHTS 10
