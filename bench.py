@@ -203,9 +203,9 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          # HBM bytes per launch measured with rocprofv3 PMC (WRITE_SIZE + 2·FETCH_SIZE, separate passes):
-                         # exactly 16 B/pixel written + 0.43 MB read — profiles/r01_d_hbm_pmc.md
-                         "traffic": int(bytes_launch + 429000) if path in (0, 1) else None,
-                         "traffic_source": "profiles/r01_d_hbm_pmc.md (rocprofv3 PMC of this kernel and workload)",
+                         # exactly 16 B/pixel written + 0.55 MB read — profiles/r01_k_hbm_pmc.md
+                         "traffic": int(bytes_launch + 552000) if path in (0, 1) else None,
+                         "traffic_source": "profiles/r01_k_hbm_pmc.md (rocprofv3 PMC of this kernel and workload)",
                          "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "stage_ms": {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
                                       "shadow": round(stages[2], 4), "shade": round(stages[3], 4)},
