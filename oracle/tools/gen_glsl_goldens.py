@@ -36,10 +36,10 @@ def pack(scene, settings):
                 settings=raw(settings))
 
 
-def frame_case(name, scene, settings, W, H, texture=None, **res):
+def frame_case(name, scene, settings, W, H, texture=None, ub10=False, **res):
     """res: noise= / skybox= (six faces) / ltc1=, ltc2= — the sampler inputs of tg.resource_case, stored in the fixture."""
     ltc = (res["ltc1"], res["ltc2"]) if "ltc1" in res else None
-    rgba, bright = run_ref.render(scene, settings, W, H, texture, noise=res.get("noise"), skybox=res.get("skybox"), ltc=ltc)
+    rgba, bright = run_ref.render(scene, settings, W, H, texture, noise=res.get("noise"), skybox=res.get("skybox"), ltc=ltc, ub10=ub10)
     extra = {} if texture is None else {"texture": texture}
     for k, v in res.items():
         if k == "noise":  # 256 KB of random bytes: stored once, shared by every fixture that samples it
@@ -65,6 +65,12 @@ def env_cases():
     frame_case("env_terrain_cloud_sky", tg.env_scene(W, H), abi.default_settings(features=sky_terr | abi.RM_FEAT_CLOUD), W, H)
     frame_case("env_all_reflect", tg.env_scene(W, H, (0, 560, 0), (0.2, 0.3, -1)),
                abi.default_settings(features=tg.ENV_ALL, enableReflection=1), W, H)
+    # the same two cloud frames with the shader's unset `nnd` given the oracle's UB10 value (essl_adapt.define_ub10)
+    frame_case("env_terrain_cloud_sky_ub10", tg.env_scene(W, H), abi.default_settings(features=sky_terr | abi.RM_FEAT_CLOUD), W, H, ub10=True)
+    frame_case("env_all_reflect_ub10", tg.env_scene(W, H, (0, 560, 0), (0.2, 0.3, -1)),
+               abi.default_settings(features=tg.ENV_ALL, enableReflection=1), W, H, ub10=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "frames":
+        return
     # function-level probes of the procedural layers (the defines must be on for these functions to exist)
     orig = run_ref.build_program
 

@@ -86,6 +86,15 @@ PROBE_MAIN = {
 }
 
 
+def define_ub10(text):
+    """E9 (only for the `*_ub10` fixtures): cloudsMap leaves its `out float nnd` unset on the early return although
+    cloudMarch reads it (frag:1961-1974, 1994-1995).  This gives it the value of the oracle's UB10 decision — `nnd = -d`
+    before the return, the order of the function's origin — so that the REST of the cloud path can be compared tightly."""
+    new, n = re.subn(r"if\(\s*d\s*>\s*0\.0\s*\)\s*return\s+vec4\(-d,\s*0\.0,\s*0\.0,\s*0\.0\);", "nnd = -d; if( d>0.0 ) return vec4(-d,0.0,0.0,0.0);", text)
+    assert n == 1, n
+    return new
+
+
 def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4, probe=None):
     """Return ESSL 3.00 source.  `defines`: {name: bool} for the #define block (frag:4-15);
     `consts`: {MAX_STEPS: n, MAX_STEPS_FRACTALS: n, NUM_REFLECTION: n, MENGER_LEVELS: n}."""
