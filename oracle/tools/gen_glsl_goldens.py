@@ -36,10 +36,10 @@ def pack(scene, settings):
                 settings=raw(settings))
 
 
-def frame_case(name, scene, settings, W, H, texture=None, ub10=False, **res):
+def frame_case(name, scene, settings, W, H, texture=None, ub10=False, ub1=False, **res):
     """res: noise= / skybox= (six faces) / ltc1=, ltc2= — the sampler inputs of tg.resource_case, stored in the fixture."""
     ltc = (res["ltc1"], res["ltc2"]) if "ltc1" in res else None
-    rgba, bright = run_ref.render(scene, settings, W, H, texture, noise=res.get("noise"), skybox=res.get("skybox"), ltc=ltc, ub10=ub10)
+    rgba, bright = run_ref.render(scene, settings, W, H, texture, noise=res.get("noise"), skybox=res.get("skybox"), ltc=ltc, ub10=ub10, ub1=ub1)
     extra = {} if texture is None else {"texture": texture}
     for k, v in res.items():
         if k == "noise":  # 256 KB of random bytes: stored once, shared by every fixture that samples it
@@ -135,6 +135,18 @@ def post_cases():
         print("post", name, out.shape, {k: float(v.mean()) for k, v in extra.items() if k == "tie"})
 
 
+def softshadow_cases():
+    """Soft shadows with the shader's unset `r.d` given the UB1 value in the harness (essl_adapt.define_ub1)."""
+    W, H = 64, 48
+    prims = tg.all_primitives_scene(W, H)
+    WB = abi.RM_FEAT_WHITE_BACKGROUND
+    frame_case("prims_a_softshadow_ub1", subset(prims, range(0, 6)), abi.default_settings(features=WB, enableSoftShadow=1), W, H, ub1=True)
+    frame_case("prims_softshadow_ao_bump_ub1", subset(prims, [0, 2, 4, 6, 8, 9]),
+               abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1), W, H, ub1=True)
+    scene, s, res = tg.resource_case("area_light_soft_bump", 64, 40)
+    frame_case("res_area_light_soft_bump_ub1", scene, s, 64, 40, ub1=True, **res)
+
+
 def resource_cases(only=None):
     """Night sky, sea, sky box and area lights: the reference shader with its noise / cube-map / LTC samplers bound to
     the synthetic inputs of tests/test_gpu_parity.py."""
@@ -161,6 +173,8 @@ def resource_cases(only=None):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "soft":
+        return softshadow_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "res":
         return resource_cases(sys.argv[2:])
     if len(sys.argv) > 1 and sys.argv[1] == "post":
@@ -173,6 +187,7 @@ def main():
     env_cases()
     post_cases()
     resource_cases()
+    softshadow_cases()
     W, H = 64, 48
     WB, DB = abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND
     prims = tg.all_primitives_scene(W, H)

@@ -95,6 +95,14 @@ def define_ub10(text):
     return new
 
 
+def define_ub1(text):
+    """E10 (only for the `*_ub1` fixtures): softshadow leaves `r.d` unset on a miss although getPhong multiplies by it when
+    soft shadows are on (frag:1720-1722, 1928).  This assigns the oracle's UB1 value, `r.d = res` (the penumbra factor)."""
+    new, n = re.subn(r"(?<![\w.])r\.intersectObj\s*=\s*-1\s*;", "r.intersectObj = -1; r.d = res;", text)
+    assert n == 1, n
+    return new
+
+
 def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4, probe=None):
     """Return ESSL 3.00 source.  `defines`: {name: bool} for the #define block (frag:4-15);
     `consts`: {MAX_STEPS: n, MAX_STEPS_FRACTALS: n, NUM_REFLECTION: n, MENGER_LEVELS: n}."""

@@ -19,12 +19,14 @@ def ctx():
     return _CTX
 
 
-def build_program(defines, consts, max_objects=6, max_lights=4, spec=None, probe=None, ub10=False):
+def build_program(defines, consts, max_objects=6, max_lights=4, spec=None, probe=None, ub10=False, ub1=False):
     c = ctx()
     vert = open(os.path.join(REF, "raymarch.vert")).read().replace("#version 330 core", "#version 300 es\nprecision highp float;")
     frag = essl_adapt.adapt(open(os.path.join(REF, "raymarch.frag")).read(), defines, consts, max_objects, max_lights, probe)
     if ub10:
         frag = essl_adapt.define_ub10(frag)
+    if ub1:
+        frag = essl_adapt.define_ub1(frag)
     if spec is not None:
         frag = essl_adapt.specialise(frag, **spec)
     for _ in range(8):
@@ -177,7 +179,7 @@ def bind_skybox(faces):
     return t
 
 
-def render(scene, settings, W, H, texture=None, noise=None, skybox=None, ltc=None, ub10=False):
+def render(scene, settings, W, H, texture=None, noise=None, skybox=None, ltc=None, ub10=False, ub1=False):
     """scene = (cam, objs, numObjects, lights, numLights, globals); returns (fragColor, BrightColor) float32 HxWx4,
     row 0 = bottom (GL read-back order).  `texture`: optional RGBA8 array bound as objTextures[0]; `noise`: RGBA8 array
     for the `noise` sampler; `skybox`: six RGBA8 faces; `ltc`: (ltc1, ltc2) uint8 (64,64,4) tables."""
@@ -201,7 +203,7 @@ def render(scene, settings, W, H, texture=None, noise=None, skybox=None, ltc=Non
         false_u.append("isTwoD")
     spec = {"false_uniforms": false_u, "present_types": sorted({objs[i].type for i in range(no)}),
             "has_area_light": any(lights[i].type == abi.RM_LIGHT_AREA for i in range(nl))}
-    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec, ub10=ub10)
+    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec, ub10=ub10, ub1=ub1)
     c = ctx()
     c.target(W, H, 2)
     set_uniforms(prog, cam, objs, no, lights, nl, g, settings, W, H)
