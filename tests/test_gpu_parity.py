@@ -902,3 +902,95 @@ def test_frame_pipeline_over_rccl_single_rank(renderer, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+# ---------------------------------------------------------------- randomised scenes
+def _random_case(rng, W, H):
+    """A random scene + settings + resources drawn from everything the ABI accepts."""
+    f = rng.uniform
+    n_obj = int(rng.integers(1, 7))
+    types = [abi.RM_CUBE, abi.RM_CONE, abi.RM_CYLINDER, abi.RM_SPHERE, abi.RM_OCTAHEDRON, abi.RM_TORUS, abi.RM_CAPSULE,
+             abi.RM_DEATHSTAR, abi.RM_RECTANGLE, abi.RM_MANDELBULB, abi.RM_MENGERSPONGE, abi.RM_SIERPINSKI]
+    texs = synthetic_textures()
+    objs = []
+    for _ in range(n_obj):
+        ty = int(rng.choice(types))
+        sc = float(f(0.6, 1.8))
+        sx, sy, sz = (sc * float(f(0.8, 1.25)) for _ in range(3))
+        M = h.translate(f(-2.2, 2.2), f(-1.0, 1.2), f(-2.5, 1.0)) @ rot_x(f(-0.6, 0.6)) @ h.scale(sx, sy, sz)
+        o = h.make_object(ty, model=M, scale_factor=min(sx, sy, sz), ambient=tuple(f(0, .3, 3)), diffuse=tuple(f(.2, 1, 3)),
+                          specular=tuple(f(0, 1, 3)), shininess=float(rng.choice([0, 1, 7.5, 25, 100])),
+                          reflective=tuple(f(0, .8, 3)) if f() < 0.4 else (0, 0, 0),
+                          transparent=tuple(f(0, .8, 3)) if f() < 0.3 else (0, 0, 0), ior=float(f(1.05, 1.6)))
+        if ty in (abi.RM_CUBE, abi.RM_CONE, abi.RM_CYLINDER, abi.RM_SPHERE) and f() < 0.4:
+            o.texLoc, o.repeatU, o.repeatV, o.blend = int(rng.integers(0, 2)), float(f(0.5, 4)), float(f(0.5, 4)), float(f(0, 1))
+        objs.append(o)
+    lights = []
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 3))
+        col = tuple(f(.3, 1.6, 3))
+        if kind == abi.RM_LIGHT_DIRECTIONAL:
+            lights.append(h.make_light(kind, col, direction=(f(-1, 1), f(-1, -0.2), f(-1, 1))))
+        elif kind == abi.RM_LIGHT_POINT:
+            lights.append(h.make_light(kind, col, pos=(f(-4, 4), f(1, 5), f(-1, 5)), func=(f(.5, 1), f(0, .1), f(0, .02))))
+        else:
+            lights.append(h.make_light(kind, col, direction=(f(-.3, .3), -1, f(-.6, 0)), pos=(f(-2, 2), f(3, 5), f(0, 3)),
+                                       func=(f(.5, 1), f(0, .1), 0), angle=float(f(.4, .9)), penumbra=float(f(.05, .3))))
+    res = {}
+    if any(o.texLoc >= 0 for o in objs):
+        res["textures"] = texs
+    if f() < 0.3:  # an area light with its emissive rectangle
+        ctm = h.translate(f(-1, 1), f(2, 3), f(-2, 0)) @ rot_x(f(0.8, 1.5)) @ h.scale(f(1, 3), f(1, 2), 1.0)
+        rect = h.make_object(abi.RM_RECTANGLE, model=ctm, scale_factor=1.0)
+        rect.isEmissive, rect.lightIdx = 1, len(lights)
+        area = h.make_light(abi.RM_LIGHT_AREA, tuple(f(.5, 1.2, 3)))
+        area.intensity, area.twoSided = float(rng.choice([0.0, 0.7])), int(rng.integers(0, 2))
+        for k, c in enumerate([(-0.5, 0.5, 0), (0.5, 0.5, 0), (0.5, -0.5, 0), (-0.5, -0.5, 0)]):
+            w = ctm @ np.array([*c, 1.0])
+            for j in range(3):
+                area.points[k][j], rect.color[j] = float(np.float32(w[j])), area.color[j]
+        objs.append(rect)
+        lights.append(area)
+        t1, t2 = synthetic_ltc()
+        res["ltc1"], res["ltc2"] = h.oracle_ltc_quantise(t1), h.oracle_ltc_quantise(t2)
+    feats = int(rng.choice([abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND, 0, abi.RM_FEAT_SKY_BACKGROUND,
+                            abi.RM_FEAT_NIGHTSKY_BACKGROUND]))
+    if f() < 0.6:
+        feats |= abi.RM_FEAT_PERLIN_BUMP
+    if f() < 0.15:
+        feats |= abi.RM_FEAT_SEA
+    if f() < 0.3:
+        feats |= abi.RM_FEAT_BULB_POWER8_ALGEBRAIC
+    if feats & (abi.RM_FEAT_NIGHTSKY_BACKGROUND | abi.RM_FEAT_SEA):
+        res["noise"] = synthetic_noise()
+    sky = f() < 0.25
+    if sky:
+        res["skybox"] = synthetic_skybox(12)
+    s = abi.default_settings(features=feats, enableSoftShadow=int(f() < 0.3), enableAmbientOcclusion=int(f() < 0.4),
+                             enableReflection=int(f() < 0.5), enableRefraction=int(f() < 0.4), enableSkyBox=int(sky),
+                             maxSteps=int(rng.choice([64, 128, 256])), fractalIters=int(rng.choice([6, 12, 20])),
+                             mengerLevels=int(rng.choice([3, 4, 5])), numReflection=int(rng.choice([1, 2, 3])))
+    g = h.make_globals(ka=f(.2, .8), kd=f(.3, 1), ks=f(.2, 1), kt=f(.2, 1), power=float(rng.choice([8.0, 8.0, 6.0, 5.5, 2.0])),
+                       julia=(f(-.5, .5), f(-.5, .5)) if f() < 0.2 else (0, 0), itime=float(f(0, 9)))
+    cam = h.make_camera((f(-1, 1), f(0.5, 2.5), f(4.5, 6.5)), (f(-.15, .15), f(-.45, -.05), -1), (0, 1, 0), float(f(35, 60)), W, H)
+    scene = (cam, (abi.RmObject * len(objs))(*objs), len(objs), (abi.RmLight * len(lights))(*lights), len(lights), g)
+    return scene, s, res
+
+
+def test_random_scenes_bit_exact(renderer):
+    """24 seeded random scenes over the whole ABI surface (every primitive and fractal type, all four light kinds, object
+    textures, sky box, night sky, sea, every option and loop-bound knob): the GPU equals the oracle in every bit."""
+    W, H = 56, 40
+    rng = np.random.default_rng(20261003)
+    kinds = set()
+    for i in range(24):
+        scene, s, res = _random_case(rng, W, H)
+        ref, ref_b = h.oracle_render(scene, s, W, H, bright=True, **res)
+        t = tables_of(scene)
+        for k, v in res.items():
+            setattr(t, k, v)
+        out, br = renderer.render(t, s, W, H, bright=True)
+        assert_bit_equal(out.cpu().numpy(), ref, f"random scene {i}")
+        assert_bit_equal(br.cpu().numpy(), ref_b, f"random scene {i} bright")
+        kinds |= {scene[1][k].type for k in range(scene[2])}
+    assert len(kinds) >= 10
