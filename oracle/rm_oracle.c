@@ -6,10 +6,13 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.  The product
  * (raymarcher_amd/csrc) never links or calls it.
  *
- * PARITY STATUS: the reference has no tests or golden vectors for this path and its GLSL cannot be
- * run unmodified in this container, so this restatement is pinned by (i) analytic known-answer
- * tests, (ii) the SwiftShader cross-check fixtures under tests/golden/ (see oracle/tools/), and
- * (iii) accuracy tests of rm_math.h against libm — see DESIGN.md §2 for what is and is not pinned.
+ * PARITY STATUS: the reference has no tests or golden vectors for this path ("parity unpinned" by the
+ * reference's own fixtures) and its desktop-GL shaders cannot be run unmodified in this container.  This
+ * restatement is pinned instead by (i) outputs of the reference's OWN shaders executed here on a software
+ * GLES rasteriser after a mechanical ESSL adaptation (tests/golden/glsl/: 24 frames, 14 function probes,
+ * 6 post-pass cases; generator oracle/tools/gen_glsl_goldens.py), (ii) analytic known-answer tests and
+ * float64 models, (iii) accuracy tests of rm_math.h against libm — DESIGN.md §2 lists what each pins and how
+ * tightly.  The host tables (loader, camera) are pinned by the reference's own loader built as-is (oracle/ref).
  *
  * Numeric contract: oracle/rm_math.h (scalar built-ins) + the vector forms below.  Build with
  * -ffp-contract=off: an fma appears only where rm_fma is written.
@@ -19,7 +22,9 @@
  *   UB2 raymarch miss:   res.d = rayDepth ("distance travelled along ray direction", frag:190-191)
  *   UB3 sdScene trap:    the trap of the LAST fractal object evaluated, as written (frag:1419-1428)
  *   UB4 unknown / CUSTOM type: object is skipped (never nearest)
- *   UB5 emissive objects / area lights: rejected by the host (out of scope)
+ *   UB5 emissive hit then objects[-1] (frag:2341, 2483): the out-of-range uniform read is zeros (no secondary rays)
+ *   UB7 seaRender's bare `return;` (frag:2290): returns ri as filled so far; SEA_TIME = 1 + iTime*0.5
+ *   UB8 LTC table filter undefined in divergent flow: GL_LINEAR; 8-bit storage of the unsized GL_RGBA upload
  *   UB9 2-D mode BrightColor: (0,0,0,1)
  *   UB10 cloudsMap leaves `nnd` unset outside the cloud: nnd = -d always (iq's original order)
  */
