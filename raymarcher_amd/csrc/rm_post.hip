@@ -57,6 +57,55 @@ __global__ void blur_kernel(const half4 *__restrict__ src, half4 *__restrict__ d
   dst[(size_t)y * W + x] = half4{__float2half_rn(r), __float2half_rn(g), __float2half_rn(b), __float2half_rn(1.0f)};
 }
 
+// One horizontal pass followed by one vertical pass (blur.frag twice) in a single launch: the source tile with its
+// 4-texel apron is staged in LDS once, the horizontal result — rounded to binary16 exactly as the ping-pong target
+// would store it — stays in LDS, and the vertical taps read it from there.  Same arithmetic, same order, same two
+// roundings per pass as two blur_kernel launches; global traffic per pair drops from 2×(9 L2 reads + 1 write) per
+// pixel to 1.4 reads + 1 write.  Rows/columns outside the image replicate the edge (CLAMP_TO_EDGE) by clamping the
+// GLOBAL coordinate when the tile is staged, which is what clamping each tap does.
+constexpr int kBlurTW = 64, kBlurTH = 32, kBlurR = 4;
+__global__ __launch_bounds__(256) void blur_pair_kernel(const half4 *__restrict__ src, half4 *__restrict__ dst, int W, int H) {
+  constexpr int SW = kBlurTW + 2 * kBlurR, SH = kBlurTH + 2 * kBlurR;  // staged source: 72 × 40
+  __shared__ half4 s_src[SH][SW];
+  __shared__ half4 s_h[SH][kBlurTW];
+  const float w[5] = {0.2270270270f, 0.1945945946f, 0.1216216216f, 0.0540540541f, 0.0162162162f};
+  const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
+  for (int i = threadIdx.x; i < SW * SH; i += 256) {
+    const int lx = i % SW, ly = i / SW;
+    s_src[ly][lx] = src[(size_t)clampi(y0 - kBlurR + ly, H) * W + clampi(x0 - kBlurR + lx, W)];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBlurTW * SH; i += 256) {  // horizontal pass on every staged row
+    const int lx = i % kBlurTW, ly = i / kBlurTW;
+    const half4 c = s_src[ly][lx + kBlurR];
+    float r = __half2float(c.x) * w[0], g = __half2float(c.y) * w[0], b = __half2float(c.z) * w[0];
+#pragma unroll
+    for (int k = 1; k < 5; k++) {
+      const half4 p = s_src[ly][lx + kBlurR + k], m = s_src[ly][lx + kBlurR - k];
+      r = fma(__half2float(p.x), w[k], r); g = fma(__half2float(p.y), w[k], g); b = fma(__half2float(p.z), w[k], b);
+      r = fma(__half2float(m.x), w[k], r); g = fma(__half2float(m.y), w[k], g); b = fma(__half2float(m.z), w[k], b);
+    }
+    asm volatile("" : "+v"(r), "+v"(g), "+v"(b));  // binary32 first, then binary16 (see blur_kernel)
+    s_h[ly][lx] = half4{__float2half_rn(r), __float2half_rn(g), __float2half_rn(b), __float2half_rn(1.0f)};
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBlurTW * kBlurTH; i += 256) {  // vertical pass on the tile
+    const int lx = i % kBlurTW, ly = i / kBlurTW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= W || y >= H) continue;
+    const half4 c = s_h[ly + kBlurR][lx];
+    float r = __half2float(c.x) * w[0], g = __half2float(c.y) * w[0], b = __half2float(c.z) * w[0];
+#pragma unroll
+    for (int k = 1; k < 5; k++) {
+      const half4 p = s_h[ly + kBlurR + k][lx], m = s_h[ly + kBlurR - k][lx];
+      r = fma(__half2float(p.x), w[k], r); g = fma(__half2float(p.y), w[k], g); b = fma(__half2float(p.z), w[k], b);
+      r = fma(__half2float(m.x), w[k], r); g = fma(__half2float(m.y), w[k], g); b = fma(__half2float(m.z), w[k], b);
+    }
+    asm volatile("" : "+v"(r), "+v"(g), "+v"(b));
+    dst[(size_t)y * W + x] = half4{__float2half_rn(r), __float2half_rn(g), __float2half_rn(b), __float2half_rn(1.0f)};
+  }
+}
+
 // hdr.frag:13-35.  Writes either the float frame (no FXAA afterwards) or the RGBA8 FXAA source.
 __global__ void light_kernel(const float4 *__restrict__ frag, const half4 *__restrict__ bloom, float4 *__restrict__ outF,
                              uchar4 *__restrict__ out8, int n, int hdr, int useBloom, float exposure) {
@@ -231,13 +280,13 @@ extern "C" int rm_post_process(const float *d_frag, const float *d_bright, float
     if (ps->enableBloom) {  // applyBloom: 10 passes H,V,H,…; the composite reads the buffer pass 9 wrote
       hipLaunchKernelGGL(bright_to_half_kernel, lin, blk, 0, st, reinterpret_cast<const float4 *>(d_bright), pa, (int)n);
       half4 *src = pa, *dst = pb;
-      int horizontal = 1;
-      for (int i = 0; i < 9; i++) {
-        hipLaunchKernelGGL(blur_kernel, grid2, blk, 0, st, src, dst, W, H, horizontal);
+      const dim3 tiles((W + kBlurTW - 1) / kBlurTW, (H + kBlurTH - 1) / kBlurTH);
+      for (int i = 0; i < 4; i++) {  // passes 1-8 as four horizontal+vertical pairs through LDS
+        hipLaunchKernelGGL(blur_pair_kernel, tiles, blk, 0, st, src, dst, W, H);
         half4 *t = src; src = dst; dst = t;
-        horizontal = !horizontal;
       }
-      bloom = src;
+      hipLaunchKernelGGL(blur_kernel, grid2, blk, 0, st, src, dst, W, H, 1);  // pass 9 (horizontal), the one composited
+      bloom = dst;
     }
     hipLaunchKernelGGL(light_kernel, lin, blk, 0, st, frag, bloom, out, ps->enableFXAA ? stage8 : nullptr, (int)n,
                        ps->enableHDR, ps->enableBloom, ps->exposure);
