@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_objs);
     for (int i = threadIdx.x; i < nd; i += 256) dst[i] = src[i];
   }
+  // the launches that read samplers build the byte→unorm table (wave-uniform condition; ends with a barrier)
+  if (TEX || (ENV && (sb->s.features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)))) initUnormTable();
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int x = blockIdx.x * kBlockW + wave * kTileW + (lane % kTileW);

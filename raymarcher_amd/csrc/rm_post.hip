@@ -136,15 +136,17 @@ __global__ void quant8_kernel(const float4 *__restrict__ frag, uchar4 *__restric
   out8[i] = make_uchar4(to8(f.x), to8(f.y), to8(f.z), 255);
 }
 
-// GL_LINEAR / GL_REPEAT fetch of the RGBA8 FXAA source at normalised (u, v)
-__device__ __forceinline__ V3 fetch8(const uchar4 *__restrict__ img, int W, int H, float u, float v) {
+// GL_LINEAR / GL_REPEAT fetch of the RGBA8 FXAA source at normalised (u, v).  `unorm` is the 256-entry table byte/255
+// (each entry the correctly rounded quotient, so a lookup equals the division bit for bit): twelve IEEE divisions per
+// fetch — ≈130 VALU instructions — become twelve LDS reads.
+__device__ __forceinline__ V3 fetch8(const uchar4 *__restrict__ img, const float *unorm, int W, int H, float u, float v) {
   float fx = fma(u, (float)W, -0.5f), fy = fma(v, (float)H, -0.5f);
   float x0 = floor_(fx), y0 = floor_(fy);
   float a = fx - x0, b = fy - y0;
   int i0 = wrapIndex(x0, W), j0 = wrapIndex(y0, H);
   int i1 = (i0 + 1 == W) ? 0 : i0 + 1, j1 = (j0 + 1 == H) ? 0 : j0 + 1;
   uchar4 p00 = img[(size_t)j0 * W + i0], p10 = img[(size_t)j0 * W + i1], p01 = img[(size_t)j1 * W + i0], p11 = img[(size_t)j1 * W + i1];
-  auto f = [](unsigned char q) { return (float)q / 255.0f; };
+  auto f = [&](unsigned char q) { return unorm[q]; };
   return v3(mix_(mix_(f(p00.x), f(p10.x), a), mix_(f(p01.x), f(p11.x), a), b),
             mix_(mix_(f(p00.y), f(p10.y), a), mix_(f(p01.y), f(p11.y), a), b),
             mix_(mix_(f(p00.z), f(p10.z), a), mix_(f(p01.z), f(p11.z), a), b));
@@ -153,12 +155,15 @@ __device__ __forceinline__ float rgb2luma(V3 c) { return sqrt_(dot(c, v3(0.299f,
 
 // fxaa.frag:22-166
 __global__ void fxaa_kernel(const uchar4 *__restrict__ img, float4 *__restrict__ out, int W, int H) {
+  __shared__ float s_unorm[256];
+  s_unorm[threadIdx.x] = (float)threadIdx.x / 255.0f;  // blockDim.x == 256
+  __syncthreads();
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
   const float quality[12] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.5f, 2.0f, 2.0f, 2.0f, 2.0f, 4.0f, 8.0f};
   const float invW = 1.0f / (float)W, invH = 1.0f / (float)H;
   const float tu = ((float)x + 0.5f) / (float)W, tv = ((float)y + 0.5f) / (float)H;
-  auto texOff = [&](int dx, int dy) { return fetch8(img, W, H, tu + (float)dx * invW, tv + (float)dy * invH); };
+  auto texOff = [&](int dx, int dy) { return fetch8(img, s_unorm, W, H, tu + (float)dx * invW, tv + (float)dy * invH); };
   V3 colorCenter = texOff(0, 0);
   V3 result = colorCenter;
   float lumaCenter = rgb2luma(colorCenter);
@@ -190,16 +195,16 @@ __global__ void fxaa_kernel(const uchar4 *__restrict__ img, float4 *__restrict__
     if (isHorizontal) cv = fma(stepLength, 0.5f, cv); else cu = fma(stepLength, 0.5f, cu);
     float ox = isHorizontal ? invW : 0.0f, oy = isHorizontal ? 0.0f : invH;
     float u1 = cu - ox, v1 = cv - oy, u2 = cu + ox, v2 = cv + oy;
-    float lumaEnd1 = rgb2luma(fetch8(img, W, H, u1, v1)) - lumaLocalAverage;
-    float lumaEnd2 = rgb2luma(fetch8(img, W, H, u2, v2)) - lumaLocalAverage;
+    float lumaEnd1 = rgb2luma(fetch8(img, s_unorm, W, H, u1, v1)) - lumaLocalAverage;
+    float lumaEnd2 = rgb2luma(fetch8(img, s_unorm, W, H, u2, v2)) - lumaLocalAverage;
     bool reached1 = fabs_(lumaEnd1) >= gradientScaled, reached2 = fabs_(lumaEnd2) >= gradientScaled;
     bool reachedBoth = reached1 && reached2;
     if (!reached1) { u1 -= ox; v1 -= oy; }
     if (!reached2) { u2 += ox; v2 += oy; }
     if (!reachedBoth) {
       for (int i = 2; i < 12; i++) {
-        if (!reached1) lumaEnd1 = rgb2luma(fetch8(img, W, H, u1, v1)) - lumaLocalAverage;
-        if (!reached2) lumaEnd2 = rgb2luma(fetch8(img, W, H, u2, v2)) - lumaLocalAverage;
+        if (!reached1) lumaEnd1 = rgb2luma(fetch8(img, s_unorm, W, H, u1, v1)) - lumaLocalAverage;
+        if (!reached2) lumaEnd2 = rgb2luma(fetch8(img, s_unorm, W, H, u2, v2)) - lumaLocalAverage;
         reached1 = fabs_(lumaEnd1) >= gradientScaled;
         reached2 = fabs_(lumaEnd2) >= gradientScaled;
         reachedBoth = reached1 && reached2;
@@ -223,7 +228,7 @@ __global__ void fxaa_kernel(const uchar4 *__restrict__ img, float4 *__restrict__
     finalOffset = max_(finalOffset, subFinal);
     float fu = tu, fv = tv;
     if (isHorizontal) fv = fma(finalOffset * stepLength, 1.0f, fv); else fu = fma(finalOffset * stepLength, 1.0f, fu);
-    result = fetch8(img, W, H, fu, fv);
+    result = fetch8(img, s_unorm, W, H, fu, fv);
   }
   out[(size_t)y * W + x] = make_float4(result.x, result.y, result.z, 1.0f);
 }

@@ -43,10 +43,11 @@ def main():
     rows = ["| configuration | kernel ms | Mpixels/s |", "|---|---|---|"]
     for name, t, s, W, H in cases:
         out = torch.empty((H, W, 4), dtype=torch.float32, device=r.device)
-        r.render(t, s, W, H, out=out)
+        for _ in range(3):
+            r.render(t, s, W, H, out=out)
         torch.cuda.synchronize()
         L.rm_set_timing(1)
-        n = 5
+        n = 10
         for _ in range(n):
             r.render(t, s, W, H, out=out)
         torch.cuda.synchronize()
