@@ -342,7 +342,9 @@ int rm_scene_camera_data(const RmScene *scene, RmCameraData *out);
 const char *rm_scene_object_texture(const RmScene *scene, int i);
 
 /* Image file → RGBA8 (stands in for QImage::load + convertToFormat(RGBA8888) + mirrored(), raymarchscene.cpp:198-209).
- * PNG only (8/16-bit grey, grey+alpha, RGB, RGBA, palette; non-interlaced).  flipVertical = 1 gives the bottom-up
+ * PNG (8/16-bit grey, grey+alpha, RGB, RGBA, palette; non-interlaced) and baseline JPEG (grayscale or YCbCr, 4:4:4 /
+ * 4:2:2 / 4:2:0; decoded with libjpeg's default arithmetic — islow IDCT, fancy upsampling — so the pixels equal
+ * QImage's).  Other formats, progressive JPEG: RM_ERR_UNSUPPORTED.  flipVertical = 1 gives the bottom-up
  * rows the renderer expects.  *outPixels is malloc'ed host memory of w·h·4 bytes; free with rm_image_free. */
 int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *w, int *h);
 void rm_image_free(uint8_t *pixels);
@@ -350,8 +352,7 @@ void rm_image_free(uint8_t *pixels);
 /* Sky-box selection of the GUI (settings.idxSkyBox → RayMarchScene::getCubeMapWithType, raymarchscene.cpp:50-86;
  * enum CUBEMAP, scenedata.h:43-48): path of face `face` (0..5, the order of RmResources.skybox) of cube map `which`
  * (1 BEACH, 2 NIGHTSKY, 3 ISLAND) relative to the scenefiles directory, or NULL.  Reproduced as written, including the
- * NIGHTSKY list naming −x before +x and −y before +y.  The BEACH faces are JPEG files, which rm_image_load does not
- * decode: the caller supplies decoded pixels. */
+ * NIGHTSKY list naming −x before +x and −y before +y.  Load each with rm_image_load(path, 1, …) as initCubeMap does. */
 const char *rm_skybox_face_path(int which, int face);
 
 /* PNG writer for RGBA8 rows (top row first) — stands in for QImage::save (realtime.cpp:346). */

@@ -166,9 +166,21 @@ int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *
   size_t n;
   while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
   std::fclose(f);
+  if (file.size() >= 4 && file[0] == 0xFF && file[1] == 0xD8) {  // JPEG (rm_jpeg.cpp)
+    std::vector<uint8_t> px;
+    int jw = 0, jh = 0;
+    int st = jpeg_decode(file, px, jw, jh);
+    if (st != RM_OK) return st;
+    uint8_t *o = static_cast<uint8_t *>(std::malloc(px.size()));
+    if (!o) { set_error("out of memory"); return RM_ERR_IO; }
+    const size_t rowBytes = (size_t)jw * 4;
+    for (int y = 0; y < jh; y++) std::memcpy(o + (size_t)(flipVertical ? jh - 1 - y : y) * rowBytes, &px[(size_t)y * rowBytes], rowBytes);
+    *outPixels = o; *w = jw; *h = jh;
+    return RM_OK;
+  }
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
   if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) {
-    set_error(std::string(path) + ": not a PNG file (only PNG textures are supported)");
+    set_error(std::string(path) + ": neither a PNG nor a JPEG file");
     return RM_ERR_UNSUPPORTED;
   }
   uint32_t W = 0, H = 0;

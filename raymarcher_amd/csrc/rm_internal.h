@@ -3,6 +3,8 @@
 #include <initializer_list>
 #include <string>
 #include <utility>
+#include <vector>
+#include <cstdint>
 
 #ifndef __HIPCC__
 #define __host__
@@ -20,6 +22,9 @@ void set_error(const std::string &msg);
 bool device_accessible(const void *p);
 // RM_ERR_INVALID_ARGUMENT (+ rm_last_error text) unless every non-null pointer of the list is device-accessible.
 int require_device_pointers(std::initializer_list<std::pair<const char *, const void *>> ptrs);
+
+// Baseline JPEG → RGBA8, top row first (rm_jpeg.cpp).
+int jpeg_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, int &W, int &H);
 
 // Rows owned by `shard` when an H-row frame is cut into tiles of tileRows rows dealt round-robin.
 __host__ __device__ inline int shard_rows(int H, int tileRows, int shard, int numShards) {

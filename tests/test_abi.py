@@ -127,10 +127,14 @@ def test_png_reader_matches_pillow(tmp_path, mode, bits):
 def test_png_reader_errors(tmp_path):
     from raymarcher_amd import RaymarcherError
     from raymarcher_amd.render import load_image
+    (tmp_path / "x.gif").write_bytes(b"GIF89a" + b"0" * 64)
+    with pytest.raises(RaymarcherError) as e:
+        load_image(tmp_path / "x.gif")
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"0" * 64)
     with pytest.raises(RaymarcherError) as e:
         load_image(tmp_path / "x.jpg")
-    assert e.value.status == abi.RM_ERR_UNSUPPORTED
+    assert e.value.status == abi.RM_ERR_PARSE
     with pytest.raises(RaymarcherError) as e:
         load_image(tmp_path / "missing.png")
     assert e.value.status == abi.RM_ERR_IO
@@ -159,3 +163,49 @@ def test_skybox_face_paths():
     assert [L.rm_skybox_face_path(2, f).decode()[-6:-4] for f in range(6)] == ["-x", "+x", "-y", "+y", "+z", "-z"]
     assert [L.rm_skybox_face_path(3, f).decode()[-6:-4] for f in range(6)] == ["+x", "-x", "+y", "-y", "+z", "-z"]
     assert L.rm_skybox_face_path(0, 0) is None and L.rm_skybox_face_path(4, 0) is None and L.rm_skybox_face_path(1, 6) is None
+
+
+@pytest.mark.parametrize("size,subsampling,quality,mode", [
+    ((64, 64), 0, 90, "RGB"), ((37, 23), 0, 75, "RGB"), ((64, 48), 1, 85, "RGB"), ((37, 23), 1, 60, "RGB"),
+    ((64, 64), 2, 90, "RGB"), ((37, 23), 2, 75, "RGB"), ((259, 380), 2, 92, "RGB"), ((512, 512), 2, 80, "RGB"),
+    ((1, 1), 2, 75, "RGB"), ((3, 5), 2, 75, "RGB"), ((5, 3), 1, 75, "RGB"), ((40, 31), 0, 75, "L"), ((17, 1), 2, 30, "RGB")])
+def test_jpeg_reader_matches_libjpeg(tmp_path, size, subsampling, quality, mode):
+    """rm_image_load on baseline JPEG files (the reference's "Beach" sky box and one texture are JPEGs read by QImage →
+    libjpeg): the pixels equal libjpeg-turbo's (Pillow) value for value — islow IDCT, fancy upsampling of 4:2:2 / 4:2:0
+    chroma (box replication for planes at most two samples wide), 16-bit fixed-point YCbCr → RGB."""
+    from PIL import Image
+    from raymarcher_amd.render import load_image
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H + subsampling)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx * 5 + yy * 9) % 256)], -1).astype(np.int32)
+    img = np.clip(img + rng.integers(-40, 41, img.shape), 0, 255).astype(np.uint8)  # noise exercises every AC coefficient
+    im = Image.fromarray(img, "RGB").convert(mode)
+    path = tmp_path / "t.jpg"
+    kw = {} if mode == "L" else {"subsampling": subsampling}
+    im.save(path, "JPEG", quality=quality, **kw)
+    exp = np.asarray(Image.open(path).convert("RGBA"))
+    got = load_image(path, flip_vertical=False)
+    assert got.shape == exp.shape
+    assert (got == exp).all(), f"max |Δ| {np.abs(got.astype(int) - exp.astype(int)).max()} on {(got != exp).any(-1).mean():.3%} of the pixels"
+    assert (load_image(path, flip_vertical=True) == exp[::-1]).all()
+
+
+def test_jpeg_reader_restart_markers_and_refusals(tmp_path):
+    from PIL import Image
+    from raymarcher_amd import RaymarcherError
+    from raymarcher_amd.render import load_image
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    path = tmp_path / "r.jpg"
+    try:
+        Image.fromarray(img).save(path, "JPEG", quality=80, subsampling=2, restart_marker_blocks=3)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    assert b"\xff\xdd" in path.read_bytes()
+    assert (load_image(path, flip_vertical=False) == np.asarray(Image.open(path).convert("RGBA"))).all()
+    prog = tmp_path / "p.jpg"
+    Image.fromarray(img).save(prog, "JPEG", progressive=True)
+    with pytest.raises(RaymarcherError) as e:
+        load_image(prog)
+    assert e.value.status == abi.RM_ERR_UNSUPPORTED
