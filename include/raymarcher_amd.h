@@ -344,7 +344,7 @@ const char *rm_scene_object_texture(const RmScene *scene, int i);
 /* Image file → RGBA8 (stands in for QImage::load + convertToFormat(RGBA8888) + mirrored(), raymarchscene.cpp:198-209).
  * PNG (8/16-bit grey, grey+alpha, RGB, RGBA, palette; non-interlaced) and baseline JPEG (grayscale or YCbCr, 4:4:4 /
  * 4:2:2 / 4:2:0; decoded with libjpeg's default arithmetic — islow IDCT, fancy upsampling — so the pixels equal
- * QImage's).  Other formats, progressive JPEG: RM_ERR_UNSUPPORTED.  flipVertical = 1 gives the bottom-up
+ * QImage's) and the first frame of a GIF.  Other formats, progressive JPEG: RM_ERR_UNSUPPORTED.  flipVertical = 1 gives the bottom-up
  * rows the renderer expects.  *outPixels is malloc'ed host memory of w·h·4 bytes; free with rm_image_free. */
 int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *w, int *h);
 void rm_image_free(uint8_t *pixels);

@@ -166,10 +166,12 @@ int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *
   size_t n;
   while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
   std::fclose(f);
-  if (file.size() >= 4 && file[0] == 0xFF && file[1] == 0xD8) {  // JPEG (rm_jpeg.cpp)
+  const bool isJpeg = file.size() >= 4 && file[0] == 0xFF && file[1] == 0xD8;
+  const bool isGif = file.size() >= 6 && !std::memcmp(file.data(), "GIF8", 4);
+  if (isJpeg || isGif) {  // rm_jpeg.cpp / rm_gif.cpp
     std::vector<uint8_t> px;
     int jw = 0, jh = 0;
-    int st = jpeg_decode(file, px, jw, jh);
+    int st = isJpeg ? jpeg_decode(file, px, jw, jh) : gif_decode(file, px, jw, jh);
     if (st != RM_OK) return st;
     uint8_t *o = static_cast<uint8_t *>(std::malloc(px.size()));
     if (!o) { set_error("out of memory"); return RM_ERR_IO; }
@@ -180,7 +182,7 @@ int rm_image_load(const char *path, int flipVertical, uint8_t **outPixels, int *
   }
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
   if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) {
-    set_error(std::string(path) + ": neither a PNG nor a JPEG file");
+    set_error(std::string(path) + ": not a PNG, JPEG or GIF file");
     return RM_ERR_UNSUPPORTED;
   }
   uint32_t W = 0, H = 0;

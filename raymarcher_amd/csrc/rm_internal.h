@@ -25,6 +25,8 @@ int require_device_pointers(std::initializer_list<std::pair<const char *, const 
 
 // Baseline JPEG → RGBA8, top row first (rm_jpeg.cpp).
 int jpeg_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, int &W, int &H);
+// First frame of a GIF → RGBA8, top row first (rm_gif.cpp).
+int gif_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, int &W, int &H);
 
 // Rows owned by `shard` when an H-row frame is cut into tiles of tileRows rows dealt round-robin.
 __host__ __device__ inline int shard_rows(int H, int tileRows, int shard, int numShards) {

@@ -127,9 +127,9 @@ def test_png_reader_matches_pillow(tmp_path, mode, bits):
 def test_png_reader_errors(tmp_path):
     from raymarcher_amd import RaymarcherError
     from raymarcher_amd.render import load_image
-    (tmp_path / "x.gif").write_bytes(b"GIF89a" + b"0" * 64)
+    (tmp_path / "x.bmp").write_bytes(b"BM" + b"0" * 64)
     with pytest.raises(RaymarcherError) as e:
-        load_image(tmp_path / "x.gif")
+        load_image(tmp_path / "x.bmp")
     assert e.value.status == abi.RM_ERR_UNSUPPORTED
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"0" * 64)
     with pytest.raises(RaymarcherError) as e:
@@ -209,3 +209,30 @@ def test_jpeg_reader_restart_markers_and_refusals(tmp_path):
     with pytest.raises(RaymarcherError) as e:
         load_image(prog)
     assert e.value.status == abi.RM_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("size,colors,interlace,transparent", [((61, 30), 256, False, False), ((33, 47), 16, False, False),
+                                                              ((64, 64), 2, False, False), ((50, 41), 200, True, False),
+                                                              ((40, 40), 64, False, True), ((361, 300), 256, False, False)])
+def test_gif_reader_matches_pillow(tmp_path, size, colors, interlace, transparent):
+    """First frame of a GIF (one reference texture is a single-frame GIF): LZW, colour tables, interlace, transparency."""
+    from PIL import Image
+    from raymarcher_amd.render import load_image
+    W, H = size
+    rng = np.random.default_rng(W + H + colors)
+    yy, xx = np.mgrid[0:H, 0:W]
+    idx = ((xx // 3 + yy // 2 + rng.integers(0, 3, (H, W))) % colors).astype(np.uint8)
+    im = Image.fromarray(idx, "P")
+    pal = rng.integers(0, 256, 768, dtype=np.uint8)
+    im.putpalette(list(pal))
+    path = tmp_path / "t.gif"
+    kw = {"interlace": interlace}
+    if transparent:
+        kw["transparency"] = 3
+    im.save(path, "GIF", **kw)
+    exp = np.asarray(Image.open(path).convert("RGBA")).copy()
+    got = load_image(path, flip_vertical=False)
+    assert got.shape == exp.shape
+    opaque = exp[..., 3] == 255
+    assert (got[opaque] == exp[opaque]).all()
+    assert (got[~opaque][:, 3] == 0).all() and (~opaque).any() == transparent
