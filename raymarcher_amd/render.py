@@ -9,7 +9,7 @@ import ctypes as C
 from dataclasses import dataclass
 
 from . import abi
-from ._lib import check, lib
+from ._lib import RaymarcherError, check, lib
 
 
 @dataclass
@@ -132,7 +132,16 @@ class Scene:
         textures = {}
         for i in range(no if load_textures else 0):
             if objs[i].texLoc >= 0 and objs[i].texLoc not in textures:
-                textures[objs[i].texLoc] = load_image(self.texture_of(i), flip_vertical=True)
+                try:
+                    textures[objs[i].texLoc] = load_image(self.texture_of(i), flip_vertical=True)
+                except RaymarcherError as e:
+                    if e.status != abi.RM_ERR_IO:
+                        raise
+                    # a texture file that is not there: the reference prints "Failed to load in image", still creates the GL
+                    # texture (initShapesTextures, realtimerender.cpp:266-303) and samples the incomplete texture, which
+                    # reads (0,0,0,1) — a 1×1 black texel gives the same samples
+                    import numpy as np
+                    textures[objs[i].texLoc] = np.array([[[0, 0, 0, 255]]], dtype=np.uint8)
         tex_list = [textures[k] for k in sorted(textures)] if textures else None
         return SceneTables(cam, objs, no, lights, nl, g, tex_list)
 

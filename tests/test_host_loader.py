@@ -137,3 +137,42 @@ def test_camera_against_independent_numpy_restatement():
         assert close(view, v.T.reshape(-1), rel=1e-5, abs_=1e-6)
         assert close(proj, p.T.reshape(-1), rel=1e-5, abs_=1e-8)
         assert close(list(cam.invProjView), inv.T.reshape(-1), rel=1e-4, abs_=1e-3)
+
+
+REF_SCENES = "/root/reference/scenefiles"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="the reference checkout (with its texture_store) is only in the build container")
+def test_every_textured_scenefile_loads_with_its_images():
+    """Container-only integration check: every scenefile of the reference that names a texture loads through the
+    product's loader AND its image files decode (PNG, JPEG, GIF) into the texture slots the renderer will index; one
+    of them is rendered by the oracle.  Also the three sky-box sets of getCubeMapWithType."""
+    import glob
+    from raymarcher_amd import Scene, abi, lib
+    from raymarcher_amd.render import load_image
+    import helpers as h
+    seen, kinds = 0, set()
+    for path in sorted(glob.glob(os.path.join(REF_SCENES, "*", "*.json"))):
+        if "textureFile" not in open(path).read():
+            continue
+        try:
+            sc = Scene(path=path)
+        except Exception:
+            continue  # scenefiles the reference's own loader rejects as well (tests above)
+        t = sc.tables(64, 48)
+        used = {t.objects[i].texLoc for i in range(t.num_objects) if t.objects[i].texLoc >= 0}
+        if not used:
+            continue
+        assert t.textures is not None and len(t.textures) == max(used) + 1, path
+        for a in t.textures:
+            assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 4 and a.size > 0
+        kinds |= {os.path.splitext(sc.texture_of(i))[1].lower() for i in range(t.num_objects) if sc.texture_of(i)}
+        seen += 1
+        if path.endswith("unit_sphere.json"):
+            img = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_),
+                                  abi.default_settings(maxSteps=64), 64, 48, textures=t.textures)
+            assert np.isfinite(img).all() and img[..., :3].std() > 0.05
+    assert seen >= 20 and {".png", ".gif"} <= kinds, (seen, kinds)
+    for which in (1, 2, 3):
+        faces = [load_image(os.path.join(REF_SCENES, lib().rm_skybox_face_path(which, f).decode()), flip_vertical=True) for f in range(6)]
+        assert all(a.shape == faces[0].shape and a.shape[0] == a.shape[1] for a in faces), which
