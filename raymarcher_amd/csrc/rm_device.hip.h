@@ -324,8 +324,36 @@ RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
 // frag:1453-1484 (side = +1 outside, −1 inside) and frag:1703-1725 (SHADOW) share one loop body.
 // SHADOW=false: returns obj, d = rayDepth − minD on a hit, rayDepth on a miss (contract UB2).
 // SHADOW=true : returns obj, d = penumbra factor res (contract UB1), k = 8, start depth 0.
-template <bool BULB, bool COUNT, bool SHADOW>
+//
+// CULL (single-Mandelbulb class only; never in the counted variant, whose counters are the reference's work): a march
+// whose miss distance nobody reads — primary / secondary rays of render(), shadow rays — may stop as soon as the ray
+// has left the ball |p_object| <= 2.1 for good, because it can no longer hit: for power 8 and |p| = ρ >= 2 the first
+// iteration gives |w| >= ρ^8 − max(ρ, |seed|) >= 254, the loop bails out, and the estimate
+// 0.25·ln(m)·√m / (8ρ^7 + 1) >= 0.68 — six hundred times the hit threshold (times scaleFactor >= 0.01) — and it only
+// grows with ρ; for shadow rays 8·d/t >= 1.4 out there, so the penumbra factor (<= 1) is not touched either.  The
+// march therefore ends at min(end, t_exit) with the same obj = −1 (and, for shadows, the same penumbra) it would have
+// reached ~12 evaluations later at t > far.  Rays that never enter the ball stop after their first evaluation.
+RM_DEV float bulbCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
+  const RmObject &o = sb->objs[0];
+  const float jx = sb->g.juliaSeed[0], jy = sb->g.juliaSeed[1];
+  const bool ok = (sb->g.power == 8.0f) && (o.scaleFactor >= 0.01f) && (fma(jx, jx, jy * jy) <= 4.0f);  // wave-uniform
+  if (!ok) return end;
+  const float *M = o.invModel;
+  const V3 po = v3(fma(M[8], ro.z, fma(M[4], ro.y, fma(M[0], ro.x, M[12]))), fma(M[9], ro.z, fma(M[5], ro.y, fma(M[1], ro.x, M[13]))),
+                   fma(M[10], ro.z, fma(M[6], ro.y, fma(M[2], ro.x, M[14]))));
+  const V3 pd = v3(fma(M[8], rd.z, fma(M[4], rd.y, M[0] * rd.x)), fma(M[9], rd.z, fma(M[5], rd.y, M[1] * rd.x)),
+                   fma(M[10], rd.z, fma(M[6], rd.y, M[2] * rd.x)));
+  const float a = dot(pd, pd), b = dot(po, pd), c = dot(po, po) - 4.41f;
+  const float disc = fma(b, b, -(a * c));
+  float tExit = (sqrt_(max_(disc, 0.0f)) - b) / a;
+  tExit = fma(tExit, 1.0001f, 1.0e-3f);
+  if (c > 0.0f && (b >= 0.0f || disc < 0.0f)) tExit = -1.0f;  // outside and never entering
+  if (!(a > 0.0f)) return end;
+  return min_(end, tExit);  // a NaN tExit leaves `end` untouched
+}
+template <bool BULB, bool COUNT, bool SHADOW, bool CULL = false>
 RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
+  if (BULB && CULL && !COUNT) end = bulbCullEnd(sb, ro, rd, end);
   float depth = 0.0f;
   float pen = 1.0f;
   SceneMin c;
@@ -613,7 +641,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
       V3 toL = sub(madd(side2, rd.y + 0.0f, madd(side1, rd.x + 0.0f, p1)), p);
       V3 L = normalize(toL);
       if (dot(N, L) <= 0.005f) continue;
-      MarchRes sh = march<BULB, COUNT, true>(sb, so, L, len(toL), 1.0f, cnt);
+      MarchRes sh = march<BULB, COUNT, true, true>(sb, so, L, len(toL), 1.0f, cnt);
       if (sh.obj != -1 && objs[sh.obj].lightIdx != i) continue;  // only the light's own rectangle may be "in the way"
       total = add(total, getAreaLight(sb, N, V, p, li, mat));
       continue;
@@ -624,7 +652,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
     // work so that the counters stay the algorithmic ones).
     MarchRes sh;
     sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
+    if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
     V3 cur;
     if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
@@ -646,7 +674,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
                         V3 bg, Counters &cnt) {
   RenderOut out;
   info.obj = -1;
-  MarchRes res = march<BULB, COUNT, false>(sb, ro, rd, maxT, side, cnt);
+  MarchRes res = march<BULB, COUNT, false, true>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
   if (res.obj == -1) {
     out.col = (TEX && sb->s.enableSkyBox) ? sampleCube(sb->skybox, rd) : bg;  // frag:2325-2327
     out.isEnv = 1;
