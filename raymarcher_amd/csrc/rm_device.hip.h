@@ -65,6 +65,11 @@ struct SceneBlock {
   RmTexture noise;                 // `noise` (night sky, sea)
   RmTexture skybox[6];             // cube-map faces +X,-X,+Y,-Y,+Z,-Z
   const uint8_t *ltc1, *ltc2;      // RM_LTC_SIZE² RGBA8 tables of the area lights
+  // World-space ball outside which no object can be hit (computed by the launcher, see scene_cull_ball); cullOk = 0
+  // when the scene holds an object without a known bound.
+  float cullC[3];
+  float cullR2;
+  int32_t cullOk;
 };
 
 struct SceneMin { int idx; float d; V4 trap; };
@@ -351,9 +356,25 @@ RM_DEV float bulbCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
   if (!(a > 0.0f)) return end;
   return min_(end, tExit);  // a NaN tExit leaves `end` untouched
 }
+// The same idea for any scene: the launcher bounds every object by a world-space ball (exact SDFs are >= the distance
+// to their object's ball; the bound includes a margin δ with minScale·δ >> the hit threshold), and a march whose miss
+// distance is unused ends where its ray leaves the ball around all of them.  Not used for soft-shadow rays, whose
+// penumbra factor min(8·d/t) can still change just outside the ball.
+RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
+  if (!sb->cullOk) return end;  // wave-uniform
+  const V3 po = v3(ro.x - sb->cullC[0], ro.y - sb->cullC[1], ro.z - sb->cullC[2]);
+  const float a = dot(rd, rd), b = dot(po, rd), c = dot(po, po) - sb->cullR2;
+  const float disc = fma(b, b, -(a * c));
+  float tExit = (sqrt_(max_(disc, 0.0f)) - b) / a;
+  tExit = fma(tExit, 1.0001f, 1.0e-3f);
+  if (c > 0.0f && (b >= 0.0f || disc < 0.0f)) tExit = -1.0f;
+  if (!(a > 0.0f)) return end;
+  return min_(end, tExit);
+}
 template <bool BULB, bool COUNT, bool SHADOW, bool CULL = false>
 RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
   if (BULB && CULL && !COUNT) end = bulbCullEnd(sb, ro, rd, end);
+  if (!BULB && CULL && !COUNT && !(SHADOW && sb->s.enableSoftShadow)) end = sceneCullEnd(sb, ro, rd, end);
   float depth = 0.0f;
   float pen = 1.0f;
   SceneMin c;
@@ -622,7 +643,8 @@ RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat
 
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
 // RES = true adds the area-light branch (frag:1884-1905); `objs` is only read there.
-template <bool BULB, bool COUNT, bool RES>
+// CULLS: end marches at the scene's bounding ball (off in the ENV instantiations, whose register budget it would break).
+template <bool BULB, bool COUNT, bool RES, bool CULLS>
 RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
   const float ka = sb->g.ka, ks = sb->g.ks;
   float ao = 1.0f;
@@ -641,7 +663,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
       V3 toL = sub(madd(side2, rd.y + 0.0f, madd(side1, rd.x + 0.0f, p1)), p);
       V3 L = normalize(toL);
       if (dot(N, L) <= 0.005f) continue;
-      MarchRes sh = march<BULB, COUNT, true, true>(sb, so, L, len(toL), 1.0f, cnt);
+      MarchRes sh = march<BULB, COUNT, true, CULLS>(sb, so, L, len(toL), 1.0f, cnt);
       if (sh.obj != -1 && objs[sh.obj].lightIdx != i) continue;  // only the light's own rectangle may be "in the way"
       total = add(total, getAreaLight(sb, N, V, p, li, mat));
       continue;
@@ -652,7 +674,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
     // work so that the counters stay the algorithmic ones).
     MarchRes sh;
     sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
+    if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt);
     V3 cur;
     if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
@@ -669,12 +691,12 @@ RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
 }
 
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
-template <bool BULB, bool COUNT, bool TEX>
+template <bool BULB, bool COUNT, bool TEX, bool CULLS>
 RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
                         V3 bg, Counters &cnt) {
   RenderOut out;
   info.obj = -1;
-  MarchRes res = march<BULB, COUNT, false, true>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
+  MarchRes res = march<BULB, COUNT, false, CULLS>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
   if (res.obj == -1) {
     out.col = (TEX && sb->s.enableSkyBox) ? sampleCube(sb->skybox, rd) : bg;  // frag:2325-2327
     out.isEnv = 1;
@@ -697,7 +719,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   const int type = BULB ? (int)RM_MANDELBULB : o.type;
-  V3 ph = getPhong<BULB, COUNT, TEX>(sb, objs, mat, pn, p, rd, maxT, cnt);
+  V3 ph = getPhong<BULB, COUNT, TEX, CULLS>(sb, objs, mat, pn, p, rd, maxT, cnt);
   V3 col = ph;
   if (type == RM_MANDELBULB) {  // frag:2354-2361
     V3 c = bulbTrapColor(res.trap.y, res.trap.z, res.trap.w);
@@ -768,7 +790,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   const float iTime = sb->g.iTime;
 
   Hit info;
-  RenderOut ri = render<BULB, COUNT, TEX>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
+  RenderOut ri = render<BULB, COUNT, TEX, !ENV>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
   EnvOut e;
   e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
   if (env) e = envLayers(feat, sb->noise, iTime, W, ro, rd, ri.d, bg);  // frag:2444-2456
@@ -801,7 +823,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
       V3 sro = v3(fma(r.x * kSurfaceDist, 3.0f, info.p.x), fma(r.y * kSurfaceDist, 3.0f, info.p.y),
                   fma(r.z * kSurfaceDist, 3.0f, info.p.z));
       fil = mul(fil, cRefl);
-      RenderOut res = render<BULB, COUNT, TEX>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
+      RenderOut res = render<BULB, COUNT, TEX, !ENV>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2506-2518 (a sea hit sets sr.isEnv, not res.isEnv: the bounce loop goes on)
         EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, r, res.d, bg);
         if (b.seaHit) res.col = b.scol;
@@ -826,7 +848,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
     if (len(rdOut) != 0.0f) {
       V3 sro = v3(fma(-(nExit.x * kSurfaceDist), 5.0f, pExit.x), fma(-(nExit.y * kSurfaceDist), 5.0f, pExit.y),
                   fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
-      RenderOut res = render<BULB, COUNT, TEX>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
+      RenderOut res = render<BULB, COUNT, TEX, !ENV>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2555-2567
         EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, rdOut, res.d, bg);
         if (b.seaHit) res.col = b.scol;

@@ -314,6 +314,70 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
   return RM_OK;
 }
 
+// A world-space ball that contains every object, grown by a margin δ such that outside it every object's distance value
+// exceeds the hit threshold by a wide factor (so a march out there can only miss).  Per object: unit-shape radius r in
+// object space (sdMatch's sizes, frag:1262-1293), world centre c = −A⁻¹b and extent r·‖A⁻¹‖_F of the ball's image under
+// the model matrix (A, b = linear part and translation of invModel), and κ = scaleFactor / ‖A⁻¹‖_F, a lower bound of
+// (distance value) / (world distance to the object's ball) for the exact SDFs.  The Mandelbulb (power 8, |seed| <= 2)
+// enters with r = 2.1: beyond it the estimate is >= 0.68·scaleFactor.  Scenes with a type that has no bound here
+// (2-D Mandelbrot, Sierpinski) get cullOk = 0.
+void scene_cull_ball(SceneBlock *h) {
+  h->cullOk = 0;
+  h->cullC[0] = h->cullC[1] = h->cullC[2] = 0.0f;
+  h->cullR2 = 0.0f;
+  const int n = h->numObjects;
+  if (n <= 0) return;
+  static const double kRadius[] = {0.8661, 0.7072, 0.7072, 0.5001, 0.5001, 0.6251, 0.6001, 0.5001, 0.7072};  // cube … rectangle
+  double cx[RM_MAX_OBJECTS], cy[RM_MAX_OBJECTS], cz[RM_MAX_OBJECTS], rad[RM_MAX_OBJECTS];
+  double kappa = 1e30, C[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    const RmObject &o = h->objs[i];
+    double r;
+    if (o.type >= RM_CUBE && o.type <= RM_RECTANGLE) r = kRadius[o.type];
+    else if (o.type == RM_MENGERSPONGE) r = 1.7322;
+    else if (o.type == RM_MANDELBULB) {
+      const double jx = h->g.juliaSeed[0], jy = h->g.juliaSeed[1];
+      if (!(h->g.power == 8.0f) || !(jx * jx + jy * jy <= 4.0) || !(o.scaleFactor >= 0.01f)) return;
+      r = 2.1;
+    } else return;
+    const float *M = o.invModel;
+    const double a[3][3] = {{M[0], M[4], M[8]}, {M[1], M[5], M[9]}, {M[2], M[6], M[10]}};  // a[row][col]
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (!(std::fabs(det) > 1e-12) || !std::isfinite(det)) return;
+    double inv[3][3];
+    inv[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det; inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det;
+    inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det; inv[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det;
+    inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det; inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+    inv[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det; inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det;
+    inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+    double nf = 0.0;
+    for (int r0 = 0; r0 < 3; r0++)
+      for (int c0 = 0; c0 < 3; c0++) nf += inv[r0][c0] * inv[r0][c0];
+    nf = std::sqrt(nf);
+    const double b[3] = {M[12], M[13], M[14]};
+    cx[i] = -(inv[0][0] * b[0] + inv[0][1] * b[1] + inv[0][2] * b[2]);
+    cy[i] = -(inv[1][0] * b[0] + inv[1][1] * b[1] + inv[1][2] * b[2]);
+    cz[i] = -(inv[2][0] * b[0] + inv[2][1] * b[1] + inv[2][2] * b[2]);
+    rad[i] = r * nf;
+    const double k = (o.type == RM_MANDELBULB) ? 1e30 : (double)o.scaleFactor / nf;  // the bulb's 0.68·scaleFactor needs no δ
+    if (!(k > 1e-6) || !std::isfinite(rad[i]) || !std::isfinite(cx[i] + cy[i] + cz[i])) return;
+    kappa = k < kappa ? k : kappa;
+    C[0] += cx[i] / n; C[1] += cy[i] / n; C[2] += cz[i] / n;
+  }
+  double R = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double d = std::sqrt((cx[i] - C[0]) * (cx[i] - C[0]) + (cy[i] - C[1]) * (cy[i] - C[1]) + (cz[i] - C[2]) * (cz[i] - C[2])) + rad[i];
+    R = d > R ? d : R;
+  }
+  const double delta = std::fmax(0.05, 4.0e-3 / kappa);  // κ·δ >= 4× the hit threshold
+  R = (R + delta) * 1.001;
+  if (!std::isfinite(R) || R > 1e6) return;
+  h->cullC[0] = (float)C[0]; h->cullC[1] = (float)C[1]; h->cullC[2] = (float)C[2];
+  h->cullR2 = (float)(R * R);
+  h->cullOk = 1;
+}
+
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut, const RmResources &res) {
   Slot *slot;
@@ -329,6 +393,7 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   h->noise = res.noise;
   for (int f = 0; f < 6; f++) h->skybox[f] = res.skybox[f];
   h->ltc1 = res.ltc1; h->ltc2 = res.ltc2;
+  scene_cull_ball(h);
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   *slotOut = slot;
   return RM_OK;
