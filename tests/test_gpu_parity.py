@@ -994,3 +994,47 @@ def test_random_scenes_bit_exact(renderer):
         assert_bit_equal(br.cpu().numpy(), ref_b, f"random scene {i} bright")
         kinds |= {scene[1][k].type for k in range(scene[2])}
     assert len(kinds) >= 10
+
+
+def test_bounding_ball_cull_edge_cases(renderer):
+    """The launcher's bounding ball (scene_cull_ball / bulbCullEnd) must never change a bit: strongly non-uniform and
+    rotated models, tiny and huge objects, objects far from the origin, the camera inside the ball, a far plane shorter
+    than the ball, secondary rays, scaled / translated / Julia Mandelbulbs, hard and soft shadows."""
+    W, H = 72, 48
+    rz = np.eye(4)
+    a = 0.7
+    rz[0, 0], rz[0, 1], rz[1, 0], rz[1, 1] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    lights = (abi.RmLight * 2)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.3, -1, -0.5)),
+                               h.make_light(abi.RM_LIGHT_POINT, (.9, .8, .7), pos=(3, 4, 4), func=(0.7, 0.05, 0)))
+    refl = dict(ambient=(.1, .1, .1), diffuse=(.7, .6, .5), specular=(.8, .8, .8), shininess=20, reflective=(.5, .5, .5))
+    cases = []
+    # 1: slab + needle, strongly non-uniform, rotated
+    objs = (abi.RmObject * 3)(
+        h.make_object(abi.RM_CUBE, model=h.translate(0, -1, 0) @ rz @ h.scale(6, 0.15, 3), scale_factor=0.15, **refl),
+        h.make_object(abi.RM_CYLINDER, model=h.translate(1, 0.5, -1) @ rot_x(0.9) @ h.scale(0.2, 4, 0.2), scale_factor=0.2, **refl),
+        h.make_object(abi.RM_TORUS, model=h.translate(-1.5, 0.4, 0.5) @ rz @ h.scale(2, 2, 0.7), scale_factor=0.7, **refl))
+    cases.append((h.make_camera((0, 1.5, 6), (0, -0.25, -1), (0, 1, 0), 45.0, W, H), objs, 3, h.make_globals()))
+    # 2: tiny and huge objects, far from the origin; camera inside the bounding ball
+    objs = (abi.RmObject * 3)(
+        h.make_object(abi.RM_SPHERE, model=h.translate(50, 2, -40) @ h.scale(30, 30, 30), scale_factor=30, **refl),
+        h.make_object(abi.RM_OCTAHEDRON, model=h.translate(0.3, 0, -2) @ h.scale(0.05, 0.05, 0.05), scale_factor=0.05, **refl),
+        h.make_object(abi.RM_DEATHSTAR, model=h.translate(-2, 0.5, -4) @ h.scale(2, 2, 2), scale_factor=2, **refl))
+    cases.append((h.make_camera((0, 0.5, 2), (0.2, 0, -1), (0, 1, 0), 60.0, W, H), objs, 3, h.make_globals()))
+    # 3: far plane inside the ball
+    cases.append((h.make_camera((0, 1.5, 6), (0, -0.25, -1), (0, 1, 0), 45.0, W, H, far=5.5), cases[0][1], 3, h.make_globals()))
+    # 4-6: Mandelbulbs: scaled + translated, Julia, tiny (scaleFactor below the cull's threshold)
+    for model, sf, glob in ((h.translate(0.4, -0.2, 0.3) @ rz @ h.scale(1.6, 1.6, 1.6), 1.6, h.make_globals()),
+                            (np.eye(4), 1.0, h.make_globals(julia=(0.4, -0.3))),
+                            (h.scale(0.005, 0.005, 0.005), 0.005, h.make_globals())):
+        objs = (abi.RmObject * 1)(h.make_object(abi.RM_MANDELBULB, model=model, scale_factor=sf, ambient=(.3, .3, .3), specular=(1, 1, 1),
+                                                shininess=100, reflective=(.4, .4, .4)))
+        pos = (0, 0, 4.5) if sf > 0.01 else (0, 0, 0.02)
+        cases.append((h.make_camera(pos, (0, 0, -1), (0, 1, 0), 30.0, W, H, near=0.001 if sf < 0.01 else 0.1), objs, 1, glob))
+    for k, (cam, objs, no, g) in enumerate(cases):
+        scene = (cam, objs, no, lights, 2, g)
+        for over in ({"enableReflection": 1, "numReflection": 2}, {"enableSoftShadow": 1, "enableAmbientOcclusion": 1, "fractalIters": 8}):
+            s = abi.default_settings(features=abi.RM_FEAT_WHITE_BACKGROUND, **over)
+            ref = h.oracle_render(scene, s, W, H)
+            assert_bit_equal(renderer.render(tables_of(scene), s, W, H).cpu().numpy(), ref, f"cull case {k} {over}")
+            if k != 5:
+                assert (ref[..., :3] != 1.0).any(-1).mean() > 0.02, f"case {k}: the objects must be in view"
