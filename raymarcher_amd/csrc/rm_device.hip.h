@@ -69,6 +69,7 @@ struct SceneBlock {
   // when the scene holds an object without a known bound.
   float cullC[3];
   float cullR2;
+  float cullR2Soft;  // larger ball for soft-shadow rays (0 = none): beyond it 8·d/t >= 1, so the penumbra min() is settled
   int32_t cullOk;
 };
 
@@ -358,12 +359,12 @@ RM_DEV float bulbCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
 }
 // The same idea for any scene: the launcher bounds every object by a world-space ball (exact SDFs are >= the distance
 // to their object's ball; the bound includes a margin δ with minScale·δ >> the hit threshold), and a march whose miss
-// distance is unused ends where its ray leaves the ball around all of them.  Not used for soft-shadow rays, whose
-// penumbra factor min(8·d/t) can still change just outside the ball.
-RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
-  if (!sb->cullOk) return end;  // wave-uniform
+// distance is unused ends where its ray leaves the ball around all of them.  Soft-shadow rays use a larger ball, beyond
+// which 8·d/t >= 1 so that the penumbra factor min(pen, 8·d/t) <= 1 can no longer change (none if the bound is too weak).
+RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R2) {
+  if (!sb->cullOk || !(R2 > 0.0f)) return end;  // wave-uniform
   const V3 po = v3(ro.x - sb->cullC[0], ro.y - sb->cullC[1], ro.z - sb->cullC[2]);
-  const float a = dot(rd, rd), b = dot(po, rd), c = dot(po, po) - sb->cullR2;
+  const float a = dot(rd, rd), b = dot(po, rd), c = dot(po, po) - R2;
   const float disc = fma(b, b, -(a * c));
   float tExit = (sqrt_(max_(disc, 0.0f)) - b) / a;
   tExit = fma(tExit, 1.0001f, 1.0e-3f);
@@ -374,7 +375,8 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
 template <bool BULB, bool COUNT, bool SHADOW, bool CULL = false>
 RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
   if (BULB && CULL && !COUNT) end = bulbCullEnd(sb, ro, rd, end);
-  if (!BULB && CULL && !COUNT && !(SHADOW && sb->s.enableSoftShadow)) end = sceneCullEnd(sb, ro, rd, end);
+  if (!BULB && CULL && !COUNT)
+    end = sceneCullEnd(sb, ro, rd, end, (SHADOW && sb->s.enableSoftShadow) ? sb->cullR2Soft : sb->cullR2);
   float depth = 0.0f;
   float pen = 1.0f;
   SceneMin c;

@@ -325,11 +325,12 @@ void scene_cull_ball(SceneBlock *h) {
   h->cullOk = 0;
   h->cullC[0] = h->cullC[1] = h->cullC[2] = 0.0f;
   h->cullR2 = 0.0f;
+  h->cullR2Soft = 0.0f;
   const int n = h->numObjects;
   if (n <= 0) return;
   static const double kRadius[] = {0.8661, 0.7072, 0.7072, 0.5001, 0.5001, 0.6251, 0.6001, 0.5001, 0.7072};  // cube … rectangle
   double cx[RM_MAX_OBJECTS], cy[RM_MAX_OBJECTS], cz[RM_MAX_OBJECTS], rad[RM_MAX_OBJECTS];
-  double kappa = 1e30, C[3] = {0, 0, 0};
+  double kappa = 1e30, kappaSoft = 1e30, C[3] = {0, 0, 0};
   for (int i = 0; i < n; i++) {
     const RmObject &o = h->objs[i];
     double r;
@@ -360,9 +361,13 @@ void scene_cull_ball(SceneBlock *h) {
     cy[i] = -(inv[1][0] * b[0] + inv[1][1] * b[1] + inv[1][2] * b[2]);
     cz[i] = -(inv[2][0] * b[0] + inv[2][1] * b[1] + inv[2][2] * b[2]);
     rad[i] = r * nf;
-    const double k = (o.type == RM_MANDELBULB) ? 1e30 : (double)o.scaleFactor / nf;  // the bulb's 0.68·scaleFactor needs no δ
-    if (!(k > 1e-6) || !std::isfinite(rad[i]) || !std::isfinite(cx[i] + cy[i] + cz[i])) return;
-    kappa = k < kappa ? k : kappa;
+    const double ki = (double)o.scaleFactor / nf;
+    if (!(ki > 1e-6) || !std::isfinite(rad[i]) || !std::isfinite(cx[i] + cy[i] + cz[i])) return;
+    // hard bound: the bulb's constant 0.68·scaleFactor needs no δ; soft bound: beyond ρ = 2.1 its estimate ≈ 0.5·ρ·ln ρ has
+    // slope >= 0.87 in object space
+    if (o.type != RM_MANDELBULB) kappa = ki < kappa ? ki : kappa;
+    const double ksi = (o.type == RM_MANDELBULB) ? 0.8 * ki : ki;
+    kappaSoft = ksi < kappaSoft ? ksi : kappaSoft;
     C[0] += cx[i] / n; C[1] += cy[i] / n; C[2] += cz[i] / n;
   }
   double R = 0.0;
@@ -370,12 +375,21 @@ void scene_cull_ball(SceneBlock *h) {
     const double d = std::sqrt((cx[i] - C[0]) * (cx[i] - C[0]) + (cy[i] - C[1]) * (cy[i] - C[1]) + (cz[i] - C[2]) * (cz[i] - C[2])) + rad[i];
     R = d > R ? d : R;
   }
+  if (kappa > 1e29) kappa = 1.0;                         // only Mandelbulbs: any margin does
   const double delta = std::fmax(0.05, 4.0e-3 / kappa);  // κ·δ >= 4× the hit threshold
   R = (R + delta) * 1.001;
   if (!std::isfinite(R) || R > 1e6) return;
   h->cullC[0] = (float)C[0]; h->cullC[1] = (float)C[1]; h->cullC[2] = (float)C[2];
   h->cullR2 = (float)(R * R);
   h->cullOk = 1;
+  // Soft shadows: a shadow ray starts on a surface, i.e. inside the ball (radius R), and at distance ρ from the centre has
+  // travelled t <= ρ + R while every distance value is >= κ·(ρ − R).  8·κ·(ρ − R) >= ρ + R  ⇔  ρ >= R·(8κ + 1)/(8κ − 1):
+  // past that radius min(pen, 8·d/t) is settled.
+  const double ks = kappaSoft;
+  if (ks > 0.2 && ks < 1e29) {
+    const double Rs = R * (8.0 * ks + 1.0) / (8.0 * ks - 1.0) * 1.001;
+    if (std::isfinite(Rs) && Rs < 1e6) h->cullR2Soft = (float)(Rs * Rs);
+  }
 }
 
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
