@@ -18,7 +18,7 @@ step tests 900 python -m pytest tests -m gpu -q "${PYTEST_ARGS:--x}"
 TESTS_RC=$?
 step bench 600 python bench.py --steps "${STEPS:-10}" --warmup 2
 if [ "${PROFILE:-1}" = "1" ]; then
-  step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants
+  step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants
   find gpurun_out/prof -name '*kernel_stats*' | head -3
 fi
 exit $TESTS_RC
