@@ -1038,3 +1038,70 @@ def test_bounding_ball_cull_edge_cases(renderer):
             assert_bit_equal(renderer.render(tables_of(scene), s, W, H).cpu().numpy(), ref, f"cull case {k} {over}")
             if k != 5:
                 assert (ref[..., :3] != 1.0).any(-1).mean() > 0.02, f"case {k}: the objects must be in view"
+
+
+CXX_HOST = r'''
+// A C++ host with no Python and no torch: what a maintainer of the reference links (INTEGRATION.md §1).
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "raymarcher_amd.h"
+extern "C" int rmo_render(const RmCamera *, const RmObject *, int, const RmLight *, int, const RmGlobals *, const RmSettings *, int, int,
+                          int, int, float *, float *, RmCounters *, int);   // the checker (oracle/), test only
+int main(int argc, char **argv) {
+  const int W = 96, H = 54;
+  RmScene *sc = nullptr;
+  if (rm_scene_load(argv[1], &sc) != RM_OK) { std::printf("load: %s\n", rm_last_error()); return 2; }
+  RmCameraData cd; RmCamera cam; RmGlobals g; RmSettings s;
+  rm_scene_camera_data(sc, &cd);
+  if (rm_camera_build(&cd, W, H, 0.1f, 100.0f, nullptr, nullptr, &cam) != RM_OK) return 3;
+  if (rm_scene_globals(sc, nullptr, &g) != RM_OK) return 4;
+  rm_settings_default(&s);
+  s.fractalIters = 12;
+  float *dFrame = nullptr; uint8_t *d8 = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&dFrame), size_t(W) * H * 16) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d8), size_t(W) * H * 4) != hipSuccess) return 5;
+  int st = rm_render(&cam, rm_scene_objects(sc), rm_scene_num_objects(sc), rm_scene_lights(sc), rm_scene_num_lights(sc), &g, &s,
+                     W, H, 0, H, dFrame, nullptr, nullptr);
+  if (st != RM_OK) { std::printf("render: %s\n", rm_last_error()); return 6; }
+  if (rm_frame_to_rgba8(dFrame, d8, W, H, nullptr) != RM_OK) return 7;
+  std::vector<float> got(size_t(W) * H * 4), ref(got.size());
+  std::vector<uint8_t> px(size_t(W) * H * 4);
+  hipMemcpy(got.data(), dFrame, got.size() * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(px.data(), d8, px.size(), hipMemcpyDeviceToHost);
+  if (rmo_render(&cam, rm_scene_objects(sc), rm_scene_num_objects(sc), rm_scene_lights(sc), rm_scene_num_lights(sc), &g, &s, W, H, 0, H,
+                 ref.data(), nullptr, nullptr, 8) != 0) return 8;
+  if (std::memcmp(got.data(), ref.data(), got.size() * 4) != 0) { std::printf("frame differs from the oracle\n"); return 9;  }
+  if (rm_write_png(argv[2], px.data(), W, H) != RM_OK) return 10;
+  std::vector<float> host(16);
+  if (rm_render(&cam, rm_scene_objects(sc), 1, rm_scene_lights(sc), 3, &g, &s, 2, 2, 0, 2, host.data(), nullptr, nullptr) != RM_ERR_INVALID_ARGUMENT) return 11;
+  rm_scene_free(sc);
+  std::printf("ok\n");
+  return 0;
+}
+'''
+
+
+def test_cxx_host_without_python(renderer, tmp_path):
+    """The drop-in boundary exercised the way the reference would use it: a C++ program (hipcc) that loads a scenefile,
+    renders through the C ABI into hipMalloc'ed memory, checks the frame against the oracle bit for bit, writes the PNG."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "host.cpp"
+    src.write_text(CXX_HOST)
+    exe = tmp_path / "host"
+    libdir, odir = os.path.join(root, "raymarcher_amd", "lib"), os.path.join(root, "oracle", "_build")
+    cmd = [hipcc, "-std=c++17", "-O1", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-lraymarcher_amd",
+           "-L", odir, "-lrm_oracle", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{odir}"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    png = tmp_path / "bulb.png"
+    r = subprocess.run([str(exe), os.path.join(SCENES, "simple", "unit_mandelbulb.json"), str(png)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-800:])
+    from PIL import Image
+    img = np.asarray(Image.open(png))
+    assert img.shape == (54, 96, 4) and (img[..., :3] != 255).any(-1).mean() > 0.2
