@@ -1105,3 +1105,28 @@ def test_cxx_host_without_python(renderer, tmp_path):
     from PIL import Image
     img = np.asarray(Image.open(png))
     assert img.shape == (54, 96, 4) and (img[..., :3] != 255).any(-1).mean() > 0.2
+
+
+def test_degenerate_knobs_bit_exact(renderer):
+    """Loop bounds at zero, no lights, one-pixel frames, NaN / inf in the tables: no hang, no fault, same bits as the oracle."""
+    W, H = 40, 24
+    cases = [(h.scene_mandelbulb(W, H), dict(maxSteps=0)), (h.scene_mandelbulb(W, H), dict(fractalIters=0)),
+             (h.scene_mandelbulb(W, H), dict(maxSteps=1, fractalIters=1)), (menger_scene(W, H), dict(mengerLevels=0, enableReflection=1)),
+             (reflect_refract_scene(W, H), dict(numReflection=0, enableReflection=1, enableRefraction=1)),
+             (reflect_refract_scene(W, H)[:3] + ((abi.RmLight * 1)(), 0) + (h.make_globals(),), dict(enableAmbientOcclusion=1))]
+    for k, (scene, over) in enumerate(cases):
+        s = abi.default_settings(**over)
+        assert_bit_equal(renderer.render(tables_of(scene), s, W, H).cpu().numpy(), h.oracle_render(scene, s, W, H), f"degenerate {k} {over}")
+    for w, hh in ((1, 1), (1, 7), (33, 1)):
+        scene = h.scene_mandelbulb(w, hh)
+        s = abi.default_settings(fractalIters=12)
+        assert_bit_equal(renderer.render(tables_of(scene), s, w, hh).cpu().numpy(), h.oracle_render(scene, s, w, hh), f"{w}x{hh}")
+    # non-finite numbers in the tables must not hang or fault (values then follow IEEE on both sides)
+    scene = reflect_refract_scene(W, H)
+    scene[1][0].invModel[12] = float("nan")
+    scene[1][1].scaleFactor = float("inf")
+    scene[3][0].dir[0] = float("nan")
+    s = abi.default_settings(enableReflection=1, maxSteps=32)
+    got, ref = renderer.render(tables_of(scene), s, W, H).cpu().numpy(), h.oracle_render(scene, s, W, H)
+    both_nan = np.isnan(got) & np.isnan(ref)
+    assert ((got.view(np.uint32) == ref.view(np.uint32)) | both_nan).all()
