@@ -33,6 +33,15 @@
 
 #include <stdlib.h>
 
+/* Work-trace hooks: no-ops here.  scripts/sim/wave_sim.c (an offline schedule simulator, not a test and not the
+ * product) defines them before including this file to record, per pixel, the Mandelbulb iteration count of every
+ * sdScene evaluation and where each march begins. */
+#ifndef RMO_TRACE_EVAL
+#define RMO_TRACE_EVAL(c, iters) ((void)0)
+#define RMO_TRACE_MARCH(c, kind, ro, rd, endp) ((void)0) /* kind 0 = raymarch, 1 = softshadow; may lower *endp */
+#define RMO_TRACE_SKIP_SHADOW(c, N, L) 0                 /* 1 = do not march a shadow ray whose light is dropped anyway */
+#endif
+
 /* ---------------------------------------------------------------- vector forms of the contract */
 typedef struct { float x, y; } v2;
 typedef struct { float x, y, z; } v3;
@@ -230,8 +239,10 @@ static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
     *resColor = V4(m, trap.y, trap.z, trap.w);
     return ((0.25f * rm_log(m)) * rm_sqrt(m)) / dz;
   }
+  int nTrace = 0;
   for (int i = 0; i < c->s.fractalIters; i++) {
     c->nIter++;
+    nTrace++;
     /* frag:787 */
     dz = rm_fma(power * rm_pow(m, pexp), dz, 1.0f);
     /* frag:789-793 */
@@ -248,6 +259,7 @@ static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
     m = dot3(w, w);
     if (m > 2.0f) break;
   }
+  RMO_TRACE_EVAL(c, nTrace);
   *resColor = V4(m, trap.y, trap.z, trap.w);
   /* frag:802 */
   return ((0.25f * rm_log(m)) * rm_sqrt(m)) / dz;
@@ -351,6 +363,7 @@ static RayMarchRes raymarch(Ctx *c, v3 ro, v3 rd, float end, float side) {
   float rayDepth = 0.0f;
   SceneMin closest;
   closest.minD = 1000000.0f; closest.minObjIdx = -1; closest.trap = V4(0, 0, 0, 0);
+  RMO_TRACE_MARCH(c, 0, ro, rd, &end);
   for (int i = 0; i < c->s.maxSteps; i++) {
     v3 p = v3_madd(rd, rayDepth, ro);
     closest = sdScene(c, p);
@@ -457,6 +470,7 @@ static RayMarchRes softshadow(Ctx *c, v3 ro, v3 rd, float mint, float maxt, floa
   float rayDepth = mint;
   SceneMin closest;
   closest.minD = 1000000.0f; closest.minObjIdx = -1; closest.trap = V4(0, 0, 0, 0);
+  RMO_TRACE_MARCH(c, 1, ro, rd, &maxt);
   for (int i = 0; i < c->s.maxSteps; i++) {
     closest = sdScene(c, v3_madd(rd, rayDepth, ro));
     if (rm_abs(closest.minD) < SURFACE_DIST || rayDepth > maxt) break;
@@ -739,6 +753,7 @@ static v3 getPhong(Ctx *c, v3 N, int intersectObj, v3 p, v3 rd, float far) {
     /* frag:1908: origin p + N*SURFACE_DIST*5 */
     v3 so = V3(rm_fma(N.x * SURFACE_DIST, 5.0f, p.x), rm_fma(N.y * SURFACE_DIST, 5.0f, p.y),
                rm_fma(N.z * SURFACE_DIST, 5.0f, p.z));
+    if (RMO_TRACE_SKIP_SHADOW(c, N, L)) continue;
     RayMarchRes sh = softshadow(c, so, L, 0.0f, maxT, 8.0f);
     if (sh.intersectObj != -1) continue;
     float NdotL = dot3(N, L);
@@ -1663,12 +1678,29 @@ int rmo_probe_env2(int kind, float iTime, const RmTexture *noise, const float *p
 }
 
 /* bits of the contract's constants, for tests */
+/* Exhaustive check behind the product's constant-divisor sequence (rm_math.hip.h, RM_DIVC): for EVERY binary32 mantissa
+ * of x, q = x·fl(1/c) followed by one fma-residual correction equals the correctly rounded x / c.  Rounding commutes with
+ * scaling by powers of two inside the normal range, so one binade of x covers them all.  Returns the mismatch count. */
+long rmo_check_const_div(float c) {
+  const float rc = 1.0f / c;
+  long bad = 0;
+  for (uint32_t m = 0; m < (1u << 23); m++) {
+    const float x = rm_u2f(0x4b000000u | m);
+    const float q0 = x * rc;
+    const float q = rm_fma(rm_fma(-c, q0, x), rc, q0);
+    if (q != x / c) bad++;
+    const float xn = -x, qn0 = xn * rc;
+    if (rm_fma(rm_fma(-c, qn0, xn), rc, qn0) != xn / c) bad++;
+  }
+  return bad;
+}
+
 uint32_t rmo_const_bits(int which) {
   switch (which) {
     case 0: return rm_f2u(RM_PI);
     case 1: return rm_f2u(RM_PIO2_HI);
     case 2: return rm_f2u(RM_PIO2_MID);
-    case 3: return rm_f2u(RM_PIO2_LO);
+    case 3: return 0u; /* (the third Cody–Waite term, no longer part of the contract) */
     case 4: return rm_f2u(RM_2OPI);
     case 5: return rm_f2u(RM_LN2);
     case 6: return rm_f2u(RM_LOG2E);

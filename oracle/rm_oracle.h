@@ -30,6 +30,8 @@ int rmo_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, 
 int rmo_probe_env(int kind, float iTime, const float *pts, float *out, int n);
 int rmo_probe_env2(int kind, float iTime, const RmTexture *noise, const float *pts, float *out, int n);
 uint32_t rmo_const_bits(int which);
+/* Mismatches of the three-instruction constant-divisor sequence against IEEE division over all mantissas (0 = exact). */
+long rmo_check_const_div(float c);
 #ifdef __cplusplus
 }
 #endif

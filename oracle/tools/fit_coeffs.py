@@ -64,6 +64,12 @@ def main():
         c32 = c.astype(np.float32)
         report(f"RM_ASIN_C{n}", c32,
                lambda x, cc: x + sum(cc[i] * x ** (3 + 2 * i) for i in range(len(cc))), np.arcsin, -0.5, 0.5)
+    # acos(x) = sqrt(1-x) * P(x), x in [0,1)  (Abramowitz & Stegun 4.4.46 form; P analytic on [0,1], P(1) = sqrt(2))
+    acr = lambda x: np.arccos(np.minimum(x, 1.0)) / np.sqrt(np.maximum(1.0 - x, 1e-300))
+    for n in (7, 8, 9):
+        c = lsq_fit(lambda x, i: x ** i, acr, lambda x: 1 / np.abs(acr(x)), 0.0, 1.0 - 1e-9, n, iters=80)
+        c32 = c.astype(np.float32)
+        report(f"RM_ACOS_C{n}", c32, lambda x, cc: sum(cc[i] * x ** i for i in range(len(cc))), acr, 0.0, 1.0 - 1e-9)
     # atan(t) = t + t*s*P(s), s=t^2, t in [0,1]
     for n in (8, 9, 10):
         c = lsq_fit(lambda x, i: x ** (3 + 2 * i), lambda x: np.arctan(x) - x,

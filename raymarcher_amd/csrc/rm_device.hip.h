@@ -151,8 +151,19 @@ RM_DEV float sdMandelBrot(const SceneBlock *sb, float px, float py) {
 //   BULB_TRIG8      power == 8: the same contract, with the two pows written out — binary exponentiation of 8 is
 //                   ((r²)²)², of 3.5 is (m·(m·m))·√m — as straight-line code (identical bits, no bit loop);
 //   BULB_ALGEBRAIC8 power == 8 and RM_FEAT_BULB_POWER8_ALGEBRAIC: the step by complex squarings (see the header).
+//
+// TRAPMIN: the orbit-trap minima (frag:795) as v_min_f32 instead of compare + select (4 instead of 8 instructions per
+// iteration).  v_min_f32 differs from the GLSL select form only when its FIRST operand — the accumulator — is NaN (a
+// NaN second operand is ignored by both forms, and every operand is >= +0, so −0 never occurs).  The accumulators start
+// from |pos| and dot(pos, pos) and stay non-NaN once they are; if one STARTS as NaN then pos holds a NaN, every iterate
+// and m are NaN, the estimate is NaN and the evaluation cannot be a hit (|NaN| < 0.001 is false) — and the trap is read
+// only for a hit.  That argument needs the trap's reader to look at THIS object's distance, which holds in the
+// single-Mandelbulb scene class (BULB); the table walk (where the trap of the last fractal evaluated is read whatever
+// object was hit, UB3) keeps the select form.
 enum BulbMode { BULB_GENERIC = 0, BULB_TRIG8 = 1, BULB_ALGEBRAIC8 = 2 };
-template <bool COUNT, int MODE>
+// TRAP = false drops the orbit trap altogether: shadow marches, normal taps and AO taps never read it (with the select
+// form the compiler removed it there by itself; the v_min_f32 form is inline asm, so it is spelled out).
+template <bool COUNT, int MODE, bool TRAPMIN, bool TRAP>
 RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
   const float power = sb->g.power;
   const float pexp = (power - 1.0f) / 2.0f;
@@ -206,20 +217,23 @@ RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &c
       else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
       w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
     }
-    trap = v4(min_(trap.x, fabs_(w.x)), min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
+    if (TRAP) {  // trap.x is never read (resColor below)
+      if (TRAPMIN) trap = v4(trap.x, hwmin_abs_(trap.y, w.y), hwmin_abs_(trap.z, w.z), hwmin_(trap.w, m));
+      else trap = v4(trap.x, min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));
+    }
     m = dot(w, w);
     if (m > 2.0f) break;  // frag:798 (FRACTALS_BAILOUT)
   }
   resColor = v4(m, trap.y, trap.z, trap.w);
   return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;  // frag:802
 }
-template <bool COUNT>
+template <bool COUNT, bool TRAPMIN, bool TRAP>
 RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
   if (sb->g.power == 8.0f) {  // wave-uniform
-    if (sb->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) return bulbIterate<COUNT, BULB_ALGEBRAIC8>(sb, pos, resColor, cnt);
-    return bulbIterate<COUNT, BULB_TRIG8>(sb, pos, resColor, cnt);
+    if (sb->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) return bulbIterate<COUNT, BULB_ALGEBRAIC8, TRAPMIN, TRAP>(sb, pos, resColor, cnt);
+    return bulbIterate<COUNT, BULB_TRIG8, TRAPMIN, TRAP>(sb, pos, resColor, cnt);
   }
-  return bulbIterate<COUNT, BULB_GENERIC>(sb, pos, resColor, cnt);
+  return bulbIterate<COUNT, BULB_GENERIC, TRAPMIN, TRAP>(sb, pos, resColor, cnt);
 }
 
 // frag:808-827
@@ -265,7 +279,7 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
 // ---- scene union (frag:1406-1430) ---------------------------------------------------------------------
 // BULB=true is the single-Mandelbulb scene class (numObjects == 1, type MANDELBULB): same arithmetic,
 // no table walk.
-template <bool BULB, bool COUNT>
+template <bool BULB, bool COUNT, bool TRAP = true>
 RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
   SceneMin res;
   res.d = 1000000.0f;
@@ -292,7 +306,7 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
       case RM_DEATHSTAR: d = sdDeathStar(po, 0.5f, 0.35f, 0.5f); break;
       case RM_RECTANGLE: d = sdBox(po, 0.5f, 0.5f, 0.0f); break;
       case RM_MANDELBROT: d = sdMandelBrot(sb, po.x, po.y); break;
-      case RM_MANDELBULB: d = sdMandelBulb<COUNT>(sb, po, res.trap, cnt); break;
+      case RM_MANDELBULB: d = sdMandelBulb<COUNT, BULB && !COUNT, TRAP>(sb, po, res.trap, cnt); break;
       case RM_MENGERSPONGE: d = sdMengerSponge(sb, po, res.trap); break;
       case RM_SIERPINSKI: d = sdSierpinski(po); break;
       default: continue;
@@ -314,7 +328,7 @@ RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
     float ox = (k == 0 || k == 3) ? ex : ey;
     float oy = (k >= 2) ? ex : ey;
     float oz = (k == 1 || k == 3) ? ex : ey;
-    float v = sdScene<BULB, COUNT>(sb, v3(p.x + ox, p.y + oy, p.z + oz), cnt).d;
+    float v = sdScene<BULB, COUNT, false>(sb, v3(p.x + ox, p.y + oy, p.z + oz), cnt).d;
     d[0] = (k == 0) ? v : d[0];
     d[1] = (k == 1) ? v : d[1];
     d[2] = (k == 2) ? v : d[2];
@@ -332,24 +346,31 @@ RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
 // SHADOW=true : returns obj, d = penumbra factor res (contract UB1), k = 8, start depth 0.
 //
 // CULL (single-Mandelbulb class only; never in the counted variant, whose counters are the reference's work): a march
-// whose miss distance nobody reads — primary / secondary rays of render(), shadow rays — may stop as soon as the ray
-// has left the ball |p_object| <= 2.1 for good, because it can no longer hit: for power 8 and |p| = ρ >= 2 the first
-// iteration gives |w| >= ρ^8 − max(ρ, |seed|) >= 254, the loop bails out, and the estimate
-// 0.25·ln(m)·√m / (8ρ^7 + 1) >= 0.68 — six hundred times the hit threshold (times scaleFactor >= 0.01) — and it only
-// grows with ρ; for shadow rays 8·d/t >= 1.4 out there, so the penumbra factor (<= 1) is not touched either.  The
-// march therefore ends at min(end, t_exit) with the same obj = −1 (and, for shadows, the same penumbra) it would have
-// reached ~12 evaluations later at t > far.  Rays that never enter the ball stop after their first evaluation.
+// whose miss distance nobody reads — primary / secondary rays of render(), hard-shadow rays — may stop as soon as the ray
+// has left a ball |p_object| <= R for good, because it can no longer hit.  For power 8 and |p| = ρ the first iteration
+// gives |w| >= ρ^8 − max(ρ, |seed|), the loop bails out (|w|² > 2) and the estimate is
+// 0.5·ln|w|·|w| / (8ρ^7 + 1), increasing in ρ and in |w|:
+//   R = 1.15 (|seed| <= 1.14, scaleFactor >= 0.05): |w| >= 1.909, estimate >= 0.0277 — times scaleFactor still 1.39× the
+//            hit threshold; the set {estimate < 0.001} lies inside the ball;
+//   R = 2.1  (|seed| <= 2,    scaleFactor >= 0.01): |w| >= 254, estimate >= 0.68.
+// The march therefore ends at min(end, t_exit) with the same obj = −1 it would have reached some evaluations later at
+// t > far.  Rays that never enter the ball stop after their first evaluation.  Soft-shadow rays also read the penumbra
+// factor min(8·d/t); they use the launcher's larger ball (sceneCullEnd with cullR2Soft), which accounts for anisotropic
+// object scales.
 RM_DEV float bulbCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
   const RmObject &o = sb->objs[0];
   const float jx = sb->g.juliaSeed[0], jy = sb->g.juliaSeed[1];
-  const bool ok = (sb->g.power == 8.0f) && (o.scaleFactor >= 0.01f) && (fma(jx, jx, jy * jy) <= 4.0f);  // wave-uniform
+  const float seed2 = fma(jx, jx, jy * jy);
+  const bool ok = (sb->g.power == 8.0f) && (o.scaleFactor >= 0.01f) && (seed2 <= 4.0f);  // wave-uniform
   if (!ok) return end;
+  const bool tight = (o.scaleFactor >= 0.05f) && (seed2 <= 1.2996f);
+  const float R2 = tight ? 1.3225f : 4.41f;
   const float *M = o.invModel;
   const V3 po = v3(fma(M[8], ro.z, fma(M[4], ro.y, fma(M[0], ro.x, M[12]))), fma(M[9], ro.z, fma(M[5], ro.y, fma(M[1], ro.x, M[13]))),
                    fma(M[10], ro.z, fma(M[6], ro.y, fma(M[2], ro.x, M[14]))));
   const V3 pd = v3(fma(M[8], rd.z, fma(M[4], rd.y, M[0] * rd.x)), fma(M[9], rd.z, fma(M[5], rd.y, M[1] * rd.x)),
                    fma(M[10], rd.z, fma(M[6], rd.y, M[2] * rd.x)));
-  const float a = dot(pd, pd), b = dot(po, pd), c = dot(po, po) - 4.41f;
+  const float a = dot(pd, pd), b = dot(po, pd), c = dot(po, po) - R2;
   const float disc = fma(b, b, -(a * c));
   float tExit = (sqrt_(max_(disc, 0.0f)) - b) / a;
   tExit = fma(tExit, 1.0001f, 1.0e-3f);
@@ -374,19 +395,22 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R
 }
 template <bool BULB, bool COUNT, bool SHADOW, bool CULL = false>
 RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
-  if (BULB && CULL && !COUNT) end = bulbCullEnd(sb, ro, rd, end);
-  if (!BULB && CULL && !COUNT)
-    end = sceneCullEnd(sb, ro, rd, end, (SHADOW && sb->s.enableSoftShadow) ? sb->cullR2Soft : sb->cullR2);
+  if (CULL && !COUNT) {
+    const bool softRay = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform
+    if (BULB && !softRay) end = bulbCullEnd(sb, ro, rd, end);
+    else end = sceneCullEnd(sb, ro, rd, end, softRay ? sb->cullR2Soft : sb->cullR2);
+  }
   float depth = 0.0f;
   float pen = 1.0f;
   SceneMin c;
   c.d = 1000000.0f; c.idx = -1; c.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
   const int steps = sb->s.maxSteps;
+  const bool soft = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform: the penumbra factor is read only then
   for (int i = 0; i < steps; i++) {
-    c = sdScene<BULB, COUNT>(sb, madd(rd, depth, ro), cnt);
+    c = sdScene<BULB, COUNT, !SHADOW>(sb, madd(rd, depth, ro), cnt);
     if (fabs_(c.d) < kSurfaceDist || depth > end) break;
     if (SHADOW) {
-      pen = min_(pen, (8.0f * c.d) / depth);
+      if (soft) pen = min_(pen, (8.0f * c.d) / depth);
       depth = depth + fabs_(c.d);
     } else {
       depth = fma(c.d, side, depth);
@@ -402,13 +426,18 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
 }
 
 // ---- Perlin bump (frag:1587-1691) ---------------------------------------------------------------------
-RM_DEV float permute(float x) { return mod_(fma(x, 34.0f, 1.0f) * x, 289.0f); }
+// mod(·, 289) and the /7 of pgrad with the constant-divisor sequence (rm_math.hip.h, RM_DIVC): every operand here is a
+// small non-negative integer, exactly representable, so the quotients are the correctly rounded ones.
+RM_DEV float permute(float x) {
+  const float y = fma(x, 34.0f, 1.0f) * x;
+  return fma(-289.0f, floor_(RM_DIVC(y, 289.0f)), y);
+}
 RM_DEV float taylorInvSqrt(float r) { return fma(-0.85373472095314f, r, 1.79284291400159f); }
 RM_DEV float fade(float t) { return ((t * t) * t) * fma(t, fma(t, 6.0f, -15.0f), 10.0f); }
 
 RM_DEV void pgrad(float ixyz, float &gx, float &gy, float &gz) {  // frag:1626-1632 / 1634-1640
-  float x = ixyz / 7.0f;
-  float y = fract_(floor_(x) / 7.0f) - 0.5f;
+  float x = RM_DIVC(ixyz, 7.0f);
+  float y = fract_(RM_DIVC(floor_(x), 7.0f)) - 0.5f;
   x = fract_(x);
   float z = (0.5f - fabs_(x)) - fabs_(y);
   float sz = step_(z, 0.0f);
@@ -467,7 +496,7 @@ RM_DEV float calcAO(const SceneBlock *sb, V3 pos, V3 nor, Counters &cnt) {
   float occ = 0.0f, sca = 1.0f;
   for (int i = 0; i < 5; i++) {
     float h = 0.01f + ((0.12f * (float)i) / 4.0f);
-    float d = sdScene<BULB, COUNT>(sb, madd(nor, h, pos), cnt).d;
+    float d = sdScene<BULB, COUNT, false>(sb, madd(nor, h, pos), cnt).d;
     occ = fma(h - d, sca, occ);
     sca = sca * 0.95f;
     if (occ > 0.35f) break;

@@ -51,11 +51,29 @@ RM_DEV float sqrt_fast_(float x) {
   return sqrt_noscale_(x);
 }
 
+// v_min_f32 (IEEE minNum: a quiet NaN operand is ignored).  Equal to min_() whenever neither operand is NaN and no
+// operand is −0; callers state why that holds, or why the NaN behaviour is the one they want.
+#ifdef RM_X_BUILTIN_MIN
+RM_DEV float hwmin_(float a, float b) { return __builtin_fminf(a, b); }
+RM_DEV float hwmin1_(float a) { return __builtin_fminf(a, 1.0f); }
+RM_DEV float hwmin_abs_(float a, float b) { return __builtin_fminf(a, __builtin_fabsf(b)); }
+#else
+RM_DEV float hwmin_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RM_DEV float hwmin1_(float a) { float r; asm("v_min_f32 %0, 1.0, %1" : "=v"(r) : "v"(a)); return r; }
+RM_DEV float hwmin_abs_(float a, float b) { float r; asm("v_min_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#endif
+// x / c for a compile-time constant c in three instructions instead of the eleven of the IEEE division expansion:
+// q = x·fl(1/c), then one fma-residual correction.  For the constants used with it (7, 289, 3^k, 100, 200, 130, 2000)
+// the result equals the correctly rounded quotient for EVERY binary32 mantissa of x — checked exhaustively by
+// tests/test_oracle_math.py::test_constant_division_sequence_is_exact — as long as x/c and the residual stay in the
+// normal range (|x| >= 2^-100 or x == 0; callers pass integers or differences of numbers near 1).
+RM_DEV float divc_(float x, float c, float rc) { float q = x * rc; float r = fma(-c, q, x); return fma(r, rc, q); }
+#define RM_DIVC(x, c) ::rm::divc_((x), (c), 1.0f / (c))
+
 constexpr float kPi = 3.14159274f;          // 0x40490fdb
 constexpr float kPio2 = 1.57079637f;        // 0x3fc90fdb
 constexpr float k2oPi = 0.636619747f;       // 0x3f22f983
 constexpr float kPio2Mid = -4.37113883e-08f;  // 0xb33bbd2e
-constexpr float kPio2Lo = -1.71512451e-15f;   // 0xa6f72ced
 
 // sin and cos of one argument sharing the Cody–Waite reduction (bits equal the separate calls).
 RM_DEV void sincos_(float x, float &sn, float &cs) {
@@ -63,7 +81,6 @@ RM_DEV void sincos_(float x, float &sn, float &cs) {
   float k = __builtin_rintf(x * k2oPi);
   float r = fma(-k, kPio2, x);
   r = fma(-k, kPio2Mid, r);
-  r = fma(-k, kPio2Lo, r);
   int q = ok ? (int)k : 0;
   r = ok ? r : 0.0f;
   float z = r * r;
@@ -85,7 +102,6 @@ RM_DEV void sincos_inrange_(float x, float &sn, float &cs) {
   float k = __builtin_rintf(x * k2oPi);
   float r = fma(-k, kPio2, x);
   r = fma(-k, kPio2Mid, r);
-  r = fma(-k, kPio2Lo, r);
   int q = (int)k;
   float z = r * r;
   float s = fma(z, -1.950213627e-04f, 8.332063444e-03f);
@@ -109,18 +125,21 @@ RM_DEV float asin_p(float z) {
   p = fma(z, p, 1.666676253e-01f);
   return p;
 }
+// acos(x) = sqrt(1 − |x|)·P(|x|) for x > 0, pi − that otherwise: one polynomial, one square root, no
+// branch on |x|.  1 − |x| is 0, >= 2^-24, negative or NaN — never a tiny positive number — so the unscaled correctly
+// rounded square root applies; its NaN for |x| > 1 is discarded by the clamp.
 RM_DEV float acos_(float x) {
   float ax = fabs_(x);
-  bool small = ax <= 0.5f;
-  float z = small ? (x * x) : ((1.0f - ax) * 0.5f);
-  // on the sqrt branch z = (1−|x|)/2 is 0, >= 2^-25, negative or NaN: never a tiny positive number
-  float s = small ? x : sqrt_noscale_(z);
-  float as = fma(s * z, asin_p(z), s);
-  float big = 2.0f * as;
-  big = (x < 0.0f) ? (kPi - big) : big;
-  float r = small ? (kPio2 - as) : big;
-  float edge = (x > 0.0f) ? 0.0f : kPi;
-  return (small || ax < 1.0f) ? r : edge;
+  float p = fma(ax, -1.253449009e-03f, 6.638590246e-03f);
+  p = fma(ax, p, -1.704506390e-02f);
+  p = fma(ax, p, 3.086272627e-02f);
+  p = fma(ax, p, -5.016417801e-02f);
+  p = fma(ax, p, 8.897730708e-02f);
+  p = fma(ax, p, -2.145987004e-01f);
+  p = fma(ax, p, 1.570796251e+00f);
+  float v = sqrt_noscale_(1.0f - ax) * p;
+  v = (ax < 1.0f) ? v : 0.0f;
+  return (x > 0.0f) ? v : (kPi - v);
 }
 
 RM_DEV float asin_(float x) {
@@ -152,7 +171,10 @@ RM_DEV float atan2_(float y, float x) {
   float mx = sw ? ay : ax;
   float mn = sw ? ax : ay;
   float t = mn / mx;
-  t = (t == t) ? t : ((mx == 0.0f) ? 0.0f : 1.0f);
+  // contract: a NaN quotient (0/0, inf/inf, NaN operand) is 0 if mx == 0 and 1 otherwise.  mn <= mx, so a non-NaN
+  // quotient is <= 1 and v_min_f32(t, 1) — which ignores a NaN operand — is t itself, or 1 for NaN.
+  t = hwmin1_(t);
+  t = (mx == 0.0f) ? 0.0f : t;
   float s = t * t;
   float a = fma(t * s, atan_p(s), t);
   a = (ay > ax) ? (kPio2 - a) : a;

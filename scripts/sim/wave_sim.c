@@ -1,0 +1,307 @@
+/*
+ * scripts/sim/wave_sim.c — OFFLINE schedule simulator for the single-Mandelbulb kernel (not a test, not the product).
+ *
+ * Includes the CPU oracle with its work-trace hooks enabled, renders sampled 32×8-pixel workgroups of a frame, records
+ * for every pixel the Mandelbulb iteration count of every sdScene evaluation of every march (primary, 4 normal taps,
+ * one shadow ray per light that is not dropped), applies the production kernel's bit-identical culls (bounding-ball
+ * march end, no shadow march for N·L <= 0.005), and then prices several wave schedules in WAVE-LEVEL VALU instructions:
+ *
+ *   nested      the shipped schedule: one lane per pixel, march loop around the iteration loop; a wave pays, per march
+ *               step, the evaluation overhead once and the iteration body max-over-lanes times
+ *   flat        the iteration loop and the march loop flattened into one loop whose body is ONE Mandelbulb iteration;
+ *               lanes that finish an evaluation run the epilogue/prologue block in the same trip (paid when any lane does)
+ *   park(T)     as flat, but finished lanes park and the epilogue block runs when >= T lanes wait or nobody iterates
+ *   wg-*        work items compacted across the 256 lanes of the workgroup before they are marched
+ *   queue       each lane marches its own shadow rays back to back (no wave-level sync between lights)
+ *
+ * Output: per schedule, total wave-instructions and lane utilisation (lane-level useful instructions / 64·wave-level).
+ * Build: see scripts/sim/run_wave_sim.py.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#define SIM_MAXS 256
+#define SIM_MAXL 4
+typedef struct {
+  int nPrimary;
+  uint8_t primary[SIM_MAXS + 8];
+  int hit;
+  uint8_t normal[4];
+  int nShadow[SIM_MAXL]; /* 0 = light dropped / pixel missed */
+  uint8_t shadow[SIM_MAXL][SIM_MAXS + 8];
+} PixTrace;
+
+static __thread PixTrace *t_pix;
+static __thread int t_light;      /* index of the light whose shadow march comes next */
+static __thread int t_phase;      /* 0 primary, 2 shadow */
+static __thread float t_cullR2;   /* object-space cull radius² (0 = no cull) */
+
+static void sim_eval(int iters) {
+  PixTrace *p = t_pix;
+  if (!p) return;
+  if (t_phase == 0) { if (p->nPrimary < SIM_MAXS + 8) p->primary[p->nPrimary++] = (uint8_t)iters; }
+  else { int l = t_light - 1; if (l >= 0 && l < SIM_MAXL && p->nShadow[l] < SIM_MAXS + 8) p->shadow[l][p->nShadow[l]++] = (uint8_t)iters; }
+}
+static int sim_skip_shadow(float ndotl) {
+  PixTrace *p = t_pix;
+  if (!p) return 0;
+  if (t_light == 0) { /* first light of a hit pixel: the last four primary-phase evaluations were the normal taps */
+    p->hit = 1;
+    for (int k = 0; k < 4; k++) p->normal[k] = p->primary[p->nPrimary - 4 + k];
+    p->nPrimary -= 4;
+  }
+  t_light++;
+  t_phase = 2;
+  return ndotl <= 0.005f;
+}
+
+#define RMO_TRACE_EVAL(c, iters) sim_eval(iters)
+#define RMO_TRACE_MARCH(c, kind, ro, rd, endp) \
+  sim_march_begin((const void *)(c), (ro).x, (ro).y, (ro).z, (rd).x, (rd).y, (rd).z, (endp))
+static void sim_march_begin(const void *ctx, float rox, float roy, float roz, float rdx, float rdy, float rdz, float *endp);
+#define RMO_TRACE_SKIP_SHADOW(c, N, L) sim_skip_shadow(dot3((N), (L)))
+#include "../../oracle/rm_oracle.c"
+
+/* the production kernel's bulbCullEnd (rm_device.hip.h): end the march where the ray leaves |p_obj| <= R for good */
+static void sim_march_begin(const void *ctx, float rox, float roy, float roz, float rdx, float rdy, float rdz, float *endp) {
+  const Ctx *c = (const Ctx *)ctx;
+  const v3 ro = V3(rox, roy, roz), rd = V3(rdx, rdy, rdz);
+  if (!(t_cullR2 > 0.0f)) return;
+  const float *M = c->objs[0].invModel;
+  v3 po = xform_point(M, ro);
+  v3 pd = V3(rm_fma(M[8], rd.z, rm_fma(M[4], rd.y, M[0] * rd.x)), rm_fma(M[9], rd.z, rm_fma(M[5], rd.y, M[1] * rd.x)),
+             rm_fma(M[10], rd.z, rm_fma(M[6], rd.y, M[2] * rd.x)));
+  float a = dot3(pd, pd), b = dot3(po, pd), cc = dot3(po, po) - t_cullR2;
+  float disc = rm_fma(b, b, -(a * cc));
+  float tExit = (rm_sqrt(rm_max(disc, 0.0f)) - b) / a;
+  tExit = rm_fma(tExit, 1.0001f, 1.0e-3f);
+  if (cc > 0.0f && (b >= 0.0f || disc < 0.0f)) tExit = -1.0f;
+  if (!(a > 0.0f)) return;
+  if (tExit < *endp) *endp = tExit;
+}
+
+/* ---------------------------------------------------------------- cost model */
+typedef struct {
+  double cIt, cEv;     /* iteration body, per-evaluation overhead (prologue + DE epilogue + march bookkeeping) */
+  double cItF, cEvF;   /* the same inside a flattened state-machine loop (state handling on top) */
+  double cRay;         /* per-ray setup (light geometry, cull end) */
+  double cHit;         /* bump + material + Phong terms per wave that holds a hit pixel (same in every schedule) */
+} Cost;
+
+typedef struct { const uint8_t *it; int n; } Item; /* one march: n evaluations with it[k] iterations each */
+
+typedef struct { double wave, lane; } Acc; /* wave-level instructions, lane-level useful instructions */
+
+static double item_lane_cost(const Item *x, const Cost *k) {
+  double s = 0;
+  for (int e = 0; e < x->n; e++) s += k->cEv + k->cIt * x->it[e];
+  return s;
+}
+/* nested loops over <= 64 items in one wave */
+static void sched_nested(const Item *it, int n, const Cost *k, Acc *a) {
+  int steps = 0;
+  for (int i = 0; i < n; i++) { if (it[i].n > steps) steps = it[i].n; a->lane += item_lane_cost(&it[i], k); }
+  for (int s = 0; s < steps; s++) {
+    int mx = 0;
+    for (int i = 0; i < n; i++) if (it[i].n > s && it[i].it[s] > mx) mx = it[i].it[s];
+    a->wave += k->cEv + k->cIt * mx;
+  }
+}
+/* flattened loop with parking threshold T (T = 1: the epilogue runs in the trip in which a lane finishes).
+ * Each lane owns a QUEUE of items (qn[i] items starting at q[i]) that it marches back to back. */
+static void sched_flat(const Item *const *q, const int *qn, int n, int T, const Cost *k, Acc *a) {
+  int cur[64], e[64], rem[64], parked[64], done[64];
+  int live = 0;
+  for (int i = 0; i < n; i++) {
+    cur[i] = 0; e[i] = 0; parked[i] = 0; done[i] = 0; rem[i] = 0;
+    while (cur[i] < qn[i] && q[i][cur[i]].n == 0) cur[i]++;
+    if (cur[i] >= qn[i]) { done[i] = 1; continue; }
+    for (int j = 0; j < qn[i]; j++) a->lane += item_lane_cost(&q[i][j], k) + k->cRay;
+    rem[i] = q[i][cur[i]].it[0];
+    live++;
+  }
+  if (!live) return;
+  a->wave += k->cEvF; /* prologue of the first evaluation */
+  while (live) {
+    int iterating = 0, nparked = 0;
+    for (int i = 0; i < n; i++) if (!done[i]) { if (parked[i]) nparked++; else iterating++; }
+    if (iterating) {
+      a->wave += k->cItF;
+      for (int i = 0; i < n; i++)
+        if (!done[i] && !parked[i]) { if (--rem[i] <= 0) { parked[i] = 1; nparked++; iterating--; } }
+    }
+    if (nparked && (nparked >= T || iterating == 0)) {
+      a->wave += k->cEvF;
+      int newRay = 0;
+      for (int i = 0; i < n; i++)
+        if (!done[i] && parked[i]) {
+          parked[i] = 0;
+          e[i]++;
+          if (e[i] >= q[i][cur[i]].n) { /* march over: next ray of the lane's queue */
+            e[i] = 0; cur[i]++;
+            while (cur[i] < qn[i] && q[i][cur[i]].n == 0) cur[i]++;
+            if (cur[i] >= qn[i]) { done[i] = 1; live--; continue; }
+            newRay = 1;
+          }
+          rem[i] = q[i][cur[i]].it[e[i]];
+        }
+      if (newRay) a->wave += k->cRay;
+    }
+  }
+}
+
+#define NSCHED 10
+static const char *kSchedNames[NSCHED] = {
+  "nested (shipped)", "flat T=1", "park T=8", "park T=16", "park T=32",
+  "nested, shadow rays wg-compacted", "flat T=1, shadow rays wg-compacted", "park T=16, shadow rays wg-compacted",
+  "park T=16 primary + per-lane ray queue", "park T=16, hit pixels + rays wg-compacted",
+};
+
+typedef struct {
+  double wave[NSCHED], lane[NSCHED];
+  double primWave[NSCHED], shadWave[NSCHED], normWave[NSCHED];
+  double pixels, hits, rays, evals, iters;
+} SimOut;
+
+/* schedule one workgroup (4 waves × 64 lanes; px[w*64 + l]) under every schedule */
+static void sim_workgroup(const PixTrace *px, int nLights, const Cost *k, SimOut *o) {
+  Item prim[256], norm[256], shad[SIM_MAXL][256];
+  for (int i = 0; i < 256; i++) {
+    prim[i].it = px[i].primary; prim[i].n = px[i].nPrimary;
+    norm[i].it = px[i].normal; norm[i].n = px[i].hit ? 4 : 0;
+    for (int l = 0; l < nLights; l++) { shad[l][i].it = px[i].shadow[l]; shad[l][i].n = px[i].nShadow[l]; }
+    o->pixels += 1; o->hits += px[i].hit;
+    for (int e = 0; e < px[i].nPrimary; e++) { o->evals++; o->iters += px[i].primary[e]; }
+    if (px[i].hit) for (int e = 0; e < 4; e++) { o->evals++; o->iters += px[i].normal[e]; }
+    for (int l = 0; l < nLights; l++) { if (px[i].nShadow[l]) o->rays++; for (int e = 0; e < px[i].nShadow[l]; e++) { o->evals++; o->iters += px[i].shadow[l][e]; } }
+  }
+  const int Ts[5] = {0, 1, 8, 16, 32};
+  for (int s = 0; s < NSCHED; s++) {
+    Acc P = {0, 0}, N = {0, 0}, S = {0, 0};
+    double hitCost = 0;
+    /* ---- primary ---- */
+    int primFlatT = (s >= 1 && s <= 4) ? Ts[s] : (s == 6 ? 1 : (s >= 7 ? 16 : 0));
+    for (int w = 0; w < 4; w++) {
+      if (!primFlatT) sched_nested(prim + 64 * w, 64, k, &P);
+      else {
+        const Item *q[64]; int qn[64];
+        for (int i = 0; i < 64; i++) { q[i] = &prim[64 * w + i]; qn[i] = 1; }
+        sched_flat(q, qn, 64, primFlatT, k, &P);
+      }
+    }
+    /* ---- normals (+ per-hit shading cost) ---- */
+    if (s == 9) { /* hit pixels compacted across the workgroup */
+      Item hitList[256]; int nh = 0;
+      for (int i = 0; i < 256; i++) if (norm[i].n) hitList[nh++] = norm[i];
+      for (int b = 0; b < nh; b += 64) { sched_nested(hitList + b, nh - b < 64 ? nh - b : 64, k, &N); hitCost += k->cHit; }
+    } else {
+      for (int w = 0; w < 4; w++) {
+        int any = 0;
+        for (int i = 0; i < 64; i++) any |= norm[64 * w + i].n;
+        if (any) { sched_nested(norm + 64 * w, 64, k, &N); hitCost += k->cHit; }
+      }
+    }
+    /* ---- shadows ---- */
+    if (s <= 4) {
+      for (int w = 0; w < 4; w++)
+        for (int l = 0; l < nLights; l++) {
+          int any = 0;
+          for (int i = 0; i < 64; i++) any |= shad[l][64 * w + i].n;
+          if (!any) continue;
+          S.wave += k->cRay;
+          if (s == 0) sched_nested(shad[l] + 64 * w, 64, k, &S);
+          else {
+            const Item *q[64]; int qn[64];
+            for (int i = 0; i < 64; i++) { q[i] = &shad[l][64 * w + i]; qn[i] = 1; }
+            Acc t = {0, 0};
+            sched_flat(q, qn, 64, Ts[s], k, &t);
+            S.wave += t.wave; S.lane += t.lane - 0; /* lane cost counted inside */
+          }
+        }
+    } else if (s == 5 || s == 6 || s == 7 || s == 9) {
+      Item rays[256 * SIM_MAXL]; int nr = 0;
+      /* compaction order: pixel-major, so that a pixel's rays and neighbouring pixels stay together */
+      for (int i = 0; i < 256; i++) for (int l = 0; l < nLights; l++) if (shad[l][i].n) rays[nr++] = shad[l][i];
+      for (int b = 0; b < nr; b += 64) {
+        int m = nr - b < 64 ? nr - b : 64;
+        S.wave += k->cRay;
+        if (s == 5) sched_nested(rays + b, m, k, &S);
+        else {
+          const Item *q[64]; int qn[64];
+          for (int i = 0; i < m; i++) { q[i] = &rays[b + i]; qn[i] = 1; }
+          sched_flat(q, qn, m, s == 6 ? 1 : 16, k, &S);
+        }
+      }
+    } else if (s == 8) {
+      for (int w = 0; w < 4; w++) {
+        Item lq[64][SIM_MAXL]; const Item *q[64]; int qn[64];
+        for (int i = 0; i < 64; i++) { qn[i] = nLights; q[i] = lq[i]; for (int l = 0; l < nLights; l++) lq[i][l] = shad[l][64 * w + i]; }
+        sched_flat(q, qn, 64, 16, k, &S);
+      }
+    }
+    /* sched_nested counts lane cost without cRay; add it for comparability */
+    if (s == 0 || s == 5) for (int i = 0; i < 256; i++) for (int l = 0; l < nLights; l++) if (shad[l][i].n) S.lane += k->cRay;
+    o->wave[s] += P.wave + N.wave + S.wave + hitCost;
+    o->lane[s] += P.lane + N.lane + S.lane;
+    o->primWave[s] += P.wave; o->normWave[s] += N.wave + hitCost; o->shadWave[s] += S.wave;
+  }
+}
+
+int sim_num_schedules(void) { return NSCHED; }
+const char *sim_schedule_name(int s) { return (s >= 0 && s < NSCHED) ? kSchedNames[s] : ""; }
+
+/* Trace and price every `stride`-th workgroup (32×8 pixels) of the frame.  cost[6] = cIt, cEv, cItF, cEvF, cRay, cHit.
+ * out: wave[NSCHED], lane[NSCHED], primWave, normWave, shadWave, then pixels, hits, rays, evals, iters. */
+int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+            const RmGlobals *g, const RmSettings *s, int W, int H, int stride, float cullRadius, const double *cost,
+            double *out, int threads) {
+  if (numObjects != 1 || objs[0].type != RM_MANDELBULB || numLights > SIM_MAXL) return RM_ERR_UNSUPPORTED;
+  RmResources none;
+  memset(&none, 0, sizeof none);
+  const Cost k = {cost[0], cost[1], cost[2], cost[3], cost[4], cost[5]};
+  const int gx = (W + 31) / 32, gy = (H + 7) / 8;
+  SimOut tot;
+  memset(&tot, 0, sizeof tot);
+#pragma omp parallel num_threads(threads)
+  {
+    SimOut loc;
+    memset(&loc, 0, sizeof loc);
+    PixTrace *px = (PixTrace *)malloc(256 * sizeof(PixTrace));
+#pragma omp for schedule(dynamic, 1)
+    for (int b = 0; b < gx * gy; b++) {
+      const int bx = b % gx, by = b / gx;
+      if ((bx + 5 * by) % stride != 0) continue;
+      Ctx c;
+      c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
+      c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = NULL; c.numTex = 0; c.res = &none; c.W = W;
+      memset(px, 0, 256 * sizeof(PixTrace));
+      for (int w = 0; w < 4; w++)
+        for (int l = 0; l < 64; l++) {
+          int x = bx * 32 + w * 8 + (l % 8), y = by * 8 + l / 8;
+          if (x >= W || y >= H) continue;
+          float col[4], br[4];
+          t_pix = &px[w * 64 + l]; t_light = 0; t_phase = 0; t_cullR2 = cullRadius * cullRadius;
+          shadePixel(&c, x, y, W, H, col, br);
+          t_pix = NULL;
+        }
+      sim_workgroup(px, numLights, &k, &loc);
+    }
+    free(px);
+#pragma omp critical
+    {
+      for (int i = 0; i < NSCHED; i++) {
+        tot.wave[i] += loc.wave[i]; tot.lane[i] += loc.lane[i]; tot.primWave[i] += loc.primWave[i];
+        tot.normWave[i] += loc.normWave[i]; tot.shadWave[i] += loc.shadWave[i];
+      }
+      tot.pixels += loc.pixels; tot.hits += loc.hits; tot.rays += loc.rays; tot.evals += loc.evals; tot.iters += loc.iters;
+    }
+  }
+  int o = 0;
+  for (int i = 0; i < NSCHED; i++) out[o++] = tot.wave[i];
+  for (int i = 0; i < NSCHED; i++) out[o++] = tot.lane[i];
+  for (int i = 0; i < NSCHED; i++) out[o++] = tot.primWave[i];
+  for (int i = 0; i < NSCHED; i++) out[o++] = tot.normWave[i];
+  for (int i = 0; i < NSCHED; i++) out[o++] = tot.shadWave[i];
+  out[o++] = tot.pixels; out[o++] = tot.hits; out[o++] = tot.rays; out[o++] = tot.evals; out[o++] = tot.iters;
+  return RM_OK;
+}
