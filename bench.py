@@ -27,46 +27,72 @@ FRACTAL_ITERS = 12
 FLOP_PER_ITER = 67 + 12     # one Mandelbulb inner iteration (frag:786-798)
 FLOP_PER_EVAL = 38 + 3      # one sdScene evaluation besides its iterations (frag:1406-1430, 802, 1461-1469)
 FLOP_PER_HIT = 1800         # 4×pnoise + Phong per shaded pixel
+SFU_PER_ITER, SFU_PER_EVAL = 12, 3  # special-function ops inside the two figures above
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+PEAK_LANE_SLOTS = 256 * 4 * 32 * 2.4e9  # VALU issue slots per second: 256 CUs x 4 SIMD-32 at 2.4 GHz (an fma = 1 slot = 2 flop)
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def cpu_baseline(settings):
-    """Oracle (CPU port of the same frame) timed on a bounded, unbiased sample of the same workload:
-    row-strided passes over the 4K frame (stride 8, offsets 4,0,1,…) until ≈10 s of wall time or the
-    whole frame is done.  One OpenMP-free oracle call per row, `cores` rows in flight."""
+def host_cores():
+    """CPU cores this process may really use: the affinity mask capped by the cgroup CPU quota (a one-GPU box exposes
+    every core of the host in the mask but grants a 16-core share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p_ = int(f.read()), int(g.read())
+            if q > 0:
+                n = max(1, min(n, -(-q // p_)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(settings, gpu_frame):
+    """The oracle (the CPU port of the same frame, built -O3) on the host's cores: the WHOLE 3840x2160 frame in one
+    OpenMP call (schedule(dynamic) over rows, every core), then a bounded single-thread sample (every 72nd row).  The
+    oracle's frame is then compared bit for bit with `gpu_frame` — the frame the timed region produced — so the number
+    this line reports is for a frame that was checked in the same run."""
     import ctypes as C
     import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as h
     from raymarcher_amd import scenes
     t = scenes.mandelbulb(W, H)
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     lib = h.oracle()
 
-    def one(r):
-        buf = np.empty((1, W, 4), dtype=np.float32)
+    def render(rows0, rows1, threads, out):
         st = lib.rmo_render(C.byref(t.camera), t.objects, t.num_objects, t.lights, t.num_lights, C.byref(t.globals_),
-                            C.byref(settings), W, H, r, r + 1, h.fptr(buf), None, None, 1)
+                            C.byref(settings), W, H, rows0, rows1, h.fptr(out), None, None, threads)
         assert st == 0
-        return r
 
-    done_rows, passes = 0, []
+    frame = np.empty((H, W, 4), dtype=np.float32)
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        for off in (4, 0, 1, 2, 3, 5, 6, 7):
-            rows = list(range(off, H, 8))
-            list(ex.map(one, rows))
-            done_rows += len(rows)
-            passes.append(off)
-            if time.perf_counter() - t0 > 10.0:
-                break
+    render(0, H, cores, frame)
     dt = time.perf_counter() - t0
-    what = "the whole frame" if done_rows == H else f"rows ≡ {passes} (mod 8): {done_rows} of {H} rows"
-    return {"value": round(done_rows * W / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{what} of the same 3840x2160 Mandelbulb frame ({done_rows * W} px), {dt:.1f} s wall, "
-                      f"scalar C oracle, one row per task on {cores} threads"}
+    # single thread: rows 36, 108, ... (30 rows spread over the frame) — bounded to a few seconds
+    rows1 = list(range(36, H, 72))
+    buf = np.empty((1, W, 4), dtype=np.float32)
+    t1 = time.perf_counter()
+    for r in rows1:
+        render(r, r + 1, 1, buf)
+    dt1 = time.perf_counter() - t1
+    got = gpu_frame.cpu().numpy()
+    bad = int((got.view(np.uint32) != frame.view(np.uint32)).sum())
+    parity = {"rows": H, "pixels": W * H, "mismatched_words": bad,
+              "what": "the last frame of the timed region against the oracle's frame rendered in this run, 32-bit words"}
+    base = {"value": round(W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"the whole 3840x2160 Mandelbulb frame ({W * H} px) in {dt:.2f} s: scalar C oracle -O3, one OpenMP "
+                      f"call, schedule(dynamic) over rows on {cores} threads",
+            "single_thread": {"value": round(len(rows1) * W / dt1 / 1e6, 5), "unit": "Mpixels/s", "cores": 1,
+                              "sample": f"{len(rows1)} rows (every 72nd) of the same frame, {len(rows1) * W} px in {dt1:.1f} s"}}
+    return base, parity
 
 
 def main():
@@ -138,6 +164,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    timed_frame = frame_holder["f"].clone() if rank == 0 else None  # what the timed region produced (checked below)
     import ctypes as C
     kms, kn = C.c_double(), C.c_int()
     stages = (C.c_double * 4)()
@@ -172,10 +199,17 @@ def main():
                    "what": "RM_FEAT_BULB_POWER8_ALGEBRAIC: w^8 by complex squarings instead of acos/atan/sin/cos/pow; same "
                            "function, |ΔDE| median 4e-8, 0.08 % of frame pixels differ by > 1e-3 from the headline frame"}
 
-    # algorithmic work of this rank's launch, from the frame's deterministic counters (outside the timed region)
-    cnt = None
+    # work of this rank's launch from the frame's deterministic counters (outside the timed region): what the REFERENCE's
+    # formulation does (algorithmic) and what the production kernel really executes (bit-identical shortcuts honoured);
+    # then the shader clock the chip held under this kernel's own load (stamped diagnostic build, after the timed launches)
+    cnt = cnt_exec = None
+    clock_mhz = None
     if rank == 0:
-        _, cnt = r.render_counted(tables, settings, W, H)
+        _, cnt = r.render_counted(tables, settings, W, H, abi.RM_COUNT_REFERENCE)
+        _, cnt_exec = r.render_counted(tables, settings, W, H, abi.RM_COUNT_EXECUTED)
+        for _ in range(5):
+            r.render(tables, settings, W, H, out=mine)
+        _, clock_mhz = r.render_clocked(tables, settings, W, H)
     if rank == 0:
         path = int(os.environ.get("RM_KERNEL_PATH", "0"))
         kernel_name = {0: "rm::render_kernel<BULB=true,COUNT=false,ENV=false,TEX=false> (one lane per pixel, 8x8 tile per wave)",
@@ -184,10 +218,18 @@ def main():
                        3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)",
                        4: "pipeline C: pipeline B with step-budgeted march passes and re-compaction"}[path]
         mpix = W * H * args.steps / dt / 1e6
-        flops_frame = cnt.bulbIters * FLOP_PER_ITER + cnt.sceneEvals * FLOP_PER_EVAL + cnt.hitPixels * FLOP_PER_HIT
+        def work(c):  # (flop, issue slots) of a frame with these counters; an SFU op is 1 flop-equivalent but 4 slots
+            flop = c.bulbIters * FLOP_PER_ITER + c.sceneEvals * FLOP_PER_EVAL + c.hitPixels * FLOP_PER_HIT
+            slots = (c.bulbIters * (FLOP_PER_ITER - SFU_PER_ITER) + c.sceneEvals * (FLOP_PER_EVAL - SFU_PER_EVAL)
+                     + c.hitPixels * FLOP_PER_HIT) / 2 + 4 * (c.bulbIters * SFU_PER_ITER + c.sceneEvals * SFU_PER_EVAL)
+            return flop, slots
+        flops_frame, slots_frame = work(cnt)
+        flops_exec, slots_exec = work(cnt_exec)
         # the dominant kernel of one launch processes 1/world of the frame (interleaved tiles ≈ equal work)
         flops_launch = flops_frame / world
-        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        secs = kernel_ms * 1e-3
+        achieved = flops_launch / secs / 1e12 if kernel_ms > 0 else 0.0
+        executed = flops_exec / world / secs / 1e12 if kernel_ms > 0 else 0.0
         bytes_launch = W * H * 16 / world
         line = {
             "metric": "Mpixels/s at 3840x2160 Mandelbulb, 256 march steps",
@@ -202,10 +244,22 @@ def main():
                        "parity": "bit-exact vs CPU oracle (rm_math contract)"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                         # HBM bytes per launch measured with rocprofv3 PMC (WRITE_SIZE + 2·FETCH_SIZE, separate passes):
-                         # exactly 16 B/pixel written + 0.55 MB read — profiles/r01_k_hbm_pmc.md
-                         "traffic": int(bytes_launch + 552000) if path in (0, 1) else None,
-                         "traffic_source": "profiles/r01_k_hbm_pmc.md (rocprofv3 PMC of this kernel and workload)",
+                         # algorithmic = the reference's work ÷ this kernel's time; executed = the work this kernel really
+                         # does (bounding-ball culls, no shadow march for dropped lights) ÷ the same time
+                         "executed": {"achieved": round(executed, 3), "frac": round(executed / PEAK_FP32_TFLOPS, 4),
+                                      "sceneEvals": cnt_exec.sceneEvals, "bulbIters": cnt_exec.bulbIters,
+                                      "flop_per_launch": flops_exec / world},
+                         # issue-slot view: an fma is one VALU slot, a special-function op four
+                         "slots": {"algorithmic_frac": round(slots_frame / world / secs / PEAK_LANE_SLOTS, 4) if kernel_ms > 0 else 0.0,
+                                   "executed_frac": round(slots_exec / world / secs / PEAK_LANE_SLOTS, 4) if kernel_ms > 0 else 0.0,
+                                   "peak_lane_slots_per_s": PEAK_LANE_SLOTS},
+                         "shader_clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
+                         "clock_source": "s_memtime / s_memrealtime stamps of every wave of one launch of the same kernel "
+                                         "(diagnostic build, rm_render_clocked) after back-to-back launches",
+                         # HBM bytes are not measured by this run: algorithmic 16 B/pixel written; the PMC measurement of this
+                         # kernel (WRITE_SIZE + 2·FETCH_SIZE, separate passes) is in profiles/ (133.26 MB per 4K launch)
+                         "traffic": None,
+                         "traffic_source": "not collected by bench.py; rocprofv3 PMC: profiles/r01_k_hbm_pmc.md",
                          "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "stage_ms": {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
                                       "shadow": round(stages[2], 4), "shade": round(stages[3], 4)},
@@ -217,7 +271,7 @@ def main():
         if variant is not None:
             line["variants"] = {"bulb_power8_algebraic": variant}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(settings)
+            line["cpu_baseline"], line["parity_check"] = cpu_baseline(settings, timed_frame)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

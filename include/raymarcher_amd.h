@@ -14,9 +14,13 @@
  *    frag:2572-2574); rm_frame_to_rgba8() applies the vertical flip of Realtime::saveViewportImage
  *    (src/realtime.cpp:337-338);
  *  - d_* pointers are DEVICE pointers owned by the caller (hipMalloc / torch tensor storage); render calls are
- *    asynchronous on the caller's stream.  The library keeps a small per-device scene ring and, for the
- *    Mandelbulb pipeline, a grow-only workspace (≤ 52 B/pixel + 8 B per pixel·light) that is (re)allocated —
- *    with a stream synchronise — only when a larger frame than any before is rendered;
+ *    asynchronous on the caller's stream and act on the calling thread's current device.  Library state is per device
+ *    (a ring of 7 KB scene-table slots that grows instead of blocking, timing records) and, for scratch memory, per
+ *    (device, stream): rm_post_process and the experimental Mandelbulb pipelines keep a grow-only workspace for each
+ *    stream they are called on (≤ 20 B/pixel resp. ≤ 52 B/pixel + 8 B per pixel·light), (re)allocated — with a
+ *    synchronise of that stream — only when a larger frame than any before is processed on it.  Calls on different
+ *    streams or devices may be issued concurrently from different host threads; calls on ONE stream must come from one
+ *    thread at a time (as with any HIP stream);
  *  - every function returns an rm_status; no exception crosses this boundary (the reference throws
  *    std::runtime_error on shader failure, src/utils/shaderloader.h:39,83, and prints + returns on
  *    scene errors, src/raymarch/raymarchscene.cpp:111).
@@ -30,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 2
+#define RM_ABI_VERSION 3
 
 /* Capacity limits — src/realtime.h:17-27 (MAX_NUM_LIGHTS 10, MAX_NUM_SHAPES 30). */
 #define RM_MAX_LIGHTS 10
@@ -88,7 +92,7 @@ typedef struct RmObject {
   float cSpecular[3];
   float cReflective[3];
   float cTransparent[3];
-  int32_t texLoc;        /* -1 = untextured (only value accepted in this ABI version) */
+  int32_t texLoc;        /* -1 = untextured; 0..numTextures-1 = index into RmResources.textures (rm_render_ex / rm_render_res) */
   float repeatU;
   float repeatV;
   int32_t isEmissive;    /* the rectangle drawn for an area light (raymarchscene.cpp:121-133): rendered as `color` */
@@ -250,13 +254,28 @@ typedef struct RmCounters {
   uint64_t bulbIters;    /* Mandelbulb inner iterations (frag:785-799) */
   uint64_t hitPixels;    /* pixels whose primary ray hit */
 } RmCounters;
-/* Same as rm_render but also accumulates counters with device atomics (slower; synchronises). */
+/* Same as rm_render but also accumulates counters with device atomics (slower; synchronises).  Counts the REFERENCE's
+ * work: every evaluation the shader as written performs, i.e. without the bit-identical shortcuts of the production
+ * kernels (marches ended at the scene's bounding ball, no shadow march for a light that N·L <= 0.005 drops anyway). */
 int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
                       int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
                       int rowEnd, float *d_rgba, float *d_bright, RmCounters *out);
+/* mode RM_COUNT_REFERENCE = rm_render_counted; RM_COUNT_EXECUTED counts the work the production kernel really executes
+ * (shortcuts honoured) — the pair gives the algorithmic and the executed figure of the roofline.  Scenes that need the
+ * procedural layers or samplers are rendered but not counted (counters stay 0). */
+enum { RM_COUNT_REFERENCE = 1, RM_COUNT_EXECUTED = 2 };
+int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
+                         int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
+                         int rowEnd, float *d_rgba, float *d_bright, int mode, RmCounters *out);
+/* Diagnostic build of the single-Mandelbulb kernel (production code + s_memtime / s_memrealtime stamps per wave, written
+ * to a buffer of their own): renders the whole frame once, synchronises and returns the shader clock the chip held under
+ * this kernel's own load, in MHz (Σ cycle spans ÷ Σ 100 MHz-tick spans over all waves).  Call it after a few back-to-back
+ * renders so that the clock has settled. */
+int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                      const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz);
 
-/* Average device time in ms of the last `rm_render*` kernel launches timed with hipEvents on their own
- * stream when profiling is switched on with rm_set_timing(1); resets the accumulator. */
+/* Average device time in ms of the `rm_render*` launches made on the CURRENT device since rm_set_timing(1), timed with
+ * hipEvents on their own stream; rm_get_* reads and resets that device's records (the on/off switch is process-wide). */
 int rm_set_timing(int on);
 int rm_get_timing(double *avgKernelMs, int *launches);
 /* Same, split by pipeline stage.  The single-Mandelbulb scene class renders as four kernels (primary march,

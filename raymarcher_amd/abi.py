@@ -5,7 +5,8 @@ struct against the library's own `rm_abi_sizeof`.
 """
 import ctypes as C
 
-RM_ABI_VERSION = 2
+RM_ABI_VERSION = 3
+RM_COUNT_REFERENCE, RM_COUNT_EXECUTED = 1, 2
 RM_MAX_LIGHTS = 10
 RM_MAX_OBJECTS = 30
 

@@ -78,7 +78,9 @@ struct MarchRes { int obj; float d; V4 trap; };
 struct Hit { V3 rd, p, n; int obj; };
 struct RenderOut { V3 col; int isEnv; float d; };
 
-// Per-lane work counters (only live in the COUNT instantiation).
+// Per-lane work counters (only live in the counting instantiations).  COUNT is a mode: 0 = no counters (production),
+// 1 = count the REFERENCE's work (no bounding-ball culls, shadow rays of dropped lights still marched — the algorithmic
+// figure of the roofline), 2 = count the work the production kernel really executes (culls and skips honoured).
 struct Counters { unsigned long long evals, iters; };
 
 // ---- primitives (frag:832-894, 991-1019), unit sizes of sdMatch (frag:1262-1293) -------------------
@@ -163,7 +165,7 @@ RM_DEV float sdMandelBrot(const SceneBlock *sb, float px, float py) {
 enum BulbMode { BULB_GENERIC = 0, BULB_TRIG8 = 1, BULB_ALGEBRAIC8 = 2 };
 // TRAP = false drops the orbit trap altogether: shadow marches, normal taps and AO taps never read it (with the select
 // form the compiler removed it there by itself; the v_min_f32 form is inline asm, so it is spelled out).
-template <bool COUNT, int MODE, bool TRAPMIN, bool TRAP>
+template <int COUNT, int MODE, bool TRAPMIN, bool TRAP>
 RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
   const float power = sb->g.power;
   const float pexp = (power - 1.0f) / 2.0f;
@@ -227,7 +229,7 @@ RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &c
   resColor = v4(m, trap.y, trap.z, trap.w);
   return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;  // frag:802
 }
-template <bool COUNT, bool TRAPMIN, bool TRAP>
+template <int COUNT, bool TRAPMIN, bool TRAP>
 RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
   if (sb->g.power == 8.0f) {  // wave-uniform
     if (sb->s.features & RM_FEAT_BULB_POWER8_ALGEBRAIC) return bulbIterate<COUNT, BULB_ALGEBRAIC8, TRAPMIN, TRAP>(sb, pos, resColor, cnt);
@@ -279,7 +281,7 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
 // ---- scene union (frag:1406-1430) ---------------------------------------------------------------------
 // BULB=true is the single-Mandelbulb scene class (numObjects == 1, type MANDELBULB): same arithmetic,
 // no table walk.
-template <bool BULB, bool COUNT, bool TRAP = true>
+template <bool BULB, int COUNT, bool TRAP = true>
 RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
   SceneMin res;
   res.d = 1000000.0f;
@@ -306,7 +308,7 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
       case RM_DEATHSTAR: d = sdDeathStar(po, 0.5f, 0.35f, 0.5f); break;
       case RM_RECTANGLE: d = sdBox(po, 0.5f, 0.5f, 0.0f); break;
       case RM_MANDELBROT: d = sdMandelBrot(sb, po.x, po.y); break;
-      case RM_MANDELBULB: d = sdMandelBulb<COUNT, BULB && !COUNT, TRAP>(sb, po, res.trap, cnt); break;
+      case RM_MANDELBULB: d = sdMandelBulb<COUNT, BULB && COUNT == 0, TRAP>(sb, po, res.trap, cnt); break;
       case RM_MENGERSPONGE: d = sdMengerSponge(sb, po, res.trap); break;
       case RM_SIERPINSKI: d = sdSierpinski(po); break;
       default: continue;
@@ -318,7 +320,7 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
 }
 
 // frag:1436-1444
-template <bool BULB, bool COUNT>
+template <bool BULB, int COUNT>
 RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
   const float ex = (1.0f * 0.5773f) * 0.0005f, ey = (-1.0f * 0.5773f) * 0.0005f;
   float d[4];
@@ -393,9 +395,9 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R
   if (!(a > 0.0f)) return end;
   return min_(end, tExit);
 }
-template <bool BULB, bool COUNT, bool SHADOW, bool CULL = false>
+template <bool BULB, int COUNT, bool SHADOW, bool CULL = false>
 RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
-  if (CULL && !COUNT) {
+  if (CULL && COUNT != 1) {
     const bool softRay = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform
     if (BULB && !softRay) end = bulbCullEnd(sb, ro, rd, end);
     else end = sceneCullEnd(sb, ro, rd, end, softRay ? sb->cullR2Soft : sb->cullR2);
@@ -491,7 +493,7 @@ RM_DEV V3 bumpNormal(V3 normal, V3 pos) {  // frag:1679-1691, BUMP_SCALE 10, BUM
 
 // ---- shading --------------------------------------------------------------------------------------------
 // frag:1729-1740
-template <bool BULB, bool COUNT>
+template <bool BULB, int COUNT>
 RM_DEV float calcAO(const SceneBlock *sb, V3 pos, V3 nor, Counters &cnt) {
   float occ = 0.0f, sca = 1.0f;
   for (int i = 0; i < 5; i++) {
@@ -675,7 +677,7 @@ RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
 // RES = true adds the area-light branch (frag:1884-1905); `objs` is only read there.
 // CULLS: end marches at the scene's bounding ball (off in the ENV instantiations, whose register budget it would break).
-template <bool BULB, bool COUNT, bool RES, bool CULLS>
+template <bool BULB, int COUNT, bool RES, bool CULLS>
 RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
   const float ka = sb->g.ka, ks = sb->g.ks;
   float ao = 1.0f;
@@ -705,7 +707,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
     // work so that the counters stay the algorithmic ones).
     MarchRes sh;
     sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (COUNT || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt);
+    if (COUNT == 1 || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt);
     V3 cur;
     if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
@@ -722,7 +724,7 @@ RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
 }
 
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
-template <bool BULB, bool COUNT, bool TEX, bool CULLS>
+template <bool BULB, int COUNT, bool TEX, bool CULLS>
 RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
                         V3 bg, Counters &cnt) {
   RenderOut out;
@@ -800,7 +802,7 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
 // raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
 // ENV = false compiles the procedural layers out (the launcher picks the instantiation from the feature bits),
 // so the common kernels do not carry their registers and code.
-template <bool BULB, bool COUNT, bool ENV, bool TEX>
+template <bool BULB, int COUNT, bool ENV, bool TEX>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
                        V4 &bright, Counters &cnt, bool &hitFlag) {
   float ndcx, ndcy;

@@ -6,7 +6,9 @@
 #include <vector>
 #include <cstdint>
 
-#ifndef __HIPCC__
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#else
 #define __host__
 #define __device__
 #endif
@@ -22,6 +24,14 @@ void set_error(const std::string &msg);
 bool device_accessible(const void *p);
 // RM_ERR_INVALID_ARGUMENT (+ rm_last_error text) unless every non-null pointer of the list is device-accessible.
 int require_device_pointers(std::initializer_list<std::pair<const char *, const void *>> ptrs);
+
+#ifdef __HIPCC__
+// Grow-only device scratch memory owned by the library, one buffer per (current device, stream, user tag): calls on
+// different streams of one device may run concurrently on the GPU and therefore never share scratch.  Growing
+// synchronises `stream` (nothing else uses the old buffer) and reallocates.  Returns an rm_status.
+enum { kWsBulbPipeline = 1, kWsPost = 2 };
+int stream_workspace(int tag, hipStream_t stream, size_t need, void **out);
+#endif
 
 // Baseline JPEG → RGBA8, top row first (rm_jpeg.cpp).
 int jpeg_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, int &W, int &H);

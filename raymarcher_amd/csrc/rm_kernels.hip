@@ -6,9 +6,12 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "rm_bulb_pipeline.hip.h"
@@ -41,11 +44,18 @@ int require_device_pointers(std::initializer_list<std::pair<const char *, const 
 constexpr int kTileW = RM_TILE_W, kTileH = 64 / RM_TILE_W;
 constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 
-template <bool BULB, bool COUNT, bool ENV, bool TEX>
+// COUNT: 0 production, 1 reference-work counters, 2 executed-work counters (rm_device.hip.h), 3 production code plus clock
+// stamps: every wave adds its (s_memtime, s_memrealtime) spans to counters[3], counters[4] — shader cycles and 100 MHz
+// ticks — from which rm_render_clocked derives the clock the chip held under this kernel's own load.  The stamps go to a
+// buffer of their own and no output value depends on them.
+template <bool BULB, int COUNT, bool ENV, bool TEX>
 __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
                                                       unsigned long long *__restrict__ counters) {
+  constexpr int CM = (COUNT == 3) ? 0 : COUNT;  // counting mode of the device code
+  unsigned long long t0 = 0, r0 = 0;
+  if (COUNT == 3) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   // LDS copy of the object table for per-lane (divergent) material lookups.
   __shared__ RmObject s_objs[RM_MAX_OBJECTS];
   {
@@ -65,14 +75,21 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
   V4 col, br;
   Counters cnt{0, 0};
   bool hit;
-  shadePixel<BULB, COUNT, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, CM, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
-  if (COUNT) {
+  if (CM) {
     atomicAdd(&counters[0], cnt.evals);
     atomicAdd(&counters[1], cnt.iters);
     if (hit) atomicAdd(&counters[2], 1ull);
+  }
+  if (COUNT == 3) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((int)__lane_id() == __builtin_ctzll(__ballot(1))) {  // first live lane of the wave
+      atomicAdd(&counters[3], t1 - t0);
+      atomicAdd(&counters[4], r1 - r0);
+    }
   }
 }
 
@@ -102,7 +119,7 @@ __global__ void probe_sdscene_kernel(const SceneBlock *__restrict__ sb, const fl
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Counters cnt{0, 0};
-  SceneMin m = sdScene<false, false>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
+  SceneMin m = sdScene<false, 0>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
   out[4 * i] = m.d;
   out[4 * i + 1] = (float)m.idx;
   out[4 * i + 2] = m.trap.y;
@@ -133,8 +150,11 @@ __global__ void deinterleave_kernel(const float4 *__restrict__ in, float4 *__res
 }
 
 // ---- launcher state -------------------------------------------------------------------------------------
+// Everything is per device: a host thread driving GPU k never takes a lock that a thread driving GPU j holds, and no lock
+// is held across a blocking HIP call on the launch path.  Scratch memory is per (device, stream): two calls on different
+// streams of one device may overlap on the GPU, so they must not share ping-pong buffers or hit lists.
 namespace {
-constexpr int kSlots = 8;
+constexpr int kSlotsInit = 8, kSlotsMax = 64;
 constexpr int kAutoBulbPath = 1;  // what rm_set_kernel_path(0) picks for the single-Mandelbulb class (measured best)
 struct Slot {
   SceneBlock *host = nullptr;  // pinned
@@ -142,22 +162,18 @@ struct Slot {
   hipEvent_t done = nullptr;
   bool used = false;
 };
+struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (single kernel) or 5 (pipeline K1..K4 boundaries)
 struct DeviceState {
-  Slot slots[kSlots];
-  int next = 0;
-  unsigned long long *dCounters = nullptr;
-  bool init = false;
-  // wavefront-pipeline workspace (grow-only; allocated outside any capture, on first use / growth)
-  void *wsMem = nullptr;
-  size_t wsBytes = 0;
+  std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
+  std::vector<Slot> slots;       // ring of scene-table slots; grows (to kSlotsMax) instead of waiting for a busy slot
+  size_t next = 0;
+  unsigned long long *dCounters = nullptr;  // 5 words: evals, iterations, hits, clock stamps (counted renders synchronise)
+  std::vector<TimedLaunch> timed;           // rm_set_timing / rm_get_timing, per device
   int numCUs = 0;
 };
-std::mutex g_mu;
 DeviceState g_dev[64];
-bool g_timing = false;
-int g_kernelPath = 0;  // rm_set_kernel_path: 0 auto, 1 one-lane-per-pixel, 2 pipeline A (state machine), 3 pipeline B (plain loops)
-struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (single kernel) or 5 (pipeline K1..K4 boundaries)
-std::vector<TimedLaunch> g_timed;
+std::atomic<bool> g_timing{false};
+std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one-lane-per-pixel, 2 pipeline A (state machine), 3 pipeline B (plain loops)
 
 #define HIP_OK(expr)                                                                              \
   do {                                                                                            \
@@ -168,45 +184,83 @@ std::vector<TimedLaunch> g_timed;
     }                                                                                             \
   } while (0)
 
-int acquire_slot(Slot **out) {
-  int dev = 0;
-  HIP_OK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) { set_error("device index out of range"); return RM_ERR_DEVICE; }
-  DeviceState &ds = g_dev[dev];
-  if (!ds.init) {
-    for (auto &s : ds.slots) {
-      HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&s.host), sizeof(SceneBlock), hipHostMallocDefault));
-      HIP_OK(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(SceneBlock)));
-      HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    }
-    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 3 * sizeof(unsigned long long)));
-    ds.init = true;
+int new_slot(Slot *s) {
+  HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&s->host), sizeof(SceneBlock), hipHostMallocDefault));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&s->dev), sizeof(SceneBlock)));
+  HIP_OK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+  return RM_OK;
+}
+// Caller holds ds.mu.  Returns a slot whose previous launch (if any) has finished: the next slot of the ring if its event
+// has fired, otherwise a fresh one — the enqueue path never blocks on the GPU while it holds the device lock.  Only when
+// kSlotsMax launches are in flight does it wait (hipEventSynchronize on the oldest), which bounds pinned memory.
+int acquire_slot(DeviceState &ds, Slot **out) {
+  if (ds.slots.empty()) {
+    ds.slots.resize(kSlotsInit);
+    for (auto &s : ds.slots) { int st = new_slot(&s); if (st != RM_OK) return st; }
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 5 * sizeof(unsigned long long)));
   }
-  Slot &s = ds.slots[ds.next];
-  ds.next = (ds.next + 1) % kSlots;
-  if (s.used) HIP_OK(hipEventSynchronize(s.done));  // only blocks with > kSlots launches in flight
-  s.used = true;
-  *out = &s;
+  Slot *s = &ds.slots[ds.next];
+  if (s->used) {
+    const hipError_t q = hipEventQuery(s->done);
+    if (q == hipErrorNotReady) {
+      if ((int)ds.slots.size() < kSlotsMax) {
+        ds.slots.insert(ds.slots.begin() + (long)ds.next, Slot{});  // a fresh slot in front of the busy one keeps ring order
+        s = &ds.slots[ds.next];
+        int st = new_slot(s);
+        if (st != RM_OK) { ds.slots.erase(ds.slots.begin() + (long)ds.next); return st; }
+      } else {
+        HIP_OK(hipEventSynchronize(s->done));
+      }
+    } else if (q != hipSuccess) {
+      set_error(std::string("hipEventQuery: ") + hipGetErrorString(q));
+      return RM_ERR_DEVICE;
+    }
+  }
+  ds.next = (ds.next + 1) % ds.slots.size();
+  s->used = true;
+  *out = s;
   return RM_OK;
 }
 
+// Grow-only scratch memory of one (device, stream, user): see rm_internal.h.
+struct WsKey { int dev; hipStream_t stream; int tag; bool operator<(const WsKey &o) const { return std::tie(dev, stream, tag) < std::tie(o.dev, o.stream, o.tag); } };
+struct WsBuf { void *mem = nullptr; size_t bytes = 0; };
+std::mutex g_wsMu;
+std::map<WsKey, WsBuf> g_ws;
+}  // namespace
+
+int stream_workspace(int tag, hipStream_t stream, size_t need, void **out) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  WsBuf *b;
+  {
+    std::lock_guard<std::mutex> lock(g_wsMu);
+    b = &g_ws[WsKey{dev, stream, tag}];  // std::map nodes are stable: the pointer outlives the lock
+  }
+  // only work enqueued on `stream` uses this buffer, and one host thread enqueues on a stream at a time
+  if (b->bytes < need) {
+    HIP_OK(hipStreamSynchronize(stream));
+    if (b->mem) HIP_OK(hipFree(b->mem));
+    b->mem = nullptr; b->bytes = 0;
+    HIP_OK(hipMalloc(&b->mem, need));
+    b->bytes = need;
+  }
+  *out = b->mem;
+  return RM_OK;
+}
+namespace {
+
 // Carve the pipeline workspace for `pixels` pixels and `nl` lights out of the device allocation.
-int bulb_workspace(DeviceState &ds, size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWsB *wsB, BulbWsC *wsC,
-                   bool withQueues) {
+int bulb_workspace(size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWsB *wsB, BulbWsC *wsC, bool withQueues) {
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
   const size_t nlq = (size_t)(nl > 0 ? nl : 1);
   const size_t oCnt = 0, oPix = align(256), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
                oN = oP + align(pixels * 16), oSh = oN + align(pixels * 16), oRay = oSh + align(pixels * nlq * 8),
                oQ = oRay + align(pixels * nlq * 4),
                qBytes = withQueues ? 2 * (3 * align(pixels * 4) + 4 * align(pixels * nlq * 4)) : 0, total = oQ + qBytes;
-  if (total > ds.wsBytes) {
-    HIP_OK(hipStreamSynchronize(stream));
-    if (ds.wsMem) HIP_OK(hipFree(ds.wsMem));
-    ds.wsMem = nullptr; ds.wsBytes = 0;
-    HIP_OK(hipMalloc(&ds.wsMem, total));
-    ds.wsBytes = total;
-  }
-  char *b = static_cast<char *>(ds.wsMem);
+  void *mem = nullptr;
+  if (int st = stream_workspace(kWsBulbPipeline, stream, total, &mem)) return st;
+  char *b = static_cast<char *>(mem);
   ws->counters = reinterpret_cast<uint32_t *>(b + oCnt);
   ws->hitPix = reinterpret_cast<int *>(b + oPix);
   ws->hitRec = reinterpret_cast<float4 *>(b + oRec);
@@ -393,9 +447,10 @@ void scene_cull_ball(SceneBlock *h) {
 }
 
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                const RmGlobals *g, const RmSettings *s, hipStream_t stream, Slot **slotOut, const RmResources &res) {
+                const RmGlobals *g, const RmSettings *s, hipStream_t stream, DeviceState &ds, Slot **slotOut,
+                const RmResources &res) {  // caller holds ds.mu
   Slot *slot;
-  int st = acquire_slot(&slot);
+  int st = acquire_slot(ds, &slot);
   if (st != RM_OK) return st;
   SceneBlock *h = slot->host;
   h->cam = *cam; h->g = *g; h->s = *s;
@@ -415,29 +470,32 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                   const RmGlobals *g, const RmSettings *s, int W, int H, RowMap map, int nRows, float *d_rgba,
-                  float *d_bright, hipStream_t stream, bool count, RmCounters *countersOut,
-                  const RmResources &res = kNoResources) {
-  std::lock_guard<std::mutex> lock(g_mu);
+                  float *d_bright, hipStream_t stream, int count, RmCounters *countersOut,
+                  const RmResources &res = kNoResources, double *clockMHz = nullptr) {
+  // count: 0 production launch, 1 / 2 counted (reference work / executed work; synchronises), 3 production code with clock stamps
   int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s, res);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || nRows < 0) { set_error("bad frame size"); return RM_ERR_INVALID_ARGUMENT; }
   if (nRows == 0) return RM_OK;  // empty row range: nothing to write, a null buffer is fine
   if (!d_rgba) { set_error("null output buffer"); return RM_ERR_INVALID_ARGUMENT; }
   if ((st = check_device_pointers(res, d_rgba, d_bright)) != RM_OK) return st;
-  Slot *slot;
-  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, &slot, res);
-  if (st != RM_OK) return st;
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
-  unsigned long long *dc = g_dev[dev].dCounters;
-  if (count) HIP_OK(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), stream));
+  if (dev < 0 || dev >= 64) { set_error("device index out of range"); return RM_ERR_DEVICE; }
+  DeviceState &ds = g_dev[dev];
+  std::lock_guard<std::mutex> lock(ds.mu);  // this device only; nothing below blocks on the GPU unless `count` asks for numbers back
+  Slot *slot;
+  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res);
+  if (st != RM_OK) return st;
+  unsigned long long *dc = ds.dCounters;
+  if (count) HIP_OK(hipMemsetAsync(dc, 0, 5 * sizeof(unsigned long long), stream));
   dim3 grid((W + kBlockW - 1) / kBlockW, (nRows + kBlockH - 1) / kBlockH), block(256);
   const bool bulb = (numObjects == 1 && objs[0].type == RM_MANDELBULB);
   auto nonzero3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
   // The wavefront pipeline covers the single-Mandelbulb class without secondary rays; everything else (and the
   // counted variant) runs the one-lane-per-pixel kernel.  Both produce the same bits.
   static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
-  int path = g_kernelPath ? g_kernelPath : envPath;
+  int path = g_kernelPath.load() ? g_kernelPath.load() : envPath;
   if (path == 0) path = kAutoBulbPath;
   const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND | RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) != 0;
   // anything that reads a sampler or takes the area-light branches: object textures, sky box, emissive rectangles, area lights
@@ -448,8 +506,9 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
   TimedLaunch tl{};
+  const bool timing = g_timing.load();
   auto stamp = [&](int i) -> int {
-    if (!g_timing) return RM_OK;
+    if (!timing) return RM_OK;
     HIP_OK(hipEventCreate(&tl.ev[i]));
     HIP_OK(hipEventRecord(tl.ev[i], stream));
     tl.n = i + 1;
@@ -457,7 +516,6 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   };
   float4 *o = reinterpret_cast<float4 *>(d_rgba), *b = reinterpret_cast<float4 *>(d_bright);
   if (pipeline) {
-    DeviceState &ds = g_dev[dev];
     if (ds.numCUs == 0) {
       hipDeviceProp_t prop;
       HIP_OK(hipGetDeviceProperties(&prop, dev));
@@ -468,7 +526,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     BulbWsC wsC;
     // hit-list capacity: every pixel may hit, plus one partly used 64-slot chunk per persistent wave
     const size_t slots = (size_t)nRows * W + (size_t)kSlotChunk * ds.numCUs * 8 * 4;
-    st = bulb_workspace(ds, slots, numLights, stream, &ws, &wsB, &wsC, path == 4);
+    st = bulb_workspace(slots, numLights, stream, &ws, &wsB, &wsC, path == 4);
     if (st != RM_OK) return st;
     HIP_OK(hipMemsetAsync(ws.counters, 0, 256, stream));
     // tuning knobs for A/B runs (defaults are the measured best)
@@ -516,28 +574,40 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // compiled out so the common kernels keep their register budget.
 #define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
-      if (envFeatures && textured) RM_LAUNCH(false, false, true, true);
-      else if (envFeatures) RM_LAUNCH(false, false, true, false);
-      else RM_LAUNCH(false, false, false, true);
+      if (envFeatures && textured) RM_LAUNCH(false, 0, true, true);
+      else if (envFeatures) RM_LAUNCH(false, 0, true, false);
+      else RM_LAUNCH(false, 0, false, true);
     } else if (bulb) {
-      if (count) RM_LAUNCH(true, true, false, false);
-      else RM_LAUNCH(true, false, false, false);
+      if (count == 1) RM_LAUNCH(true, 1, false, false);
+      else if (count == 2) RM_LAUNCH(true, 2, false, false);
+      else if (count == 3) RM_LAUNCH(true, 3, false, false);
+      else RM_LAUNCH(true, 0, false, false);
     } else {
-      if (count) RM_LAUNCH(false, true, false, false);
-      else RM_LAUNCH(false, false, false, false);
+      if (count == 1) RM_LAUNCH(false, 1, false, false);
+      else if (count == 2) RM_LAUNCH(false, 2, false, false);
+      else RM_LAUNCH(false, 0, false, false);
     }
 #undef RM_LAUNCH
     if ((st = stamp(1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
-  if (g_timing) g_timed.push_back(tl);
+  if (timing) ds.timed.push_back(tl);
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
-    unsigned long long hc[3];
+    unsigned long long hc[5];
     HIP_OK(hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (countersOut) { countersOut->sceneEvals = hc[0]; countersOut->bulbIters = hc[1]; countersOut->hitPixels = hc[2]; }
+    if (clockMHz) *clockMHz = hc[4] ? 100.0 * (double)hc[3] / (double)hc[4] : 0.0;
   }
+  return RM_OK;
+}
+// the device the calling thread has current
+int current_device_state(DeviceState **out) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { set_error("device index out of range"); return RM_ERR_DEVICE; }
+  *out = &g_dev[dev];
   return RM_OK;
 }
 }  // namespace
@@ -564,7 +634,7 @@ int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const R
   int n = rowEnd - rowBegin;
   RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
-                       static_cast<hipStream_t>(stream), false, nullptr);
+                       static_cast<hipStream_t>(stream), 0, nullptr);
 }
 
 int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -576,7 +646,7 @@ int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, cons
   RmResources res{};
   res.textures = textures; res.numTextures = numTextures;
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
-                       static_cast<hipStream_t>(stream), false, nullptr, res);
+                       static_cast<hipStream_t>(stream), 0, nullptr, res);
 }
 
 int rm_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -586,16 +656,34 @@ int rm_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, con
   int n = rowEnd - rowBegin;
   RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
-                       static_cast<hipStream_t>(stream), false, nullptr, res ? *res : kNoResources);
+                       static_cast<hipStream_t>(stream), 0, nullptr, res ? *res : kNoResources);
 }
 
+int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                         const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *d_rgba,
+                         float *d_bright, int mode, RmCounters *out) {
+  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
+  if (mode != RM_COUNT_REFERENCE && mode != RM_COUNT_EXECUTED) { set_error("bad counting mode"); return RM_ERR_INVALID_ARGUMENT; }
+  int n = rowEnd - rowBegin;
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, mode, out);
+}
 int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                       const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *d_rgba,
                       float *d_bright, RmCounters *out) {
-  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
-  int n = rowEnd - rowBegin;
-  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
-  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, true, out);
+  return rm_render_counted_ex(cam, objs, numObjects, lights, numLights, g, s, W, H, rowBegin, rowEnd, d_rgba, d_bright,
+                              RM_COUNT_REFERENCE, out);
+}
+int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                      const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz) {
+  if (!shaderMHz) { set_error("null shaderMHz"); return RM_ERR_INVALID_ARGUMENT; }
+  if (!(numObjects == 1 && objs && objs[0].type == RM_MANDELBULB)) {
+    set_error("rm_render_clocked covers the single-Mandelbulb scene class");
+    return RM_ERR_UNSUPPORTED;
+  }
+  RowMap map{0, H > 0 ? H : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, H, d_rgba, nullptr, nullptr, 3, nullptr,
+                       kNoResources, shaderMHz);
 }
 
 int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -607,7 +695,7 @@ int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, c
   }
   RowMap map{0, tileRows, shard, numShards};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards),
-                       d_rgba, d_bright, static_cast<hipStream_t>(stream), false, nullptr);
+                       d_rgba, d_bright, static_cast<hipStream_t>(stream), 0, nullptr);
 }
 
 int rm_render_tiles_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -619,7 +707,7 @@ int rm_render_tiles_res(const RmCamera *cam, const RmObject *objs, int numObject
   }
   RowMap map{0, tileRows, shard, numShards};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards),
-                       d_rgba, d_bright, static_cast<hipStream_t>(stream), false, nullptr, res ? *res : kNoResources);
+                       d_rgba, d_bright, static_cast<hipStream_t>(stream), 0, nullptr, res ? *res : kNoResources);
 }
 
 int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
@@ -649,11 +737,13 @@ int rm_frame_to_rgba8(const float *d_rgba, uint8_t *d_out, int W, int H, void *s
 }
 
 int rm_set_timing(int on) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  g_timing = on != 0;
-  for (auto &t : g_timed)
+  g_timing.store(on != 0);
+  DeviceState *ds;
+  if (int st = current_device_state(&ds)) return st;
+  std::lock_guard<std::mutex> lock(ds->mu);
+  for (auto &t : ds->timed)
     for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
-  g_timed.clear();
+  ds->timed.clear();
   return RM_OK;
 }
 int rm_get_timing(double *avgKernelMs, int *launches) {
@@ -661,32 +751,38 @@ int rm_get_timing(double *avgKernelMs, int *launches) {
   return rm_get_stage_timing(avgKernelMs, stages, launches);
 }
 int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  double total = 0.0, stage[4] = {0, 0, 0, 0};
-  for (auto &t : g_timed) {
-    if (t.n < 2) continue;
-    HIP_OK(hipEventSynchronize(t.ev[t.n - 1]));
-    float ms = 0.0f;
-    HIP_OK(hipEventElapsedTime(&ms, t.ev[0], t.ev[t.n - 1]));
-    total += ms;
-    for (int i = 0; i + 1 < t.n && i < 4; i++) {
-      HIP_OK(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
-      stage[i] += ms;
-    }
+  DeviceState *ds;
+  if (int st = current_device_state(&ds)) return st;
+  std::vector<TimedLaunch> timed;
+  {
+    std::lock_guard<std::mutex> lock(ds->mu);
+    timed.swap(ds->timed);  // waiting for the events happens outside the device lock
   }
-  const double n = g_timed.empty() ? 1.0 : (double)g_timed.size();
-  if (launches) *launches = (int)g_timed.size();
+  double total = 0.0, stage[4] = {0, 0, 0, 0};
+  int rc = RM_OK;
+  for (auto &t : timed) {
+    if (t.n < 2 || rc != RM_OK) continue;
+    float ms = 0.0f;
+    if (hipEventSynchronize(t.ev[t.n - 1]) != hipSuccess || hipEventElapsedTime(&ms, t.ev[0], t.ev[t.n - 1]) != hipSuccess) {
+      set_error("timing events could not be read");
+      rc = RM_ERR_DEVICE;
+      continue;
+    }
+    total += ms;
+    for (int i = 0; i + 1 < t.n && i < 4; i++)
+      if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) stage[i] += ms;
+  }
+  const double n = timed.empty() ? 1.0 : (double)timed.size();
+  if (launches) *launches = (int)timed.size();
   if (avgTotalMs) *avgTotalMs = total / n;
   if (avgStageMs) for (int i = 0; i < 4; i++) avgStageMs[i] = stage[i] / n;
-  for (auto &t : g_timed)
+  for (auto &t : timed)
     for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
-  g_timed.clear();
-  return RM_OK;
+  return rc;
 }
 int rm_set_kernel_path(int path) {
-  std::lock_guard<std::mutex> lock(g_mu);
   if (path < 0 || path > 4) { set_error("kernel path must be 0..4"); return RM_ERR_INVALID_ARGUMENT; }
-  g_kernelPath = path;
+  g_kernelPath.store(path);
   return RM_OK;
 }
 
@@ -702,16 +798,18 @@ int rm_probe_math(int fn, const float *d_x, const float *d_y, const float *d_z, 
 
 int rm_probe_sdscene(const RmObject *objs, int numObjects, const RmGlobals *g, const RmSettings *s, const float *d_pts,
                      float *d_out, int n, void *stream) {
-  std::lock_guard<std::mutex> lock(g_mu);
   RmCamera cam{};
   int st = validate_scene(&cam, objs, numObjects, nullptr, 0, g, s, kNoResources);
   if (st != RM_OK) return st;
   if (!d_pts || !d_out || n < 0) { set_error("bad probe arguments"); return RM_ERR_INVALID_ARGUMENT; }
   if (int st2 = require_device_pointers({{"d_pts", d_pts}, {"d_out", d_out}})) return st2;
   if (n == 0) return RM_OK;
+  DeviceState *ds;
+  if ((st = current_device_state(&ds)) != RM_OK) return st;
+  std::lock_guard<std::mutex> lock(ds->mu);
   Slot *slot;
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  st = stage_scene(&cam, objs, numObjects, nullptr, 0, g, s, hs, &slot, kNoResources);
+  st = stage_scene(&cam, objs, numObjects, nullptr, 0, g, s, hs, *ds, &slot, kNoResources);
   if (st != RM_OK) return st;
   hipLaunchKernelGGL(probe_sdscene_kernel, dim3((n + 255) / 256), dim3(256), 0, hs, slot->dev, d_pts, d_out, n);
   HIP_OK(hipGetLastError());

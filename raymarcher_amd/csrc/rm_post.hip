@@ -233,9 +233,6 @@ __global__ void fxaa_kernel(const uchar4 *__restrict__ img, float4 *__restrict__
   out[(size_t)y * W + x] = make_float4(result.x, result.y, result.z, 1.0f);
 }
 
-std::mutex g_postMu;
-struct PostWs { void *mem = nullptr; size_t bytes = 0; };
-PostWs g_postWs[64];
 
 }  // namespace
 }  // namespace rm
@@ -256,21 +253,12 @@ extern "C" int rm_post_process(const float *d_frag, const float *d_bright, float
   if (!d_frag || !d_out || !ps || W <= 0 || H <= 0) { set_error("bad post-process arguments"); return RM_ERR_INVALID_ARGUMENT; }
   if (ps->enableBloom && !d_bright) { set_error("bloom needs the BrightColor plane"); return RM_ERR_INVALID_ARGUMENT; }
   if (int rc = require_device_pointers({{"d_frag", d_frag}, {"d_bright", d_bright}, {"d_out", d_out}})) return rc;
-  std::lock_guard<std::mutex> lock(g_postMu);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t n = (size_t)W * H;
-  int dev = 0;
-  HIP_OK(hipGetDevice(&dev));
-  PostWs &ws = g_postWs[dev & 63];
-  const size_t need = n * (8 + 8 + 4);
-  if (ws.bytes < need) {
-    HIP_OK(hipStreamSynchronize(st));
-    if (ws.mem) HIP_OK(hipFree(ws.mem));
-    ws.mem = nullptr; ws.bytes = 0;
-    HIP_OK(hipMalloc(&ws.mem, need));
-    ws.bytes = need;
-  }
-  half4 *pa = static_cast<half4 *>(ws.mem), *pb = pa + n;
+  // ping-pong + 8-bit staging images of THIS stream: post-processing two frames on two streams never shares them
+  void *wsMem = nullptr;
+  if (int rc = stream_workspace(kWsPost, st, n * (8 + 8 + 4), &wsMem)) return rc;
+  half4 *pa = static_cast<half4 *>(wsMem), *pb = pa + n;
   uchar4 *stage8 = reinterpret_cast<uchar4 *>(pb + n);
   const float4 *frag = reinterpret_cast<const float4 *>(d_frag);
   float4 *out = reinterpret_cast<float4 *>(d_out);

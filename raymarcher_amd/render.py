@@ -220,14 +220,25 @@ class Renderer:
                                   C.c_void_p(br.data_ptr()) if bright else None, self._stream()))
         return (out, br) if bright else out
 
-    def render_counted(self, tables, settings, W, H):
+    def render_counted(self, tables, settings, W, H, mode=abi.RM_COUNT_REFERENCE):
+        """rm_render_counted_ex: the frame plus its work counters — the reference's work (mode RM_COUNT_REFERENCE) or
+        what the production kernel really executes (RM_COUNT_EXECUTED)."""
         t = self.torch
         out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
         cnt = abi.RmCounters()
         t.cuda.synchronize(self.device)
-        check(lib().rm_render_counted(*tables.args(settings), W, H, 0, H, C.c_void_p(out.data_ptr()), None,
-                                      C.byref(cnt)))
+        check(lib().rm_render_counted_ex(*tables.args(settings), W, H, 0, H, C.c_void_p(out.data_ptr()), None, mode,
+                                         C.byref(cnt)))
         return out, cnt
+
+    def render_clocked(self, tables, settings, W, H):
+        """rm_render_clocked: the frame from the stamped diagnostic build and the shader clock (MHz) it ran at."""
+        t = self.torch
+        out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
+        mhz = C.c_double()
+        t.cuda.synchronize(self.device)
+        check(lib().rm_render_clocked(*tables.args(settings), W, H, C.c_void_p(out.data_ptr()), C.byref(mhz)))
+        return out, mhz.value
 
     def render_tiles(self, tables, settings, W, H, tile_rows, shard, num_shards, out=None):
         """rm_render_tiles: this shard's interleaved row tiles, packed → (rm_shard_rows, W, 4)."""

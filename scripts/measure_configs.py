@@ -28,9 +28,13 @@ def main():
                   abi.default_settings(fractalIters=12, features=abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC), 3840, 2160))
     cases.append(("C3'' Mandelbulb p8 20 iters (reference constant) 3840x2160", scenes.mandelbulb(3840, 2160), abi.default_settings(), 3840, 2160))
     t = Scene(path=os.path.join(S, "simple", "volumetric.json")).tables(3840, 2160, far=2000.0)
+    cases.append(("C4 volumetric.json as is (camera below the terrain, looking down) + terrain + cloud + sky 3840x2160", t,
+                  abi.default_settings(features=tg.ENV_ALL), 3840, 2160))
+    t = Scene(path=os.path.join(S, "simple", "volumetric.json")).tables(3840, 2160, far=2000.0)
     t.camera = tg.env_scene(3840, 2160)[0]
-    cases.append(("C4 terrain + cloud + sky 3840x2160 (1 GPU)", t, abi.default_settings(features=tg.ENV_ALL), 3840, 2160))
-    cases.append(("C5 Menger 5 levels, reflection 2 bounces 7680x4320 (1 GPU)", scenes.mengersponge(7680, 4320),
+    cases.append(("C4 same scene, camera turned to the horizon: terrain + cloud + sky 3840x2160 (1 GPU)", t, abi.default_settings(features=tg.ENV_ALL), 3840, 2160))
+    cases.append(("C5 unit_mengersponge.json, 5 levels, reflection 2 bounces 7680x4320 (1 GPU)",
+                  Scene(path=os.path.join(S, "simple", "unit_mengersponge.json")).tables(7680, 4320),
                   abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1), 7680, 4320))
     sea = tg.resource_case("sea_sky", 3840, 2160)
     ts = tg.tables_of(sea[0])

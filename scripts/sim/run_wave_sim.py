@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--stride", type=int, default=16, help="simulate every stride-th workgroup")
     ap.add_argument("--cull", type=float, default=2.1, help="object-space cull radius (0 = none)")
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--cost", type=float, nargs=6, default=[165, 75, 173, 90, 60, 2600],
+    ap.add_argument("--cost", type=float, nargs=6, default=[148, 75, 156, 90, 60, 1700],
                     metavar=("cIt", "cEv", "cItF", "cEvF", "cRay", "cHit"))
     args = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))

@@ -150,11 +150,39 @@ static void sched_flat(const Item *const *q, const int *qn, int n, int T, const 
   }
 }
 
-#define NSCHED 10
+/* nested loops where every lane marches its OWN queue of rays back to back: a wave step evaluates each live lane's next
+ * point; lanes whose ray ended set up their next ray in the same step (paid once per step if any lane does) */
+static void sched_nested_queue(const Item *const *q, const int *qn, int n, const Cost *k, Acc *a) {
+  int cur[64], e[64], live = 0;
+  for (int i = 0; i < n; i++) {
+    cur[i] = 0; e[i] = 0;
+    while (cur[i] < qn[i] && q[i][cur[i]].n == 0) cur[i]++;
+    if (cur[i] < qn[i]) live++;
+    for (int j = 0; j < qn[i]; j++) if (q[i][j].n) a->lane += item_lane_cost(&q[i][j], k) + k->cRay;
+  }
+  if (live) a->wave += k->cRay;
+  while (live) {
+    int mx = 0, sw = 0;
+    for (int i = 0; i < n; i++) {
+      if (cur[i] >= qn[i]) continue;
+      const Item *it = &q[i][cur[i]];
+      if (it->it[e[i]] > mx) mx = it->it[e[i]];
+      if (++e[i] >= it->n) {
+        e[i] = 0; cur[i]++;
+        while (cur[i] < qn[i] && q[i][cur[i]].n == 0) cur[i]++;
+        if (cur[i] >= qn[i]) live--; else sw = 1;
+      }
+    }
+    a->wave += k->cEv + k->cIt * mx + (sw ? k->cRay : 0);
+  }
+}
+
+#define NSCHED 11
 static const char *kSchedNames[NSCHED] = {
   "nested (shipped)", "flat T=1", "park T=8", "park T=16", "park T=32",
   "nested, shadow rays wg-compacted", "flat T=1, shadow rays wg-compacted", "park T=16, shadow rays wg-compacted",
   "park T=16 primary + per-lane ray queue", "park T=16, hit pixels + rays wg-compacted",
+  "nested, per-lane shadow-ray queue",
 };
 
 typedef struct {
@@ -180,7 +208,7 @@ static void sim_workgroup(const PixTrace *px, int nLights, const Cost *k, SimOut
     Acc P = {0, 0}, N = {0, 0}, S = {0, 0};
     double hitCost = 0;
     /* ---- primary ---- */
-    int primFlatT = (s >= 1 && s <= 4) ? Ts[s] : (s == 6 ? 1 : (s >= 7 ? 16 : 0));
+    int primFlatT = (s >= 1 && s <= 4) ? Ts[s] : (s == 6 ? 1 : ((s >= 7 && s <= 9) ? 16 : 0));
     for (int w = 0; w < 4; w++) {
       if (!primFlatT) sched_nested(prim + 64 * w, 64, k, &P);
       else {
@@ -231,6 +259,12 @@ static void sim_workgroup(const PixTrace *px, int nLights, const Cost *k, SimOut
           for (int i = 0; i < m; i++) { q[i] = &rays[b + i]; qn[i] = 1; }
           sched_flat(q, qn, m, s == 6 ? 1 : 16, k, &S);
         }
+      }
+    } else if (s == 10) {
+      for (int w = 0; w < 4; w++) {
+        Item lq[64][SIM_MAXL]; const Item *q[64]; int qn[64];
+        for (int i = 0; i < 64; i++) { qn[i] = nLights; q[i] = lq[i]; for (int l = 0; l < nLights; l++) lq[i][l] = shad[l][64 * w + i]; }
+        sched_nested_queue(q, qn, 64, k, &S);
       }
     } else if (s == 8) {
       for (int w = 0; w < 4; w++) {

@@ -823,10 +823,16 @@ def test_config4_terrain_cloud_4k_row_tiles(renderer):
     from raymarcher_amd import Scene, lib
     W, H, T, N = 3840, 2160, 8, 8
     t = Scene(path=os.path.join(SCENES, "simple", "volumetric.json")).tables(W, H, far=2000.0)
-    # the scenefile's camera (0,500,5) looks straight down into the terrain (a black frame); the reference's user flies
-    # the camera — same position, looking at the horizon, as in env_scene()
-    t.camera = env_scene(W, H)[0]
     s = abi.default_settings(features=ENV_ALL)
+    # (i) the scenefile exactly as it is: its camera (0,500,5) sits below the terrain surface and looks straight down, so
+    # every ray starts inside the height field — a nearly black frame, but the reference's own; rows against the oracle
+    asis = renderer.render(t, s, W, H)
+    for r0 in (7, 1080, 2100):
+        ref = h.oracle_render(_scene_tuple(t), s, W, H, r0, r0 + 8, threads=16)
+        assert_bit_equal(asis[r0:r0 + 8].cpu().numpy(), ref, f"4K volumetric.json as is, rows {r0}..{r0 + 8}")
+    # (ii) the view the layers are made for — the reference's user flies the camera: same position, looking at the
+    # horizon, as in env_scene() (DESIGN.md §6 lists both)
+    t.camera = env_scene(W, H)[0]
     full = renderer.render(t, s, W, H)
     assert 0.1 < float(torch.nan_to_num(full[..., :3]).mean()) < 1.5
     slot = lib().rm_shard_rows(H, T, 0, N)
@@ -844,12 +850,13 @@ def test_config4_terrain_cloud_4k_row_tiles(renderer):
 
 
 def test_config5_menger_8k_reflection(renderer):
-    """configs[4]: Menger sponge, 5 levels, reflection with 2 bounces, 7680×4320 (530 MB of float4): one of the 8 shards
-    against the full frame, sampled rows against the oracle."""
+    """configs[4]: scenefiles/simple/unit_mengersponge.json through the product's loader, 5 levels, reflection with 2
+    bounces, 7680×4320 (530 MB of float4): one of the 8 shards against the full frame, sampled rows against the oracle."""
     import torch
-    from raymarcher_amd import lib, scenes
+    from raymarcher_amd import Scene, lib
     W, H, T, N = 7680, 4320, 8, 8
-    t = scenes.mengersponge(W, H)
+    t = Scene(path=os.path.join(SCENES, "simple", "unit_mengersponge.json")).tables(W, H)  # the reference's own scenefile
+    assert t.num_objects == 1 and t.num_lights == 3 and t.objects[0].type == abi.RM_MENGERSPONGE
     s = abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1)
     full = renderer.render(t, s, W, H)
     k = 5

@@ -176,3 +176,19 @@ def test_every_textured_scenefile_loads_with_its_images():
     for which in (1, 2, 3):
         faces = [load_image(os.path.join(REF_SCENES, lib().rm_skybox_face_path(which, f).decode()), flip_vertical=True) for f in range(6)]
         assert all(a.shape == faces[0].shape and a.shape[0] == a.shape[1] for a in faces), which
+
+
+@pytest.mark.parametrize("name", ["unit_mandelbulb", "unit_mengersponge"])
+def test_bench_scene_constants_equal_the_scenefile(name):
+    """bench.py / the full-size GPU tests take the north-star scenes from raymarcher_amd.scenes (scenefiles restated as
+    constants, no file IO in the product); they must be the tables the loader gives for the reference's own scenefile,
+    byte for byte — camera, object, lights and globals."""
+    from raymarcher_amd import scenes
+    fn = {"unit_mandelbulb": scenes.mandelbulb, "unit_mengersponge": scenes.mengersponge}[name]
+    for W, H in ((3840, 2160), (7680, 4320), (96, 54)):
+        a = fn(W, H)
+        b = Scene(path=os.path.join(GOLD, "scenes", "simple", name + ".json")).tables(W, H)
+        raw = lambda x: bytes(memoryview(x).cast("B"))
+        assert (a.num_objects, a.num_lights) == (b.num_objects, b.num_lights) == (1, 3)
+        assert raw(a.camera) == raw(b.camera) and raw(a.objects) == raw(b.objects)
+        assert raw(a.lights) == raw(b.lights) and raw(a.globals_) == raw(b.globals_)
