@@ -62,13 +62,13 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
     const int nd = sb->numObjects * (int)(sizeof(RmObject) / 4);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sb->objs);
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_objs);
-    for (int i = threadIdx.x; i < nd; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
   }
   // the launches that read samplers build the byte→unorm table (wave-uniform condition; ends with a barrier)
   if (TEX || (ENV && (sb->s.features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)))) initUnormTable();
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int x = blockIdx.x * kBlockW + wave * kTileW + (lane % kTileW);
+  const int x = (blockIdx.x * (blockDim.x >> 6) + wave) * kTileW + (lane % kTileW);
   const int r = blockIdx.y * kBlockH + (lane / kTileW);
   if (x >= W || r >= nRows) return;
   const int y = map.frameRow(r);
@@ -572,7 +572,14 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
     // procedural layers or textures; the generic kernel with either or both.  Features a launch does not need are
     // compiled out so the common kernels keep their register budget.
-#define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
+    // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
+    // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident
+    // (measured, profiles/r02_c_waves_per_block.md: the 4K bulb frame 3.34 / 3.13 / 3.18 ms at 4 / 2 / 1 waves, the 8K
+    // Menger frame 105 / 97 / 89 ms): two for the bulb class, one for everything else.  RM_WAVES_PER_BLOCK overrides.
+    static const int wpb = std::getenv("RM_WAVES_PER_BLOCK") ? std::atoi(std::getenv("RM_WAVES_PER_BLOCK")) : 0;
+    const int nw = (wpb == 1 || wpb == 2 || wpb == 4) ? wpb : ((bulb && !envFeatures && !textured) ? 2 : 1);
+    const dim3 rgrid((W + nw * kTileW - 1) / (nw * kTileW), (nRows + kBlockH - 1) / kBlockH), rblock(64 * nw);
+#define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
       if (envFeatures && textured) RM_LAUNCH(false, 0, true, true);
       else if (envFeatures) RM_LAUNCH(false, 0, true, false);

@@ -13,7 +13,7 @@ namespace rm {
 // A lookup equals the division bit for bit.  Kernels that sample must call initUnormTable() first.
 __shared__ float s_unorm[256];
 RM_DEV void initUnormTable() {
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_unorm[i] = (float)i / 255.0f;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_unorm[i] = RM_DIVC((float)i, 255.0f);  // = i / 255 (exact sequence, rm_math.hip.h)
   __syncthreads();
 }
 RM_DEV float unorm8(unsigned char q) { return s_unorm[q]; }
