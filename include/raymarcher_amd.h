@@ -270,9 +270,11 @@ int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjec
 /* Diagnostic build of the single-Mandelbulb kernel (production code + s_memtime / s_memrealtime stamps per wave, written
  * to a buffer of their own): renders the whole frame once, synchronises and returns the shader clock the chip held under
  * this kernel's own load, in MHz (Σ cycle spans ÷ Σ 100 MHz-tick spans over all waves).  Call it after a few back-to-back
- * renders so that the clock has settled. */
+ * renders so that the clock has settled.  d_waveSpans (device, may be NULL): 2 words per wave — its first and last
+ * s_memrealtime stamp (100 MHz ticks) — for ceil(W/16)·ceil(H/8)·2 waves in workgroup order, for occupancy timelines. */
 int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                      const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz);
+                      const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz,
+                      unsigned long long *d_waveSpans);
 
 /* Average device time in ms of the `rm_render*` launches made on the CURRENT device since rm_set_timing(1), timed with
  * hipEvents on their own stream; rm_get_* reads and resets that device's records (the on/off switch is process-wide). */
@@ -287,6 +289,17 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
  * hit / shadow-ray lists, 4 = as 3 with the march stages cut into step-budgeted passes (survivors re-compacted
  * between launches).  All paths produce identical bits; the switch exists for A/B measurement and tests. */
 int rm_set_kernel_path(int path);
+/* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never
+ * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely
+ * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): feedback — every
+ * frame records each tile's shader-cycle cost, and the next frame of the same size on the same stream starts its tiles
+ * heaviest-first by those costs (the first frame, and the first after a change of size, run in raster order); mode 0:
+ * always raster order; -1: back to the default / the RM_TILE_ORDER environment variable.  Applies to scenes without
+ * procedural layers or samplers and to frames of at least 2048 tiles. */
+int rm_set_tile_order(int mode);
+/* Experiments: force a given launch order (d_order: a device permutation of 0..tileCount-1, or NULL) and / or collect the
+ * tiles' costs (d_cost: tileCount device words, accumulated, or NULL) for subsequent launches on the current device. */
+int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCount);
 
 /*
  * rm_frame_to_rgba8 — clamp→×255→round and vertical flip, the read-back of

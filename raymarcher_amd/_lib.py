@@ -45,11 +45,13 @@ SIGNATURES = {
                                                   _P(abi.RmCounters)]),
     "rm_render_counted_ex": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                      _P(abi.RmCounters)]),
-    "rm_render_clocked": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_void_p, _P(C.c_double)]),
+    "rm_render_clocked": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_void_p, _P(C.c_double), C.c_void_p]),
     "rm_set_timing": (C.c_int, [C.c_int]),
     "rm_get_timing": (C.c_int, [_P(C.c_double), _P(C.c_int)]),
     "rm_get_stage_timing": (C.c_int, [_P(C.c_double), _P(C.c_double), _P(C.c_int)]),
     "rm_set_kernel_path": (C.c_int, [C.c_int]),
+    "rm_set_tile_order": (C.c_int, [C.c_int]),
+    "rm_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rm_frame_to_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rm_post_process": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(abi.RmPostSettings), C.c_void_p]),
     "rm_probe_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -71,6 +71,11 @@ struct SceneBlock {
   float cullR2;
   float cullR2Soft;  // larger ball for soft-shadow rays (0 = none): beyond it 8·d/t >= 1, so the penumbra min() is settled
   int32_t cullOk;
+  // Launch order of the workgroups (see rm_kernels.hip, "tile order"): workgroup b renders tile tileOrder[b] (a permutation
+  // of 0..tileCount-1, heaviest tiles first) or tile b if null; tileCost (or null) accumulates every tile's shader-cycle cost.
+  const int32_t *tileOrder;
+  uint32_t *tileCost;
+  int32_t tileCount;
 };
 
 struct SceneMin { int idx; float d; V4 trap; };

@@ -48,8 +48,11 @@ constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 // stamps: every wave adds its (s_memtime, s_memrealtime) spans to counters[3], counters[4] — shader cycles and 100 MHz
 // ticks — from which rm_render_clocked derives the clock the chip held under this kernel's own load.  The stamps go to a
 // buffer of their own and no output value depends on them.
+// Register budget = waves per SIMD (second launch bound): 4 (≤128 VGPRs) for the plain and single-bulb classes, 3 (≤168) with
+// the procedural layers, 2 with samplers — the occupancies the kernels were tuned at; without the bound a few registers
+// more (131 instead of 128) silently cost a quarter of the resident waves.
 template <bool BULB, int COUNT, bool ENV, bool TEX>
-__global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+__global__ __launch_bounds__(256, (TEX ? 2 : (ENV ? 3 : 4))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
                                                       unsigned long long *__restrict__ counters) {
@@ -68,8 +71,16 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
   if (TEX || (ENV && (sb->s.features & (RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)))) initUnormTable();
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int x = (blockIdx.x * (blockDim.x >> 6) + wave) * kTileW + (lane % kTileW);
-  const int r = blockIdx.y * kBlockH + (lane / kTileW);
+  // tile order: the workgroups of a grid start in blockIdx order; sb->tileOrder (if any) says which tile each one renders
+  int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const int32_t *order = sb->tileOrder;
+  if (order && sb->tileCount == (int)(gridDim.x * gridDim.y)) tile = order[tile];
+  const int tbx = tile % (int)gridDim.x, tby = tile / (int)gridDim.x;
+  // the wave's start stamp waits in LDS (not in two scalar registers across the whole kernel — the register budget is tight)
+  __shared__ unsigned long long s_c0[4];
+  if (sb->tileCost && lane == 0) s_c0[wave] = __builtin_amdgcn_s_memtime();
+  const int x = (tbx * (blockDim.x >> 6) + wave) * kTileW + (lane % kTileW);
+  const int r = tby * kBlockH + (lane / kTileW);
   if (x >= W || r >= nRows) return;
   const int y = map.frameRow(r);
   V4 col, br;
@@ -84,12 +95,89 @@ __global__ __launch_bounds__(256) void render_kernel(const SceneBlock *__restric
     atomicAdd(&counters[1], cnt.iters);
     if (hit) atomicAdd(&counters[2], 1ull);
   }
+  if (sb->tileCost && sb->tileCount == (int)(gridDim.x * gridDim.y)) {  // wave-uniform
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    int t2 = blockIdx.y * gridDim.x + blockIdx.x;  // recomputed rather than kept live
+    if (sb->tileOrder) t2 = sb->tileOrder[t2];
+    if ((int)__lane_id() == __builtin_ctzll(__ballot(1))) atomicAdd(&sb->tileCost[t2], (uint32_t)((c1 - s_c0[wave]) >> 6));
+  }
   if (COUNT == 3) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if ((int)__lane_id() == __builtin_ctzll(__ballot(1))) {  // first live lane of the wave
       atomicAdd(&counters[3], t1 - t0);
       atomicAdd(&counters[4], r1 - r0);
+      // optional per-wave life span (100 MHz ticks) for occupancy timelines: counters[5] holds a device pointer or 0
+      unsigned long long *spans = reinterpret_cast<unsigned long long *>(counters[5]);
+      if (spans) {
+        int t3 = blockIdx.y * gridDim.x + blockIdx.x;
+        if (sb->tileOrder && sb->tileCount == (int)(gridDim.x * gridDim.y)) t3 = sb->tileOrder[t3];
+        const size_t w = (size_t)t3 * (blockDim.x >> 6) + wave;
+        spans[2 * w] = r0;
+        spans[2 * w + 1] = r1;
+      }
     }
+  }
+}
+
+// ---- tile order ------------------------------------------------------------------------------------------
+// The cost of a tile (one workgroup of render_kernel) spans three orders of magnitude: background tiles end after one
+// evaluation, while an interior tile may hold ONE ray that creeps through a crevice for all 256 steps without ever
+// converging — a sequential chain of ≈0.5 M instructions, ≈1 ms on its own.  Workgroups start in blockIdx order; with
+// tiles in raster order such stragglers start at random times, the last of them late, and the kernel ends in a tail of a
+// few lonely waves (profiles/r02_e_wave_timeline.md: the last 15 % of the kernel's life had ≤ 3 waves resident).
+// Starting the heavy tiles first removes the tail: 3.11 → 2.43 ms on the 4K bulb frame with measured costs
+// (profiles/r02_f_tile_order.md).  Nothing about a pixel changes, only when its tile starts.
+// Where the straggler pixels are cannot be told from a sparse pre-pass (tried: 8 sample rays per tile, 0.24 ms, no gain);
+// what does know is the previous frame.  render_kernel adds every wave's shader-cycle span to tileCost[tile]; the next
+// frame of the same size on the same stream starts its tiles in descending order of those costs (a renderer's consecutive
+// frames are nearly the same picture; a frame with no history, or after a change of size, runs in raster order).
+// The order is a two-launch bucket sort by log2(cost): tile_hist_kernel counts, tile_scatter_kernel places.
+constexpr int kOrderBuckets = 16;
+RM_DEV int orderBucket(uint32_t cost) {  // heaviest = bucket 0; costs are shader cycles / 64, i.e. ≈2^5 … 2^17
+  const int lg = 31 - __builtin_clz(cost | 1u);
+  const int b = 17 - lg;
+  return b < 0 ? 0 : (b >= kOrderBuckets ? kOrderBuckets - 1 : b);
+}
+__global__ __launch_bounds__(256) void tile_hist_kernel(const uint32_t *__restrict__ cost, int n, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t s_cnt[kOrderBuckets];
+  if (threadIdx.x < kOrderBuckets) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = i < n ? orderBucket(cost[i]) : -1;
+  for (int k = 0; k < kOrderBuckets; k++) {  // wave-aggregated: one LDS atomic per wave and bucket present
+    const unsigned long long m = __ballot(b == k);
+    if (m && (int)__lane_id() == __builtin_ctzll(m)) atomicAdd(&s_cnt[k], (uint32_t)__builtin_popcountll(m));
+  }
+  __syncthreads();
+  if (threadIdx.x < kOrderBuckets && s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_cnt[threadIdx.x]);
+}
+// hist[0..15] = bucket sizes (from tile_hist_kernel), hist[16..31] = cursors (zero on entry).  Consumes (clears) cost[].
+__global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict__ cost, int n, uint32_t *__restrict__ hist,
+                                                            int32_t *__restrict__ order) {
+  __shared__ uint32_t s_cnt[kOrderBuckets], s_base[kOrderBuckets];
+  if (threadIdx.x < kOrderBuckets) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = i < n ? orderBucket(cost[i]) : -1;
+  uint32_t rank = 0;  // position inside the block's share of bucket b
+  for (int k = 0; k < kOrderBuckets; k++) {
+    const unsigned long long m = __ballot(b == k);
+    if (!m) continue;
+    uint32_t waveBase = 0;
+    if ((int)__lane_id() == __builtin_ctzll(m)) waveBase = atomicAdd(&s_cnt[k], (uint32_t)__builtin_popcountll(m));
+    waveBase = __shfl(waveBase, __builtin_ctzll(m));
+    if (b == k) rank = waveBase + (uint32_t)__builtin_popcountll(m & ((1ull << __lane_id()) - 1ull));
+  }
+  __syncthreads();
+  if (threadIdx.x < kOrderBuckets) {
+    uint32_t start = 0;  // exclusive scan of the bucket sizes, heaviest bucket first
+    for (int k = 0; k < (int)threadIdx.x; k++) start += hist[k];
+    s_base[threadIdx.x] = start + (s_cnt[threadIdx.x] ? atomicAdd(&hist[kOrderBuckets + threadIdx.x], s_cnt[threadIdx.x]) : 0u);
+  }
+  __syncthreads();
+  if (i < n) {
+    order[s_base[b] + rank] = i;
+    cost[i] = 0u;  // the next frame accumulates afresh
   }
 }
 
@@ -162,6 +250,7 @@ struct Slot {
   hipEvent_t done = nullptr;
   bool used = false;
 };
+struct TileOrderState { int tileCount = 0, W = 0, nRows = 0, nw = 0; void *mem = nullptr; };
 struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (single kernel) or 5 (pipeline K1..K4 boundaries)
 struct DeviceState {
   std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
@@ -170,7 +259,13 @@ struct DeviceState {
   unsigned long long *dCounters = nullptr;  // 5 words: evals, iterations, hits, clock stamps (counted renders synchronise)
   std::vector<TimedLaunch> timed;           // rm_set_timing / rm_get_timing, per device
   int numCUs = 0;
+  std::map<hipStream_t, TileOrderState> tileOrder;  // what the feedback costs of each stream belong to
+  const int32_t *dbgTileOrder = nullptr;  // rm_debug_set_tile_order (experiments): overrides the modes below
+  uint32_t *dbgTileCost = nullptr;
+  int dbgTileCount = 0;
 };
+std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_ORDER or the default
+constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
 std::atomic<bool> g_timing{false};
 std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one-lane-per-pixel, 2 pipeline A (state machine), 3 pipeline B (plain loops)
@@ -197,7 +292,7 @@ int acquire_slot(DeviceState &ds, Slot **out) {
   if (ds.slots.empty()) {
     ds.slots.resize(kSlotsInit);
     for (auto &s : ds.slots) { int st = new_slot(&s); if (st != RM_OK) return st; }
-    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 5 * sizeof(unsigned long long)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 6 * sizeof(unsigned long long)));
   }
   Slot *s = &ds.slots[ds.next];
   if (s->used) {
@@ -448,7 +543,8 @@ void scene_cull_ball(SceneBlock *h) {
 
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, hipStream_t stream, DeviceState &ds, Slot **slotOut,
-                const RmResources &res) {  // caller holds ds.mu
+                const RmResources &res, const int32_t *tileOrder = nullptr, uint32_t *tileCost = nullptr,
+                int tileCount = 0) {  // caller holds ds.mu
   Slot *slot;
   int st = acquire_slot(ds, &slot);
   if (st != RM_OK) return st;
@@ -463,6 +559,7 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   for (int f = 0; f < 6; f++) h->skybox[f] = res.skybox[f];
   h->ltc1 = res.ltc1; h->ltc2 = res.ltc2;
   scene_cull_ball(h);
+  h->tileOrder = tileOrder; h->tileCost = tileCost; h->tileCount = tileCount;
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   *slotOut = slot;
   return RM_OK;
@@ -471,7 +568,7 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                   const RmGlobals *g, const RmSettings *s, int W, int H, RowMap map, int nRows, float *d_rgba,
                   float *d_bright, hipStream_t stream, int count, RmCounters *countersOut,
-                  const RmResources &res = kNoResources, double *clockMHz = nullptr) {
+                  const RmResources &res = kNoResources, double *clockMHz = nullptr, unsigned long long *d_waveSpans = nullptr) {
   // count: 0 production launch, 1 / 2 counted (reference work / executed work; synchronises), 3 production code with clock stamps
   int st = validate_scene(cam, objs, numObjects, lights, numLights, g, s, res);
   if (st != RM_OK) return st;
@@ -484,11 +581,6 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (dev < 0 || dev >= 64) { set_error("device index out of range"); return RM_ERR_DEVICE; }
   DeviceState &ds = g_dev[dev];
   std::lock_guard<std::mutex> lock(ds.mu);  // this device only; nothing below blocks on the GPU unless `count` asks for numbers back
-  Slot *slot;
-  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res);
-  if (st != RM_OK) return st;
-  unsigned long long *dc = ds.dCounters;
-  if (count) HIP_OK(hipMemsetAsync(dc, 0, 5 * sizeof(unsigned long long), stream));
   dim3 grid((W + kBlockW - 1) / kBlockW, (nRows + kBlockH - 1) / kBlockH), block(256);
   const bool bulb = (numObjects == 1 && objs[0].type == RM_MANDELBULB);
   auto nonzero3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
@@ -505,6 +597,45 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   const bool pipeline = bulb && !count && path != 1 && !envFeatures && !textured && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
+  // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
+  // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident
+  // (measured, profiles/r02_c_waves_per_block.md: the 4K bulb frame 3.34 / 3.13 / 3.18 ms at 4 / 2 / 1 waves, the 8K
+  // Menger frame 105 / 97 / 89 ms): two for the bulb class, one for everything else.  RM_WAVES_PER_BLOCK overrides.
+  static const int wpb = std::getenv("RM_WAVES_PER_BLOCK") ? std::atoi(std::getenv("RM_WAVES_PER_BLOCK")) : 0;
+  const int nw = (wpb == 1 || wpb == 2 || wpb == 4) ? wpb : ((bulb && !envFeatures && !textured) ? 2 : 1);
+  const dim3 rgrid((W + nw * kTileW - 1) / (nw * kTileW), (nRows + kBlockH - 1) / kBlockH), rblock(64 * nw);
+  // Tile order ("tile order" above): 0 raster order, 1 feedback — tiles start heaviest-first by the costs the previous frame
+  // of this size on this stream recorded.  Plain and single-bulb scenes; small frames are not worth the two extra launches.
+  static const int envOrder = std::getenv("RM_TILE_ORDER") ? std::atoi(std::getenv("RM_TILE_ORDER")) : kDefaultTileOrder;
+  const int orderMode = g_tileOrderMode.load() >= 0 ? g_tileOrderMode.load() : envOrder;
+  const int tileCount = (int)(rgrid.x * rgrid.y);
+  const bool ordered = orderMode > 0 && !pipeline && !envFeatures && !textured && !g->isTwoD && count == 0 &&
+                       tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
+  uint32_t *oCost = nullptr, *oHist = nullptr;
+  int32_t *oOrder = nullptr;
+  bool haveCost = false;
+  if (ordered) {
+    void *mem = nullptr;
+    if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 8 + 256, &mem)) != RM_OK) return st;
+    oHist = static_cast<uint32_t *>(mem);
+    oCost = oHist + 64;
+    oOrder = reinterpret_cast<int32_t *>(oCost + tileCount);
+    TileOrderState &ts = ds.tileOrder[stream];
+    const TileOrderState now{tileCount, W, nRows, nw, mem};
+    haveCost = ts.tileCount == now.tileCount && ts.W == W && ts.nRows == nRows && ts.nw == nw && ts.mem == mem;
+    if (!haveCost) HIP_OK(hipMemsetAsync(oCost, 0, (size_t)tileCount * 4, stream));
+    ts = now;
+  }
+  Slot *slot;
+  st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res,
+                   ordered ? (haveCost ? oOrder : nullptr) : ds.dbgTileOrder, ordered ? oCost : ds.dbgTileCost,
+                   ordered ? tileCount : ds.dbgTileCount);
+  if (st != RM_OK) return st;
+  unsigned long long *dc = ds.dCounters;
+  if (count) {
+    HIP_OK(hipMemsetAsync(dc, 0, 6 * sizeof(unsigned long long), stream));
+    if (d_waveSpans) HIP_OK(hipMemcpyAsync(dc + 5, &d_waveSpans, sizeof(d_waveSpans), hipMemcpyHostToDevice, stream));
+  }
   TimedLaunch tl{};
   const bool timing = g_timing.load();
   auto stamp = [&](int i) -> int {
@@ -572,13 +703,13 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
     // procedural layers or textures; the generic kernel with either or both.  Features a launch does not need are
     // compiled out so the common kernels keep their register budget.
-    // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
-    // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident
-    // (measured, profiles/r02_c_waves_per_block.md: the 4K bulb frame 3.34 / 3.13 / 3.18 ms at 4 / 2 / 1 waves, the 8K
-    // Menger frame 105 / 97 / 89 ms): two for the bulb class, one for everything else.  RM_WAVES_PER_BLOCK overrides.
-    static const int wpb = std::getenv("RM_WAVES_PER_BLOCK") ? std::atoi(std::getenv("RM_WAVES_PER_BLOCK")) : 0;
-    const int nw = (wpb == 1 || wpb == 2 || wpb == 4) ? wpb : ((bulb && !envFeatures && !textured) ? 2 : 1);
-    const dim3 rgrid((W + nw * kTileW - 1) / (nw * kTileW), (nRows + kBlockH - 1) / kBlockH), rblock(64 * nw);
+    if (ordered && haveCost) {  // this frame's launch order from the previous frame's tile costs, ahead of the render
+      const dim3 sgrid((tileCount + 255) / 256);
+      HIP_OK(hipMemsetAsync(oHist, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
+      hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist);
+      hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder);
+      if ((st = stamp(1)) != RM_OK) return st;  // stage 0 = the ordering launches, stage 1 = the render
+    }
 #define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
       if (envFeatures && textured) RM_LAUNCH(false, 0, true, true);
@@ -595,7 +726,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       else RM_LAUNCH(false, 0, false, false);
     }
 #undef RM_LAUNCH
-    if ((st = stamp(1)) != RM_OK) return st;
+    if ((st = stamp((ordered && haveCost) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
   if (timing) ds.timed.push_back(tl);
@@ -682,15 +813,17 @@ int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects,
                               RM_COUNT_REFERENCE, out);
 }
 int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
-                      const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz) {
+                      const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz,
+                      unsigned long long *d_waveSpans) {
   if (!shaderMHz) { set_error("null shaderMHz"); return RM_ERR_INVALID_ARGUMENT; }
+  if (d_waveSpans && !device_accessible(d_waveSpans)) { set_error("d_waveSpans is not device-accessible memory"); return RM_ERR_INVALID_ARGUMENT; }
   if (!(numObjects == 1 && objs && objs[0].type == RM_MANDELBULB)) {
     set_error("rm_render_clocked covers the single-Mandelbulb scene class");
     return RM_ERR_UNSUPPORTED;
   }
   RowMap map{0, H > 0 ? H : 1, 0, 1};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, H, d_rgba, nullptr, nullptr, 3, nullptr,
-                       kNoResources, shaderMHz);
+                       kNoResources, shaderMHz, d_waveSpans);
 }
 
 int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -786,6 +919,18 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
   for (auto &t : timed)
     for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
   return rc;
+}
+int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCount) {
+  DeviceState *ds;
+  if (int st = current_device_state(&ds)) return st;
+  std::lock_guard<std::mutex> lock(ds->mu);
+  ds->dbgTileOrder = d_order; ds->dbgTileCost = d_cost; ds->dbgTileCount = tileCount;
+  return RM_OK;
+}
+int rm_set_tile_order(int mode) {
+  if (mode < -1 || mode > 1) { set_error("tile order mode must be -1, 0 or 1"); return RM_ERR_INVALID_ARGUMENT; }
+  g_tileOrderMode.store(mode);
+  return RM_OK;
 }
 int rm_set_kernel_path(int path) {
   if (path < 0 || path > 4) { set_error("kernel path must be 0..4"); return RM_ERR_INVALID_ARGUMENT; }

@@ -130,6 +130,9 @@ RM_DEV float asin_p(float z) {
 // rounded square root applies; its NaN for |x| > 1 is discarded by the clamp.
 RM_DEV float acos_(float x) {
   float ax = fabs_(x);
+  // keep |x| in a register of its own: folded into the fma operands as a source modifier it forces the VOP3 encoding, which
+  // takes no literal, and the seven coefficients would each occupy a scalar register across the march loops
+  asm("" : "+v"(ax));
   float p = fma(ax, -1.253449009e-03f, 6.638590246e-03f);
   p = fma(ax, p, -1.704506390e-02f);
   p = fma(ax, p, 3.086272627e-02f);

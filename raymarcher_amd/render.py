@@ -231,14 +231,17 @@ class Renderer:
                                          C.byref(cnt)))
         return out, cnt
 
-    def render_clocked(self, tables, settings, W, H):
-        """rm_render_clocked: the frame from the stamped diagnostic build and the shader clock (MHz) it ran at."""
+    def render_clocked(self, tables, settings, W, H, wave_spans=False):
+        """rm_render_clocked: the frame from the stamped diagnostic build and the shader clock (MHz) it ran at; with
+        wave_spans=True also an int64 tensor (waves, 2) of every wave's first / last 100 MHz tick."""
         t = self.torch
         out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
         mhz = C.c_double()
+        spans = t.zeros((((W + 15) // 16) * ((H + 7) // 8) * 2, 2), dtype=t.int64, device=self.device) if wave_spans else None
         t.cuda.synchronize(self.device)
-        check(lib().rm_render_clocked(*tables.args(settings), W, H, C.c_void_p(out.data_ptr()), C.byref(mhz)))
-        return out, mhz.value
+        check(lib().rm_render_clocked(*tables.args(settings), W, H, C.c_void_p(out.data_ptr()), C.byref(mhz),
+                                      C.c_void_p(spans.data_ptr()) if wave_spans else None))
+        return (out, mhz.value, spans) if wave_spans else (out, mhz.value)
 
     def render_tiles(self, tables, settings, W, H, tile_rows, shard, num_shards, out=None):
         """rm_render_tiles: this shard's interleaved row tiles, packed → (rm_shard_rows, W, 4)."""

@@ -56,5 +56,78 @@ def main():
               f"{prim[i] / wave[0]:7.3f}  {norm[i] / wave[0]:13.3f}  {shad[i] / wave[0]:6.3f}")
 
 
+    # tail estimate: list-schedule the waves, in dispatch order, onto the chip's wave slots (every slot runs at the same
+    # rate: 1/occ of a SIMD); compare with the perfectly balanced time
+    import numpy as np
+    import heapq
+    cost = (C.c_float * (1 << 18))()
+    idx = (C.c_int * (1 << 18))()
+    est = (C.c_float * (1 << 18))()
+    m = sim.sim_wave_costs(cost, idx, est, 1 << 18)
+    cst, ix, es = np.array(cost[:m], dtype=np.float64), np.array(idx[:m]), np.array(est[:m], dtype=np.float64)
+    ba, bs = (C.c_double * 65)(), (C.c_double * 257)()
+    sim.sim_histograms(ba, bs)
+    ba, bs = np.array(ba), np.array(bs)
+    tot = ba.sum()
+    print("march cost of the shipped schedule by number of lanes still marching (share of all march cost):")
+    for lo, hi in ((1, 1), (2, 4), (5, 8), (9, 16), (17, 32), (33, 48), (49, 64)):
+        print(f"  {lo:2d}-{hi:2d} lanes: {ba[lo:hi + 1].sum() / tot:.3f}")
+    print("march cost by step index: " + ", ".join(f"steps {a}-{b}: {bs[a:b + 1].sum() / tot:.3f}" for a, b in ((0, 15), (16, 31), (32, 63), (64, 127), (128, 256))))
+    dout = (C.c_double * 30)()
+    sim.sim_defer_results(dout)
+    dd = np.array(dout).reshape(5, 6)
+    print("tail deferral (a march with <= T live lanes hands its rest to a dense second kernel), relative to the shipped total:")
+    for t, row in zip((0, 4, 8, 12, 16), dd):
+        print(f"  T={t:2d}: main kernel {row[0] / wave[0]:.3f} (heaviest wave {row[1]:.0f}), tail kernels {row[2] / wave[0]:.3f}, sum {(row[0] + row[2]) / wave[0]:.3f}; "
+              f"deferred primary rays/px {row[3] / pixels:.4f}, shadow rays/px {row[4] / pixels:.4f}")
+    if args.stride == 1:
+        s0, s1 = (C.c_float * (1 << 18))(), (C.c_float * (1 << 18))()
+        sim.sim_wave_costs_spread(s0, s1, 1 << 18)
+        for name, arr in (("shipped", cst), ("shadow rays of all lights together when <= 64", np.array(s0[:m], dtype=np.float64)),
+                          ("shadow rays of all lights together always", np.array(s1[:m], dtype=np.float64))):
+            order = np.argsort(ix, kind="stable")
+            heap = [0.0] * 4096
+            end = 0.0
+            for c in arr[order]:
+                t = heapq.heappop(heap) + c
+                end = max(end, t)
+                heapq.heappush(heap, t)
+            print(f"  {name:48s}: total {arr.sum() / cst.sum():.3f}, heaviest wave {arr.max():.0f}, raster-order makespan {end / (cst.sum() / 4096):.3f} (x shipped balanced)")
+        pr, hh, mp, ms_ = (C.c_float * (1 << 18))(), (C.c_short * (1 << 18))(), (C.c_short * (1 << 18))(), (C.c_short * (1 << 18))()
+        sim.sim_wave_detail(pr, hh, mp, ms_, 1 << 18)
+        pr, hh, mp, ms_ = (np.array(a[:m]) for a in (pr, hh, mp, ms_))
+        gx = (args.W + 31) // 32
+        top = np.argsort(-cst)[:25]
+        print("heaviest waves: cost, primary share, hit lanes, max primary steps, max shadow steps, tile (x, y) of 480 x 270")
+        for i in top:
+            wv = ix[i]; bx = (wv // 4) % gx; by = (wv // 4) // gx
+            print(f"   {cst[i]:8.0f} {pr[i] / cst[i]:5.2f} {hh[i]:3d} {mp[i]:4d} {ms_[i]:4d}   ({bx * 4 + wv % 4}, {by})")
+        for lo, hi in ((0, 1), (1, 16), (16, 48), (48, 65)):
+            sel = (hh >= lo) & (hh < hi)
+            print(f"   waves with {lo}..{hi - 1} hit lanes: {sel.mean():.3f} of waves, {cst[sel].sum() / cst.sum():.3f} of cost, mean {cst[sel].mean():.0f}, max {cst[sel].max():.0f}")
+        print("corr(est, cost) =", np.corrcoef(es, cst)[0, 1], " share of waves with cost <= 2x min:", (cst <= 2 * cst.min()).mean(),
+              " cost share of the top 1% waves:", np.sort(cst)[-m // 100:].sum() / cst.sum())
+        print(f"waves {m}: mean cost {cst.mean():.0f}, max {cst.max():.0f} wave-instructions; total/4096 slots = {cst.sum() / 4096:.0f}")
+        for name, order in (("dispatch order (row-major workgroups)", np.argsort(ix, kind="stable")),
+                            ("heaviest first (oracle knowledge)", np.argsort(-cst, kind="stable")),
+                            ("by the cost of the tile's 4 centre pixels", np.argsort(-es, kind="stable")),
+                            ("cheap (<= 2x min cost) waves last, rest row-major", np.lexsort((ix, cst <= 2 * cst.min()))),
+                            ("centre rows first", None)):
+            if order is None:
+                gx = (args.W + 31) // 32
+                row = (ix // 4) // gx
+                gy = (args.H + 7) // 8
+                order = np.lexsort((ix, np.abs(row - gy / 2)))
+            for slots in (4096, 3072):
+                heap = [0.0] * slots
+                heapq.heapify(heap)
+                end = 0.0
+                for c in cst[order]:
+                    t = heapq.heappop(heap) + c
+                    end = max(end, t)
+                    heapq.heappush(heap, t)
+                print(f"  {name:40s} {slots} slots: makespan / balanced = {end / (cst.sum() / slots):.3f}")
+
+
 if __name__ == "__main__":
     main()

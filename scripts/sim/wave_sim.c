@@ -86,6 +86,7 @@ typedef struct {
   double cItF, cEvF;   /* the same inside a flattened state-machine loop (state handling on top) */
   double cRay;         /* per-ray setup (light geometry, cull end) */
   double cHit;         /* bump + material + Phong terms per wave that holds a hit pixel (same in every schedule) */
+  int hist;            /* fill the histograms */
 } Cost;
 
 typedef struct { const uint8_t *it; int n; } Item; /* one march: n evaluations with it[k] iterations each */
@@ -97,14 +98,23 @@ static double item_lane_cost(const Item *x, const Cost *k) {
   for (int e = 0; e < x->n; e++) s += k->cEv + k->cIt * x->it[e];
   return s;
 }
+/* histogram of the shipped schedule's march cost by the number of lanes still marching (filled by sched_nested) */
+static double g_costByActive[65];
+static double g_costByStep[257];
 /* nested loops over <= 64 items in one wave */
 static void sched_nested(const Item *it, int n, const Cost *k, Acc *a) {
   int steps = 0;
   for (int i = 0; i < n; i++) { if (it[i].n > steps) steps = it[i].n; a->lane += item_lane_cost(&it[i], k); }
   for (int s = 0; s < steps; s++) {
-    int mx = 0;
-    for (int i = 0; i < n; i++) if (it[i].n > s && it[i].it[s] > mx) mx = it[i].it[s];
+    int mx = 0, act = 0;
+    for (int i = 0; i < n; i++) if (it[i].n > s) { act++; if (it[i].it[s] > mx) mx = it[i].it[s]; }
     a->wave += k->cEv + k->cIt * mx;
+    if (k->hist) {
+#pragma omp atomic
+      g_costByActive[act] += k->cEv + k->cIt * mx;
+#pragma omp atomic
+      g_costByStep[s < 256 ? s : 256] += k->cEv + k->cIt * mx;
+    }
   }
 }
 /* flattened loop with parking threshold T (T = 1: the epilogue runs in the trip in which a lane finishes).
@@ -185,6 +195,11 @@ static const char *kSchedNames[NSCHED] = {
   "nested, per-lane shadow-ray queue",
 };
 
+#define SIM_MAXWAVES (1 << 18)
+static float g_waveEst[SIM_MAXWAVES];  /* lane-level cost of the wave's centre pixel (a cheap predictor) */
+static float g_waveCost[SIM_MAXWAVES]; /* shipped-schedule cost of every simulated wave, in dispatch order */
+static int g_waveIdx[SIM_MAXWAVES];
+static int g_nWaves;
 typedef struct {
   double wave[NSCHED], lane[NSCHED];
   double primWave[NSCHED], shadWave[NSCHED], normWave[NSCHED];
@@ -281,6 +296,155 @@ static void sim_workgroup(const PixTrace *px, int nLights, const Cost *k, SimOut
   }
 }
 
+/* shipped-schedule cost of one wave (64 pixels) */
+static double wave_cost_shipped(const PixTrace *px, int nLights, const Cost *k) {
+  Item it[64];
+  Acc a = {0, 0};
+  int anyHit = 0;
+  for (int i = 0; i < 64; i++) { it[i].it = px[i].primary; it[i].n = px[i].nPrimary; anyHit |= px[i].hit; }
+  sched_nested(it, 64, k, &a);
+  if (anyHit) {
+    for (int i = 0; i < 64; i++) { it[i].it = px[i].normal; it[i].n = px[i].hit ? 4 : 0; }
+    sched_nested(it, 64, k, &a);
+    a.wave += k->cHit;
+    for (int l = 0; l < nLights; l++) {
+      int any = 0;
+      for (int i = 0; i < 64; i++) { it[i].it = px[i].shadow[l]; it[i].n = px[i].nShadow[l]; any |= it[i].n; }
+      if (any) { a.wave += k->cRay; sched_nested(it, 64, k, &a); }
+    }
+  }
+  return a.wave;
+}
+static double pixel_cost(const PixTrace *p, int nLights, const Cost *k) {
+  double c = 0;
+  Item it;
+  it.it = p->primary; it.n = p->nPrimary; c += item_lane_cost(&it, k);
+  if (p->hit) { it.it = p->normal; it.n = 4; c += item_lane_cost(&it, k) + k->cHit; }
+  for (int l = 0; l < nLights; l++) { it.it = p->shadow[l]; it.n = p->nShadow[l]; c += item_lane_cost(&it, k); }
+  return c;
+}
+/* cost of one wave when the shadow rays of all lights are spread over the lanes and marched together (<= 64 rays: one pass;
+ * more: passes of 64 rays in pixel-major order) */
+static double wave_cost_spread(const PixTrace *px, int nLights, const Cost *k, int onlyIfFit) {
+  Item it[64];
+  Acc a = {0, 0};
+  int anyHit = 0;
+  for (int i = 0; i < 64; i++) { it[i].it = px[i].primary; it[i].n = px[i].nPrimary; anyHit |= px[i].hit; }
+  sched_nested(it, 64, k, &a);
+  if (!anyHit) return a.wave;
+  for (int i = 0; i < 64; i++) { it[i].it = px[i].normal; it[i].n = px[i].hit ? 4 : 0; }
+  sched_nested(it, 64, k, &a);
+  a.wave += k->cHit;
+  Item rays[64 * SIM_MAXL];
+  int nr = 0;
+  for (int i = 0; i < 64; i++) for (int l = 0; l < nLights; l++) if (px[i].nShadow[l]) { rays[nr].it = px[i].shadow[l]; rays[nr].n = px[i].nShadow[l]; nr++; }
+  if (nr <= 64 || !onlyIfFit) {
+    for (int b = 0; b < nr; b += 64) { a.wave += k->cRay + 40; sched_nested(rays + b, nr - b < 64 ? nr - b : 64, k, &a); }
+  } else {
+    for (int l = 0; l < nLights; l++) {
+      int any = 0;
+      for (int i = 0; i < 64; i++) { it[i].it = px[i].shadow[l]; it[i].n = px[i].nShadow[l]; any |= it[i].n; }
+      if (any) { a.wave += k->cRay; sched_nested(it, 64, k, &a); }
+    }
+  }
+  return a.wave;
+}
+static float g_waveCostSpread[2][SIM_MAXWAVES];
+static float g_wavePrimCost[SIM_MAXWAVES];
+static short g_waveHits[SIM_MAXWAVES], g_waveMaxPrimSteps[SIM_MAXWAVES], g_waveMaxShadSteps[SIM_MAXWAVES];
+int sim_wave_detail(float *prim, short *hits, short *mp, short *ms, int max) {
+  int n = g_nWaves < max ? g_nWaves : max;
+  for (int i = 0; i < n; i++) { prim[i] = g_wavePrimCost[i]; hits[i] = g_waveHits[i]; mp[i] = g_waveMaxPrimSteps[i]; ms[i] = g_waveMaxShadSteps[i]; }
+  return n;
+}
+int sim_wave_costs_spread(float *c0, float *c1, int max) {
+  int n = g_nWaves < max ? g_nWaves : max;
+  for (int i = 0; i < n; i++) { c0[i] = g_waveCostSpread[0][i]; c1[i] = g_waveCostSpread[1][i]; }
+  return n;
+}
+int sim_wave_costs(float *cost, int *idx, float *est, int max) {
+  int n = g_nWaves < max ? g_nWaves : max;
+  for (int i = 0; i < n; i++) { cost[i] = g_waveCost[i]; idx[i] = g_waveIdx[i]; est[i] = g_waveEst[i]; }
+  return n;
+}
+
+/* ---- tail deferral: a march whose live lanes drop to <= T hands its remaining evaluations to a pool; pools are
+ * marched later in dense waves of 64 rays (a second kernel).  Pools are per simulator thread (arbitrary packing order). */
+typedef struct { uint8_t it[SIM_MAXS + 8]; int n; } PoolItem;
+typedef struct { PoolItem items[64]; int n; double wave, lane; long rays; } Pool;
+static void pool_flush(Pool *p, const Cost *k) {
+  if (!p->n) return;
+  Item v[64];
+  for (int i = 0; i < p->n; i++) { v[i].it = p->items[i].it; v[i].n = p->items[i].n; }
+  Acc a = {0, 0};
+  sched_nested(v, p->n, k, &a);
+  p->wave += a.wave + k->cRay;
+  p->lane += a.lane;
+  p->n = 0;
+}
+static void pool_push(Pool *p, const uint8_t *it, int n, const Cost *k) {
+  if (n <= 0) return;
+  PoolItem *q = &p->items[p->n];
+  memcpy(q->it, it, (size_t)n);
+  q->n = n;
+  p->rays++;
+  if (++p->n == 64) pool_flush(p, k);
+}
+/* nested march of one wave with deferral; defer[i] is set for lanes whose remainder went to the pool */
+static double nested_defer(const Item *it, int n, int T, Pool *pool, const Cost *k, int *defer) {
+  double c = 0;
+  int steps = 0;
+  for (int i = 0; i < n; i++) if (it[i].n > steps) steps = it[i].n;
+  for (int s = 0; s < steps; s++) {
+    int mx = 0, act = 0;
+    for (int i = 0; i < n; i++) if (it[i].n > s) { act++; if (it[i].it[s] > mx) mx = it[i].it[s]; }
+    if (act <= T) {
+      for (int i = 0; i < n; i++) if (it[i].n > s) { pool_push(pool, it[i].it + s, it[i].n - s, k); if (defer) defer[i] = 1; }
+      c += 20; /* writing the continuation records */
+      break;
+    }
+    c += k->cEv + k->cIt * mx;
+  }
+  return c;
+}
+typedef struct { double k1, k1max; Pool prim, norm, shad; } DeferAcc;
+static void wave_cost_defer(const PixTrace *px, int nLights, int T, const Cost *k, DeferAcc *d) {
+  Item it[64];
+  int defer[64];
+  memset(defer, 0, sizeof defer);
+  int anyHit = 0;
+  for (int i = 0; i < 64; i++) { it[i].it = px[i].primary; it[i].n = px[i].nPrimary; }
+  double c = nested_defer(it, 64, T, &d->prim, k, defer);
+  for (int i = 0; i < 64; i++) {
+    if (defer[i] && px[i].hit) { /* the rest of a deferred pixel runs in the tail kernels */
+      pool_push(&d->norm, px[i].normal, 4, k);
+      for (int l = 0; l < nLights; l++) pool_push(&d->shad, px[i].shadow[l], px[i].nShadow[l], k);
+    }
+    if (!defer[i]) anyHit |= px[i].hit;
+  }
+  if (anyHit) {
+    for (int i = 0; i < 64; i++) { it[i].it = px[i].normal; it[i].n = (px[i].hit && !defer[i]) ? 4 : 0; }
+    Acc a = {0, 0};
+    sched_nested(it, 64, k, &a);
+    c += a.wave + k->cHit;
+    for (int l = 0; l < nLights; l++) {
+      int any = 0;
+      for (int i = 0; i < 64; i++) { it[i].it = px[i].shadow[l]; it[i].n = defer[i] ? 0 : px[i].nShadow[l]; any |= it[i].n; }
+      if (any) c += k->cRay + nested_defer(it, 64, T, &d->shad, k, NULL);
+    }
+  }
+  d->k1 += c;
+  if (c > d->k1max) d->k1max = c;
+}
+#define NDEFER 5
+static const int kDeferT[NDEFER] = {0, 4, 8, 12, 16};
+static double g_deferOut[NDEFER][6]; /* k1 total, k1 max wave, tail-kernel wave cost, rays deferred (prim, shad), pixels */
+void sim_defer_results(double *out) { memcpy(out, g_deferOut, sizeof g_deferOut); }
+
+void sim_histograms(double *byActive, double *byStep) {
+  for (int i = 0; i < 65; i++) byActive[i] = g_costByActive[i];
+  for (int i = 0; i < 257; i++) byStep[i] = g_costByStep[i];
+}
 int sim_num_schedules(void) { return NSCHED; }
 const char *sim_schedule_name(int s) { return (s >= 0 && s < NSCHED) ? kSchedNames[s] : ""; }
 
@@ -292,15 +456,22 @@ int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmL
   if (numObjects != 1 || objs[0].type != RM_MANDELBULB || numLights > SIM_MAXL) return RM_ERR_UNSUPPORTED;
   RmResources none;
   memset(&none, 0, sizeof none);
-  const Cost k = {cost[0], cost[1], cost[2], cost[3], cost[4], cost[5]};
+  const Cost k = {cost[0], cost[1], cost[2], cost[3], cost[4], cost[5], 0};
+  Cost kh = k;
+  kh.hist = 1;
+  memset(g_costByActive, 0, sizeof g_costByActive);
+  memset(g_costByStep, 0, sizeof g_costByStep);
+  memset(g_deferOut, 0, sizeof g_deferOut);
   const int gx = (W + 31) / 32, gy = (H + 7) / 8;
   SimOut tot;
   memset(&tot, 0, sizeof tot);
+  g_nWaves = 0;
 #pragma omp parallel num_threads(threads)
   {
     SimOut loc;
     memset(&loc, 0, sizeof loc);
     PixTrace *px = (PixTrace *)malloc(256 * sizeof(PixTrace));
+    DeferAcc *da = (DeferAcc *)calloc(NDEFER, sizeof(DeferAcc));
 #pragma omp for schedule(dynamic, 1)
     for (int b = 0; b < gx * gy; b++) {
       const int bx = b % gx, by = b / gx;
@@ -319,10 +490,45 @@ int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmL
           t_pix = NULL;
         }
       sim_workgroup(px, numLights, &k, &loc);
+      for (int w = 0; w < 4; w++) {
+        const double c = wave_cost_shipped(px + 64 * w, numLights, &kh);
+        for (int t = 0; t < NDEFER; t++) wave_cost_defer(px + 64 * w, numLights, kDeferT[t], &k, &da[t]);
+        int slot;
+#pragma omp atomic capture
+        slot = g_nWaves++;
+        if (slot < SIM_MAXWAVES) {
+          g_waveCost[slot] = (float)c; g_waveIdx[slot] = b * 4 + w;
+          {
+            Item it[64]; Acc a = {0, 0}; int nh = 0, mp = 0, ms = 0;
+            for (int i = 0; i < 64; i++) {
+              const PixTrace *q = &px[64 * w + i];
+              it[i].it = q->primary; it[i].n = q->nPrimary; nh += q->hit;
+              if (q->nPrimary > mp) mp = q->nPrimary;
+              for (int l = 0; l < numLights; l++) if (q->nShadow[l] > ms) ms = q->nShadow[l];
+            }
+            sched_nested(it, 64, &k, &a);
+            g_wavePrimCost[slot] = (float)a.wave; g_waveHits[slot] = (short)nh; g_waveMaxPrimSteps[slot] = (short)mp; g_waveMaxShadSteps[slot] = (short)ms;
+          }
+          g_waveCostSpread[0][slot] = (float)wave_cost_spread(px + 64 * w, numLights, &k, 1);
+          g_waveCostSpread[1][slot] = (float)wave_cost_spread(px + 64 * w, numLights, &k, 0);
+          /* predictor: the 4 pixels around the tile centre (lanes (3,3),(4,3),(3,4),(4,4)) */
+          g_waveEst[slot] = (float)(pixel_cost(&px[64 * w + 27], numLights, &k) + pixel_cost(&px[64 * w + 28], numLights, &k) +
+                                    pixel_cost(&px[64 * w + 35], numLights, &k) + pixel_cost(&px[64 * w + 36], numLights, &k));
+        }
+      }
     }
     free(px);
+    /* (da is read in the critical section below and leaked at exit of the region: a few KB per thread) */
 #pragma omp critical
     {
+      for (int t = 0; t < NDEFER; t++) {
+        pool_flush(&da[t].prim, &k); pool_flush(&da[t].norm, &k); pool_flush(&da[t].shad, &k);
+        g_deferOut[t][0] += da[t].k1;
+        if (da[t].k1max > g_deferOut[t][1]) g_deferOut[t][1] = da[t].k1max;
+        g_deferOut[t][2] += da[t].prim.wave + da[t].norm.wave + da[t].shad.wave;
+        g_deferOut[t][3] += (double)da[t].prim.rays;
+        g_deferOut[t][4] += (double)da[t].shad.rays;
+      }
       for (int i = 0; i < NSCHED; i++) {
         tot.wave[i] += loc.wave[i]; tot.lane[i] += loc.lane[i]; tot.primWave[i] += loc.primWave[i];
         tot.normWave[i] += loc.normWave[i]; tot.shadWave[i] += loc.shadWave[i];
