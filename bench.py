@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--bulb-eval", choices=["reference", "algebraic"], default="reference",
                     help="reference: acos/atan/sin/cos/pow as the shader writes the step (the headline); algebraic: "
                          "RM_FEAT_BULB_POWER8_ALGEBRAIC, the same step by complex squarings (also reported as a variant)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra timing of the algebraic variant (profiling runs)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timings (algebraic step, raster tile order): profiling runs")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (RCCL process group, pipelined gather, de-interleave) even with one rank: "
                          "a rehearsal of the multi-GPU path on a one-GPU box")
@@ -178,6 +178,28 @@ def main():
     dt = float(tmax.item())
     kernel_ms = float(kmax.item())
 
+    # the same frame without the tile-order feedback (raster order: what a first frame, or a frame after a change of size,
+    # costs); the headline's timed frames all ran with the previous frame's tile costs
+    raster = None
+    if not distributed and not args.no_variants:
+        L.rm_set_tile_order(0)
+        r.render(tables, settings, W, H, out=mine)
+        fence()
+        L.rm_set_timing(1)
+        tr = time.perf_counter()
+        nr = max(3, min(args.steps, 10))
+        for _ in range(nr):
+            r.render(tables, settings, W, H, out=mine)
+        fence()
+        dr = time.perf_counter() - tr
+        rk, rn = C.c_double(), C.c_int()
+        L.rm_get_timing(C.byref(rk), C.byref(rn))
+        L.rm_set_timing(0)
+        L.rm_set_tile_order(-1)
+        raster = {"value": round(W * H * nr / dr / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dr / nr * 1e3, 4),
+                  "kernel_ms": round(rk.value, 4), "steps": nr,
+                  "what": "rm_set_tile_order(0): tiles start in raster order — a frame with no history"}
+
     # the opt-in evaluation scheme of the same step, timed beside the headline (single GPU only; never `value`)
     variant = None
     if not distributed and args.bulb_eval == "reference" and not args.no_variants:
@@ -227,7 +249,11 @@ def main():
         flops_exec, slots_exec = work(cnt_exec)
         # the dominant kernel of one launch processes 1/world of the frame (interleaved tiles ≈ equal work)
         flops_launch = flops_frame / world
-        secs = kernel_ms * 1e-3
+        # with tile-order feedback a launch is two sort kernels (stage 0, ~0.02 ms) + the render kernel (stage 1): the roofline is
+        # the render kernel's, `kernel_ms` stays the whole launch
+        ordered = world == 1 and path in (0, 1) and stages[1] > 0.0
+        render_ms = stages[1] if ordered else kernel_ms
+        secs = render_ms * 1e-3
         achieved = flops_launch / secs / 1e12 if kernel_ms > 0 else 0.0
         executed = flops_exec / world / secs / 1e12 if kernel_ms > 0 else 0.0
         bytes_launch = W * H * 16 / world
@@ -241,6 +267,8 @@ def main():
                                    + ("; step evaluated with RM_FEAT_BULB_POWER8_ALGEBRAIC" if args.bulb_eval == "algebraic" else ""),
                        "rows": "whole frame" if world == 1 else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; RCCL gather of "
                                "frame i to rank 0 overlapped with the render of frame i+1; every frame de-interleaved on rank 0",
+                       "tile_order": "feedback: each frame records its tiles' shader-cycle costs, the next frame starts heavy tiles "
+                                     "first (same pixels, same work; variants.raster_tile_order = no history)",
                        "parity": "bit-exact vs CPU oracle (rm_math contract)"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
@@ -260,16 +288,20 @@ def main():
                          # kernel (WRITE_SIZE + 2·FETCH_SIZE, separate passes) is in profiles/ (133.26 MB per 4K launch)
                          "traffic": None,
                          "traffic_source": "not collected by bench.py; rocprofv3 PMC: profiles/r01_k_hbm_pmc.md",
-                         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
-                         "stage_ms": {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
-                                      "shadow": round(stages[2], 4), "shade": round(stages[3], 4)},
+                         "kernel": kernel_name, "kernel_ms": round(render_ms, 4), "launch_ms": round(kernel_ms, 4),
+                         "stage_ms": ({"tile_order_sort": round(stages[0], 4), "render_kernel": round(stages[1], 4)} if ordered else
+                                      {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
+                                       "shadow": round(stages[2], 4), "shade": round(stages[3], 4)}),
                          "algorithmic": {"flop_per_launch": flops_launch, "sceneEvals": cnt.sceneEvals,
                                          "bulbIters": cnt.bulbIters, "hitPixels": cnt.hitPixels},
                          "hbm": {"achieved": round(bytes_launch / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes_per_pixel": 16}},
         }
+        line["variants"] = {}
         if variant is not None:
-            line["variants"] = {"bulb_power8_algebraic": variant}
+            line["variants"]["bulb_power8_algebraic"] = variant
+        if raster is not None:
+            line["variants"]["raster_tile_order"] = raster
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"], line["parity_check"] = cpu_baseline(settings, timed_frame)
         print(json.dumps(line), flush=True)
