@@ -43,7 +43,8 @@ int main(int argc, char **argv) {
   glm::mat4 view = cam.getViewMatrix(), proj = cam.getProjMatrix();
   glm::mat4 inv = glm::inverse(proj * view);
   std::printf("\n@@JSON {\"ok\": true, ");
-  std::printf("\"ka\": %.9g, \"kd\": %.9g, \"ks\": %.9g, ", rd.globalData.ka, rd.globalData.kd, rd.globalData.ks);
+  std::printf("\"ka\": %.9g, \"kd\": %.9g, \"ks\": %.9g, \"kt\": %.9g, ", rd.globalData.ka, rd.globalData.kd, rd.globalData.ks,
+              rd.globalData.kt);
   mat("view", view); mat("proj", proj); mat("invProjView", inv);
   vec("camPos", rd.cameraData.pos, 4); vec("camLook", rd.cameraData.look, 4); vec("camUp", rd.cameraData.up, 4);
   std::printf("\"heightAngle\": %.9g, ", rd.cameraData.heightAngle);

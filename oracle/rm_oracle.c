@@ -388,6 +388,26 @@ static inline float permute1(float x) { return rm_mod(rm_fma(x, 34.0f, 1.0f) * x
 static inline float taylorInvSqrt1(float r) { return rm_fma(-0.85373472095314f, r, 1.79284291400159f); } /* frag:1606 */
 static inline float fade1(float t) { return ((t * t) * t) * rm_fma(t, rm_fma(t, 6.0f, -15.0f), 10.0f); } /* frag:1587 */
 
+/* Lattice gradient of one corner (frag:1626-1632 / 1634-1640), always in binary32 (rmo_f32 is `float` here; the binary64
+ * arbiter build, rm_oracle_f64.c, keeps it binary32 too).  In real arithmetic gz = 0.5 − |gx| − |gy| is EXACTLY 0 for 7
+ * of the 49 hash classes, so step(gz, 0) — which flips the gradient — is decided by the rounding of ixyz / 7 and of the
+ * two fract()s: the shader's result is defined by its binary32 evaluation, not by the real-number expression.  The input
+ * is an exact small integer (a lattice hash), so the decision depends on the lattice cell only, not on the sample point. */
+#ifndef RMO_F32_DEFINED
+typedef float rmo_f32;
+#endif
+static void pgrad1(rmo_f32 ixyz, rmo_f32 *ogx, rmo_f32 *ogy, rmo_f32 *ogz) {
+  rmo_f32 gx = ixyz / 7.0f;
+  rmo_f32 t = floorf(gx) / 7.0f;
+  rmo_f32 gy = (t - floorf(t)) - 0.5f;
+  gx = gx - floorf(gx);
+  rmo_f32 gz = (0.5f - fabsf(gx)) - fabsf(gy);
+  rmo_f32 sz = (0.0f < gz) ? 0.0f : 1.0f;                      /* step(gz, 0) */
+  gx = fmaf(-sz, ((gx < 0.0f) ? 0.0f : 1.0f) - 0.5f, gx);      /* step(0, gx) */
+  gy = fmaf(-sz, ((gy < 0.0f) ? 0.0f : 1.0f) - 0.5f, gy);
+  *ogx = gx; *ogy = gy; *ogz = gz;
+}
+
 /* frag:1610-1676; lanes k = 0..3 are the vec4 components */
 static float pnoise(v3 p) {
   v3 Pi0 = V3(rm_floor(p.x), rm_floor(p.y), rm_floor(p.z));
@@ -403,23 +423,10 @@ static float pnoise(v3 p) {
     float ixy = permute1(permute1(ix[k]) + iy[k]);
     float ixy0 = permute1(ixy + Pi0.z);
     float ixy1 = permute1(ixy + Pi1.z);
-    /* frag:1626-1632 */
-    float gx = ixy0 / 7.0f;
-    float gy = rm_fract(rm_floor(gx) / 7.0f) - 0.5f;
-    gx = rm_fract(gx);
-    float gz = (0.5f - rm_abs(gx)) - rm_abs(gy);
-    float sz = rm_step(gz, 0.0f);
-    gx = rm_fma(-sz, rm_step(0.0f, gx) - 0.5f, gx);
-    gy = rm_fma(-sz, rm_step(0.0f, gy) - 0.5f, gy);
+    rmo_f32 gx, gy, gz;
+    pgrad1((rmo_f32)ixy0, &gx, &gy, &gz); /* frag:1626-1632 */
     gx0[k] = gx; gy0[k] = gy; gz0[k] = gz;
-    /* frag:1634-1640 */
-    gx = ixy1 / 7.0f;
-    gy = rm_fract(rm_floor(gx) / 7.0f) - 0.5f;
-    gx = rm_fract(gx);
-    gz = (0.5f - rm_abs(gx)) - rm_abs(gy);
-    sz = rm_step(gz, 0.0f);
-    gx = rm_fma(-sz, rm_step(0.0f, gx) - 0.5f, gx);
-    gy = rm_fma(-sz, rm_step(0.0f, gy) - 0.5f, gy);
+    pgrad1((rmo_f32)ixy1, &gx, &gy, &gz); /* frag:1634-1640 */
     gx1[k] = gx; gy1[k] = gy; gz1[k] = gz;
   }
   /* lane order: x=000/001, y=100/101, z=010/011, w=110/111 (frag:1642-1649) */

@@ -171,8 +171,97 @@ def resource_cases(only=None):
         print("probe", kind, out.shape)
 
 
+# ---- scenefile → pixels: the BASELINE.json scenefiles through the REFERENCE'S OWN loader (oracle/_ref/dump_tables, the
+# unmodified sceneparser / scenefilereader / camera sources) and then through the reference shader on SwiftShader.
+REF_SCENES = "/root/reference/scenefiles"
+SCENEFILE_CASES = {
+    # name: (scenefile, W, H, settings overrides, harness flags)
+    "c1_unit_sphere_64steps": ("simple/unit_sphere.json", 64, 64, dict(maxSteps=64), {}),
+    "unit_sphere_defaults": ("simple/unit_sphere.json", 96, 54, {}, {}),
+    "c2_directional_light_2_soft_ao_ub1": ("lighting/directional_light_2.json", 96, 54, dict(enableSoftShadow=1, enableAmbientOcclusion=1), dict(ub1=True)),
+    "directional_light_2_defaults": ("lighting/directional_light_2.json", 96, 54, {}, {}),
+    "c3_unit_mandelbulb_12iters": ("simple/unit_mandelbulb.json", 96, 54, dict(fractalIters=12), {}),
+    "unit_mandelbulb_defaults": ("simple/unit_mandelbulb.json", 96, 54, {}, {}),
+    "c5_unit_mengersponge_l5_refl2": ("simple/unit_mengersponge.json", 96, 54, dict(mengerLevels=5, numReflection=2, enableReflection=1), {}),
+    "unit_mengersponge_defaults": ("simple/unit_mengersponge.json", 96, 54, {}, {}),
+}
+
+
+def reference_tables(rel, W, H):
+    """ABI tables built from what the reference's own loader + camera produce for scenefile `rel` (realtimerender.cpp:596-811
+    uploads exactly these): nothing of the product's loader is involved."""
+    import json
+    import subprocess
+    binp = os.path.join(ROOT, "oracle", "_ref", "dump_tables")
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib")
+    out = subprocess.run([binp, os.path.join(REF_SCENES, rel), str(W), str(H)], env=env, capture_output=True, text=True, check=True).stdout
+    t = json.loads([l for l in out.splitlines() if l.startswith("@@JSON ")][-1][7:])
+    assert t["ok"]
+    cam = abi.RmCamera()
+    for i in range(16):
+        cam.invProjView[i] = t["invProjView"][i]
+    cam.initialFar = 100.0  # settings.farPlane, mainwindow.cpp:130
+    for i in range(4):
+        cam.eyePosition[i] = t["camPos"][i]
+    objs = (abi.RmObject * max(len(t["objects"]), 1))()
+    tex_slots = 0
+    for i, o in enumerate(t["objects"]):
+        d = objs[i]
+        d.type = o["type"]
+        for k in range(16):
+            d.invModel[k] = o["invModel"][k]
+        d.scaleFactor, d.shininess, d.blend, d.ior = o["scaleFactor"], o["shininess"], o["blend"], o["ior"]
+        for k in range(3):
+            d.cAmbient[k], d.cDiffuse[k], d.cSpecular[k] = o["cAmbient"][k], o["cDiffuse"][k], o["cSpecular"][k]
+            d.cReflective[k], d.cTransparent[k] = o["cReflective"][k], o["cTransparent"][k]
+        d.texLoc, d.lightIdx = -1, -1
+        if o["textured"]:  # configureShapesUniforms hands out texture units in first-use order (realtimerender.cpp:735-806)
+            d.texLoc, d.repeatU, d.repeatV = tex_slots, o["repeatU"], o["repeatV"]
+            tex_slots += 1
+    lights = (abi.RmLight * max(len(t["lights"]), 1))()
+    for i, l in enumerate(t["lights"]):
+        d = lights[i]
+        d.type, d.angle, d.penumbra = l["type"], l["angle"], l["penumbra"]
+        for k in range(3):
+            d.color[k], d.dir[k], d.pos[k], d.func[k] = l["color"][k], l["dir"][k], l["pos"][k], l["func"][k]
+    g = abi.RmGlobals(t["ka"], t["kd"], t["ks"], t["kt"], 8.0)  # power 8, juliaSeed 0, iTime 0: settings.h defaults
+    assert tex_slots <= 1, "the ESSL harness binds one object texture"
+    return (cam, objs, len(t["objects"]), lights, len(t["lights"]), g), tex_slots
+
+
+def scenefile_cases(only=None):
+    from PIL import Image
+    for name, (rel, W, H, over, flags) in SCENEFILE_CASES.items():
+        if only and name not in only:
+            continue
+        scene, ntex = reference_tables(rel, W, H)
+        s = abi.default_settings(**over)
+        tex = None
+        if ntex:  # QImage::load + convertToFormat(RGBA8888) + mirrored() (raymarchscene.cpp:198-209), decoded here with PIL
+            import json
+            sc = json.load(open(os.path.join(REF_SCENES, rel)))
+            files = []
+
+            def walk(node):
+                for p in node.get("primitives", []):
+                    if "textureFile" in p:
+                        files.append(p["textureFile"])
+                for ch in node.get("groups", []):
+                    walk(ch)
+            walk({"groups": sc.get("groups", [])})
+            tex = np.ascontiguousarray(np.asarray(Image.open(os.path.join(REF_SCENES, files[0])).convert("RGBA"))[::-1])
+        rgba, bright = run_ref.render(scene, s, W, H, tex, **flags)
+        # what saveViewportImage writes (realtime.cpp:284-350): clamp, ×255, round, rows top-down
+        png8 = (np.clip(rgba[::-1], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+        np.savez_compressed(os.path.join(OUT, f"scenefile_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, png8=png8,
+                            scenefile=rel, **{k: int(v) for k, v in flags.items()}, **pack(scene, s))
+        print("scenefile", name, rgba.shape, float(np.nanmean(rgba[..., :3])))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "scenefile":
+        return scenefile_cases(sys.argv[2:])
     if len(sys.argv) > 1 and sys.argv[1] == "soft":
         return softshadow_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "res":
@@ -183,6 +272,7 @@ def main():
         return env_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "tex":
         return texture_cases()
+    scenefile_cases()
     texture_cases()
     env_cases()
     post_cases()

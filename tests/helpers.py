@@ -185,6 +185,74 @@ def oracle_render(scene, settings, W, H, row0=0, row1=None, threads=8, bright=Fa
     return res[0] if len(res) == 1 else tuple(res)
 
 
+# ------------------------------------------------------------------ the binary64 arbiter (oracle/rm_oracle_f64.c)
+_ARBITER = None
+_F64_TYPES = {}
+
+
+def arbiter():
+    """ctypes handle of oracle/_build/librm_oracle_f64.so: the same restatement with every float a double and libm
+    built-ins.  Compared with tolerances only."""
+    global _ARBITER
+    if _ARBITER is None:
+        so = os.path.join(ROOT, "oracle", "_build", "librm_oracle_f64.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        _ARBITER = C.CDLL(so)
+    return _ARBITER
+
+
+def _f64_type(t):
+    """The ctypes twin of an ABI type with every c_float a c_double (what `#define float double` makes of the header)."""
+    if t is C.c_float:
+        return C.c_double
+    if t in _F64_TYPES:
+        return _F64_TYPES[t]
+    if isinstance(t, type) and issubclass(t, C.Array):
+        r = _f64_type(t._type_) * t._length_
+    elif isinstance(t, type) and issubclass(t, C.Structure):
+        r = type(t.__name__ + "F64", (C.Structure,), {"_fields_": [(n, _f64_type(ft)) for n, ft in t._fields_]})
+    else:
+        r = t
+    _F64_TYPES[t] = r
+    return r
+
+
+def _to_f64(src):
+    """Copy an ABI struct / array into its binary64 twin, field by field (exact: every binary32 is a binary64)."""
+    dst = _f64_type(type(src))()
+
+    def copy(d, s_):
+        if isinstance(s_, C.Array):
+            for i in range(len(s_)):
+                if isinstance(s_[i], (C.Array, C.Structure)):
+                    copy(d[i], s_[i])
+                else:
+                    d[i] = s_[i]
+        else:
+            for n, _ in s_._fields_:
+                v = getattr(s_, n)
+                if isinstance(v, (C.Array, C.Structure)):
+                    copy(getattr(d, n), v)
+                else:
+                    setattr(d, n, v)
+    copy(dst, src)
+    return dst
+
+
+def arbiter_render(scene, settings, W, H, row0=0, row1=None, threads=8, textures=None, **resources):
+    """The frame in binary64 (float64 array, rows × W × 4)."""
+    cam, objs, no, lights, nl, g = scene[:6]
+    row1 = H if row1 is None else row1
+    out = np.zeros((row1 - row0, W, 4), dtype=np.float64)
+    res, _keep = host_resources(textures=textures, **resources)  # pointers and ints only: same layout in both builds
+    cam64, objs64, lights64, g64 = _to_f64(cam), _to_f64(objs), _to_f64(lights), _to_f64(g)
+    st = arbiter().rmo_render_res(C.byref(cam64), objs64, no, lights64, nl, C.byref(g64), C.byref(settings), C.byref(res), W, H,
+                                  row0, row1, out.ctypes.data_as(C.POINTER(C.c_double)), None, None, threads)
+    assert st == 0, f"arbiter status {st}"
+    return out
+
+
 def oracle_ltc_quantise(table):
     t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1, 4)
     out = np.empty(t.shape, dtype=np.uint8)
