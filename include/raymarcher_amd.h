@@ -248,6 +248,25 @@ int rm_shard_row_to_frame(int H, int tileRows, int shard, int numShards, int loc
 int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
                     int shardStrideRows, void *stream);
 
+/*
+ * rm_gather_* — the gather of a sharded frame, for a host that drives all GPUs of a node from ONE process (no reference
+ * counterpart).  devices[k] renders shard k of numDevices (rm_render_tiles on a stream of that device);
+ * rm_gather_tiles then moves every shard's packed rows into slot k of d_gathered on devices[root] — one grouped
+ * ncclSend / ncclRecv pair per peer over RCCL (xGMI: each peer has its own link to the root), the root's own tiles by a
+ * device copy — asynchronously: the send of shard k is enqueued on streams[k] (behind its render), the receives on
+ * streams[root], where rm_deinterleave(d_gathered, d_frame, W, H, tileRows, numDevices, rm_gather_slot_rows(...),
+ * streams[root]) follows.  Slots are rm_gather_slot_rows(H, tileRows, numDevices) rows each (the largest shard), so
+ * d_gathered holds numDevices · slotRows · W float4.  librccl is loaded on first use (RM_ERR_UNSUPPORTED if absent);
+ * with one device no communicator is created.  One process per GPU (torch.distributed / MPI hosts) does not need this:
+ * raymarcher_amd/dist.py gathers with the process group's own RCCL.
+ */
+typedef struct RmGather RmGather;
+int rm_gather_create(const int *devices, int numDevices, RmGather **out);
+void rm_gather_destroy(RmGather *g);
+int rm_gather_slot_rows(int H, int tileRows, int numShards);
+int rm_gather_tiles(RmGather *g, const float *const *d_tiles, float *d_gathered, int W, int H, int tileRows, int root,
+                    void *const *streams);
+
 /* Fractal / shading work counters of the last counted render (debug/roofline accounting). */
 typedef struct RmCounters {
   uint64_t sceneEvals;   /* sdScene evaluations (frag:1406) */

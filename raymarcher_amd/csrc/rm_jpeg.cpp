@@ -17,8 +17,8 @@ namespace {
 
 struct Huff {
   // canonical decode: codes of length l are in [mincode[l], maxcode[l]], values start at valptr[l]
-  int mincode[17], maxcode[18], valptr[17];
-  uint8_t vals[256];
+  int mincode[17] = {}, maxcode[18] = {}, valptr[17] = {};
+  uint8_t vals[256] = {};
   bool present = false;
 };
 struct Comp { int id, h, v, tq, td, ta, wBlocks, hBlocks, dw, dh, pred; std::vector<uint8_t> plane; int stride; };
@@ -222,7 +222,7 @@ inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v))
 int jpeg_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, int &W, int &H) {
   auto fail = [](int st, const char *msg) { set_error(std::string("JPEG: ") + msg); return st; };
   if (file.size() < 4 || file[0] != 0xFF || file[1] != 0xD8) return fail(RM_ERR_PARSE, "missing SOI");
-  uint16_t qt[4][64];
+  uint16_t qt[4][64] = {};
   bool qtPresent[4] = {false, false, false, false};
   Huff dc[4], ac[4];
   std::vector<Comp> comps;
@@ -278,6 +278,9 @@ int jpeg_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, in
         comps[k].v = d[7 + 3 * k] & 15;
         comps[k].tq = d[8 + 3 * k];
         if (comps[k].h < 1 || comps[k].h > 4 || comps[k].v < 1 || comps[k].v > 4 || comps[k].tq > 3) return fail(RM_ERR_PARSE, "bad SOF");
+        comps[k].td = comps[k].ta = -1;  // assigned by the scan header
+        for (int j = 0; j < k; j++)
+          if (comps[j].id == comps[k].id) return fail(RM_ERR_PARSE, "SOF lists a component id twice");
       }
       haveSOF = true;
     } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
@@ -298,6 +301,8 @@ int jpeg_decode(const std::vector<uint8_t> &file, std::vector<uint8_t> &rgba, in
         c->ta = d[2 + 2 * k] & 15;
         if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present || !qtPresent[c->tq]) return fail(RM_ERR_PARSE, "missing table");
       }
+      for (auto &cc : comps)  // every component of the frame got its tables from this scan (a scan naming one id twice leaves another without)
+        if (cc.td < 0 || cc.ta < 0) return fail(RM_ERR_PARSE, "a component is missing from the scan");
       int hmax = 1, vmax = 1;
       for (auto &c : comps) { hmax = c.h > hmax ? c.h : hmax; vmax = c.v > vmax ? c.v : vmax; }
       if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }  // a single-component scan is never interleaved

@@ -470,8 +470,15 @@ struct Reader {
   }
 
   // sceneparser.cpp:38-108: ctm = parent · M · T · R · S, accumulated scale = parentScale · S.
+  // `path` holds the nodes between the root and n: a template group that (directly or not) contains itself is cut where it
+  // re-enters instead of being expanded 2^depth times; flattenBudget bounds the total expansion of hostile files.
+  std::vector<const Node *> path;
+  long flattenBudget = 1 << 20;
   void flatten(const Node *n, const M4 &parent, const M4 &parentScale, RmScene &sc, std::vector<M4> &lightCtms, int depth) {
-    if (depth > 64) return;  // cyclic template reference guard
+    if (depth > 64 || --flattenBudget < 0) return;
+    for (const Node *p : path)
+      if (p == n) return;  // cyclic template reference
+    path.push_back(n);
     M4 T = identity(), R = identity(), S = identity(), Mx = identity();
     if (n->hasM) Mx = n->matrix;
     if (n->hasS) { S.m[0] = n->scale[0]; S.m[5] = n->scale[1]; S.m[10] = n->scale[2]; }
@@ -512,6 +519,7 @@ struct Reader {
       lightCtms.push_back(ctm);
     }
     for (const Node *c : n->children) flatten(c, ctm, accS, sc, lightCtms, depth + 1);
+    path.pop_back();
   }
 
   bool read(const std::string &text, RmScene &sc) {

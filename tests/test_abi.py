@@ -209,6 +209,24 @@ def test_jpeg_reader_restart_markers_and_refusals(tmp_path):
     with pytest.raises(RaymarcherError) as e:
         load_image(prog)
     assert e.value.status == abi.RM_ERR_UNSUPPORTED
+    # crafted headers: a frame header that lists one component id twice, and a scan that names one id twice (leaving
+    # another component without Huffman tables) are refused, not decoded with unset tables
+    base = tmp_path / "b.jpg"
+    Image.fromarray(img).save(base, "JPEG", quality=80, subsampling=0)
+    data = bytearray(base.read_bytes())
+    sof = data.index(b"\xff\xc0")
+    ids = [data[sof + 10 + 3 * k] for k in range(3)]
+    bad = bytearray(data)
+    bad[sof + 10 + 3] = ids[0]  # second component takes the first one's id
+    (tmp_path / "dup_sof.jpg").write_bytes(bad)
+    sos = data.index(b"\xff\xda")
+    bad2 = bytearray(data)
+    bad2[sos + 5 + 2] = ids[0]  # second scan component names the first id again
+    (tmp_path / "dup_sos.jpg").write_bytes(bad2)
+    for name in ("dup_sof.jpg", "dup_sos.jpg"):
+        with pytest.raises(RaymarcherError) as e:
+            load_image(tmp_path / name)
+        assert e.value.status == abi.RM_ERR_PARSE, name
 
 
 @pytest.mark.parametrize("size,colors,interlace,transparent", [((61, 30), 256, False, False), ((33, 47), 16, False, False),
@@ -280,3 +298,16 @@ int main(int argc, char **argv) {
     assert p.returncode == 0, p.stderr[-2000:]
     r = subprocess.run([str(exe), scene], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("ok RM_ERR_UNSUPPORTED"), (r.returncode, r.stdout, r.stderr[-500:])
+
+
+def test_gather_slot_arithmetic():
+    """rm_gather_slot_rows (the equal slot of the C-ABI gather) holds every shard of the rm_render_tiles partition, the
+    shards partition the frame's rows, and rm_shard_row_to_frame inverts the packing — for ragged sizes too."""
+    L = lib()
+    for H, T, N in ((2160, 8, 8), (2160, 8, 1), (4320, 8, 8), (54, 8, 3), (7, 8, 4), (1080, 16, 5), (33, 1, 64)):
+        slot = L.rm_gather_slot_rows(H, T, N)
+        rows = [L.rm_shard_rows(H, T, k, N) for k in range(N)]
+        assert sum(rows) == H and slot == rows[0] == max(rows)
+        seen = sorted(L.rm_shard_row_to_frame(H, T, k, N, i) for k in range(N) for i in range(rows[k]))
+        assert seen == list(range(H))
+    assert L.rm_gather_slot_rows(0, 8, 2) == 0 and L.rm_gather_slot_rows(10, 0, 2) == 0

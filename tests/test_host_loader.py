@@ -192,3 +192,19 @@ def test_bench_scene_constants_equal_the_scenefile(name):
         assert (a.num_objects, a.num_lights) == (b.num_objects, b.num_lights) == (1, 3)
         assert raw(a.camera) == raw(b.camera) and raw(a.objects) == raw(b.objects)
         assert raw(a.lights) == raw(b.lights) and raw(a.globals_) == raw(b.globals_)
+
+
+def test_self_referencing_template_groups_terminate():
+    """A template group that contains itself (here twice, which a depth cap alone would expand 2^depth times) is cut where
+    it re-enters: the load returns at once with the primitives outside the cycle."""
+    import time
+    text = json.dumps({
+        "name": "root", "globalData": {"ambientCoeff": 0.5, "diffuseCoeff": 0.5, "specularCoeff": 0.5},
+        "cameraData": {"position": [0, 0, 4], "up": [0, 1, 0], "heightAngle": 30.0, "look": [0, 0, -1]},
+        "templateGroups": [{"name": "loop", "primitives": [{"type": "sphere", "diffuse": [1, 1, 1]}],
+                            "groups": [{"name": "loop"}, {"name": "loop"}]}],
+        "groups": [{"name": "loop"}, {"primitives": [{"type": "cube", "diffuse": [1, 0, 0]}]}]})
+    t0 = time.perf_counter()
+    sc = Scene(text=text)
+    assert time.perf_counter() - t0 < 2.0
+    assert 2 <= sc.num_objects <= 30
