@@ -41,6 +41,9 @@
 #define RMO_TRACE_MARCH(c, kind, ro, rd, endp) ((void)0) /* kind 0 = raymarch, 1 = softshadow; may lower *endp */
 #define RMO_TRACE_SKIP_SHADOW(c, N, L) 0                 /* 1 = do not march a shadow ray whose light is dropped anyway */
 #endif
+#ifndef RMO_TRACE_SCENE_EVAL
+#define RMO_TRACE_SCENE_EVAL(c) ((void)0)                /* every sdScene evaluation (any scene) */
+#endif
 
 /* ---------------------------------------------------------------- vector forms of the contract */
 typedef struct { float x, y; } v2;
@@ -316,6 +319,7 @@ static SceneMin sdScene(Ctx *c, v3 p) {
   int minObj = -1;
   v4 trapCol = V4(0.0f, 0.0f, 0.0f, 0.0f);
   c->nEval++;
+  RMO_TRACE_SCENE_EVAL(c);
   for (int i = 0; i < c->numObjects; i++) {
     const RmObject *obj = &c->objs[i];
     v3 po = xform_point(obj->invModel, p); /* frag:1417 */

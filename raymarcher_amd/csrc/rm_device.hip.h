@@ -257,29 +257,52 @@ RM_DEV float sdSierpinski(V3 p) {
 }
 
 // frag:1049-1071 (ma = frag:124-126, column-major)
+// Two bit-identical shortcuts, both on wave-uniform conditions:
+//  * ani == 0 (always at iTime = 0): p ← mix(p, ma·(p + off), 0) = ma·(…)·0 + p·1 is p itself — up to the sign of a zero
+//    component, which nothing downstream can see (|p| in the box, mod(p·s, 2) gives +0 for either zero) — or NaN where p is
+//    not finite, where the level's candidate c is NaN with or without the mix; so the rotation is skipped (15 of ≈45
+//    instructions per level);
+//  * the division by s = 3^(m+1) uses the exact constant-divisor sequence (RM_DIVC) for the first eight levels: its
+//    numerator is min(…) − 1 with min(…) a number near 1, i.e. 0 or at least 2^-24 in magnitude.
 RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
   float d = sdBox(p, 1.0f, 1.0f, 1.0f);
   res = v4(d, 1.0f, 0.0f, 0.0f);
   const float ani = smoothstep_(-0.2f, 0.2f, -cos_(0.5f * sb->g.iTime));
   const float off = 1.5f * sin_(0.01f * sb->g.iTime);
   const int levels = sb->s.mengerLevels;
+  const bool still = __builtin_amdgcn_readfirstlane((int)(ani == 0.0f)) != 0;  // iTime is a uniform
   float s = 1.0f;
-  for (int m = 0; m < levels; m++) {
-    V3 v = v3(p.x + off, p.y + off, p.z + off);
-    V3 mv = v3(fma(-0.80f, v.z, fma(0.00f, v.y, 0.60f * v.x)), fma(0.00f, v.z, fma(1.00f, v.y, 0.00f * v.x)),
-               fma(0.60f, v.z, fma(0.00f, v.y, 0.80f * v.x)));
-    p = mix(p, mv, ani);
+  // one level (frag:1057-1069); DIVC > 0: the divisor 3^(m+1) as a compile-time constant
+  auto level = [&](int m, float divc) __attribute__((always_inline)) {
+    if (!still) {
+      V3 v = v3(p.x + off, p.y + off, p.z + off);
+      V3 mv = v3(fma(-0.80f, v.z, fma(0.00f, v.y, 0.60f * v.x)), fma(0.00f, v.z, fma(1.00f, v.y, 0.00f * v.x)),
+                 fma(0.60f, v.z, fma(0.00f, v.y, 0.80f * v.x)));
+      p = mix(p, mv, ani);
+    }
     V3 a = v3(mod_(p.x * s, 2.0f) - 1.0f, mod_(p.y * s, 2.0f) - 1.0f, mod_(p.z * s, 2.0f) - 1.0f);
     s = s * 3.0f;
     float rx = fabs_(fma(-3.0f, fabs_(a.x), 1.0f)), ry = fabs_(fma(-3.0f, fabs_(a.y), 1.0f)),
           rz = fabs_(fma(-3.0f, fabs_(a.z), 1.0f));
     float da = max_(rx, ry), db = max_(ry, rz), dc = max_(rz, rx);
-    float c = (min_(da, min_(db, dc)) - 1.0f) / s;
+    const float num = min_(da, min_(db, dc)) - 1.0f;
+    const float c = (divc > 0.0f) ? divc_(num, divc, 1.0f / divc) : (num / s);
     if (c > d) {
       d = c;
       res = v4(d, min_(res.y, ((0.2f * da) * db) * dc), (1.0f + (float)m) / 4.0f, 0.0f);
     }
-  }
+  };
+  // the first eight levels written out (straight-line code, constants as immediates, one scalar test per level); deeper
+  // ones — far below pixel size — in a loop with the IEEE division
+  if (levels > 0) level(0, 3.0f);
+  if (levels > 1) level(1, 9.0f);
+  if (levels > 2) level(2, 27.0f);
+  if (levels > 3) level(3, 81.0f);
+  if (levels > 4) level(4, 243.0f);
+  if (levels > 5) level(5, 729.0f);
+  if (levels > 6) level(6, 2187.0f);
+  if (levels > 7) level(7, 6561.0f);
+  for (int m = 8; m < levels; m++) level(m, 0.0f);
   return d;
 }
 

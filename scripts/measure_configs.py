@@ -44,7 +44,10 @@ def main():
     ta = tg.tables_of(al[0])
     ta.ltc1, ta.ltc2 = al[2]["ltc1"], al[2]["ltc2"]
     cases.append(("area light (LTC) + point light, reflection 1920x1080", ta, al[1], 1920, 1080))
-    rows = ["| configuration | kernel ms | Mpixels/s |", "|---|---|---|"]
+    only = os.environ.get("RM_ONLY")  # e.g. RM_ONLY=C5: a single configuration (PMC passes profile one kernel at a time)
+    if only:
+        cases = [c for c in cases if c[0].startswith(only + " ")]
+    rows = ["| configuration | kernel ms | Mpixels/s | sceneEvals (reference / executed) |", "|---|---|---|---|"]
     for name, t, s, W, H in cases:
         out = torch.empty((H, W, 4), dtype=torch.float32, device=r.device)
         for _ in range(3):
@@ -58,7 +61,16 @@ def main():
         ms, k = C.c_double(), C.c_int()
         L.rm_get_timing(C.byref(ms), C.byref(k))
         L.rm_set_timing(0)
-        rows.append(f"| {name} | {ms.value:.3f} | {W * H / ms.value / 1e3:.1f} |")
+        ev = ""
+        if not os.environ.get("RM_NO_COUNT"):
+            try:
+                _, c1 = r.render_counted(t, s, W, H, abi.RM_COUNT_REFERENCE)
+                _, c2 = r.render_counted(t, s, W, H, abi.RM_COUNT_EXECUTED)
+                if c1.sceneEvals:
+                    ev = f"{c1.sceneEvals / 1e6:.1f} M / {c2.sceneEvals / 1e6:.1f} M ({c1.sceneEvals / (W * H):.1f} / {c2.sceneEvals / (W * H):.1f} per pixel)"
+            except Exception as e:  # counted renders do not take sampler resources
+                ev = ""
+        rows.append(f"| {name} | {ms.value:.3f} | {W * H / ms.value / 1e3:.1f} | {ev} |")
         print(rows[-1], flush=True)
     if len(sys.argv) > 1:
         with open(sys.argv[1], "w") as f:

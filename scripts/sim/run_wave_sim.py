@@ -80,6 +80,10 @@ def main():
     for t, row in zip((0, 4, 8, 12, 16), dd):
         print(f"  T={t:2d}: main kernel {row[0] / wave[0]:.3f} (heaviest wave {row[1]:.0f}), tail kernels {row[2] / wave[0]:.3f}, sum {(row[0] + row[2]) / wave[0]:.3f}; "
               f"deferred primary rays/px {row[3] / pixels:.4f}, shadow rays/px {row[4] / pixels:.4f}")
+    un = (C.c_double * 4)()
+    sim.sim_unified(un)
+    print("unified per-lane march state machine (primary → normals → surface work → shadow rays, one evaluation per trip), "
+          "surface block parked until T lanes wait: " + ", ".join(f"T={t}: {v / wave[0]:.3f}" for t, v in zip((1, 8, 16, 32), un)))
     if args.stride == 1:
         s0, s1 = (C.c_float * (1 << 18))(), (C.c_float * (1 << 18))()
         sim.sim_wave_costs_spread(s0, s1, 1 << 18)

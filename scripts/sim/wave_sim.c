@@ -55,9 +55,26 @@ static int sim_skip_shadow(float ndotl) {
   return ndotl <= 0.005f;
 }
 
+/* ---- generic scenes (constant-cost evaluations): per pixel the sequence of marches with their evaluation counts */
+#define SIM_MAXSEG 40
+typedef struct { int n; short evals[SIM_MAXSEG]; unsigned char kind[SIM_MAXSEG]; } SegTrace;
+static __thread SegTrace *t_seg;
+static __thread int t_segKind;
+static void seg_begin(int kind) {
+  SegTrace *s = t_seg;
+  if (!s) return;
+  if (s->n < SIM_MAXSEG) { s->kind[s->n] = (unsigned char)kind; s->evals[s->n] = 0; s->n++; }
+}
+static void seg_eval(void) {
+  SegTrace *s = t_seg;
+  if (!s) return;
+  if (s->n == 0) seg_begin(0);
+  s->evals[s->n - 1]++;
+}
+#define RMO_TRACE_SCENE_EVAL(c) seg_eval()
 #define RMO_TRACE_EVAL(c, iters) sim_eval(iters)
 #define RMO_TRACE_MARCH(c, kind, ro, rd, endp) \
-  sim_march_begin((const void *)(c), (ro).x, (ro).y, (ro).z, (rd).x, (rd).y, (rd).z, (endp))
+  t_segKind = (kind), sim_march_begin((const void *)(c), (ro).x, (ro).y, (ro).z, (rd).x, (rd).y, (rd).z, (endp))
 static void sim_march_begin(const void *ctx, float rox, float roy, float roz, float rdx, float rdy, float rdz, float *endp);
 #define RMO_TRACE_SKIP_SHADOW(c, N, L) sim_skip_shadow(dot3((N), (L)))
 #include "../../oracle/rm_oracle.c"
@@ -65,6 +82,7 @@ static void sim_march_begin(const void *ctx, float rox, float roy, float roz, fl
 /* the production kernel's bulbCullEnd (rm_device.hip.h): end the march where the ray leaves |p_obj| <= R for good */
 static void sim_march_begin(const void *ctx, float rox, float roy, float roz, float rdx, float rdy, float rdz, float *endp) {
   const Ctx *c = (const Ctx *)ctx;
+  seg_begin(t_segKind);
   const v3 ro = V3(rox, roy, roz), rd = V3(rdx, rdy, rdz);
   if (!(t_cullR2 > 0.0f)) return;
   const float *M = c->objs[0].invModel;
@@ -296,6 +314,60 @@ static void sim_workgroup(const PixTrace *px, int nLights, const Cost *k, SimOut
   }
 }
 
+/* Unified per-lane state machine at the MARCH-STEP level: every lane runs its own sequence primary march → (hit) 4 normal
+ * taps → surface work (bump, material, light setup: cSurf, once) → shadow ray 1 → shadow ray 2 …; a wave trip evaluates
+ * the next point of every lane that is in a march (cost cEv + cIt·max iterations); lanes that reach the surface work park
+ * until >= T lanes wait there or nobody is marching, then the block runs once for all of them (cost cSurf); a lane that
+ * starts a new shadow ray pays cRay in the trip it starts (once per trip if any lane does). */
+static double wave_cost_unified(const PixTrace *px, int nLights, const Cost *k, int T, double cSurf) {
+  int phase[64];   /* 0 primary, 1 normals, 2 parked for surface work, 3.. shadow ray (phase-3), 99 done */
+  int e[64];
+  double c = 0;
+  int live = 0;
+  for (int i = 0; i < 64; i++) { phase[i] = px[i].nPrimary > 0 ? 0 : 99; e[i] = 0; if (phase[i] != 99) live++; }
+  while (live) {
+    int mx = -1, marching = 0, parked = 0, newRay = 0;
+    for (int i = 0; i < 64; i++) {
+      const PixTrace *q = &px[i];
+      if (phase[i] == 99) continue;
+      if (phase[i] == 2) { parked++; continue; }
+      marching++;
+      const uint8_t *it; int n;
+      if (phase[i] == 0) { it = q->primary; n = q->nPrimary; }
+      else if (phase[i] == 1) { it = q->normal; n = 4; }
+      else { it = q->shadow[phase[i] - 3]; n = q->nShadow[phase[i] - 3]; }
+      if (it[e[i]] > mx) mx = it[e[i]];
+      if (++e[i] >= n) { /* this march ends with this evaluation */
+        e[i] = 0;
+        if (phase[i] == 0) phase[i] = q->hit ? 1 : 99;
+        else if (phase[i] == 1) phase[i] = 2;
+        else {
+          int l = phase[i] - 3 + 1;
+          while (l < nLights && q->nShadow[l] == 0) l++;
+          phase[i] = l < nLights ? 3 + l : 99;
+          if (phase[i] != 99) newRay = 1;
+        }
+        if (phase[i] == 99) live--;
+      }
+    }
+    if (marching) c += k->cEv + k->cIt * mx + (newRay ? k->cRay : 0);
+    /* surface block */
+    parked = 0; marching = 0;
+    for (int i = 0; i < 64; i++) { if (phase[i] == 2) parked++; else if (phase[i] != 99) marching++; }
+    if (parked && (parked >= T || marching == 0)) {
+      c += cSurf;
+      for (int i = 0; i < 64; i++)
+        if (phase[i] == 2) {
+          int l = 0;
+          while (l < nLights && px[i].nShadow[l] == 0) l++;
+          phase[i] = l < nLights ? 3 + l : 99;
+          if (phase[i] == 99) live--;
+        }
+    }
+  }
+  return c;
+}
+
 /* shipped-schedule cost of one wave (64 pixels) */
 static double wave_cost_shipped(const PixTrace *px, int nLights, const Cost *k) {
   Item it[64];
@@ -349,6 +421,8 @@ static double wave_cost_spread(const PixTrace *px, int nLights, const Cost *k, i
   }
   return a.wave;
 }
+static double g_unified[4];
+void sim_unified(double *out) { for (int i = 0; i < 4; i++) out[i] = g_unified[i]; }
 static float g_waveCostSpread[2][SIM_MAXWAVES];
 static float g_wavePrimCost[SIM_MAXWAVES];
 static short g_waveHits[SIM_MAXWAVES], g_waveMaxPrimSteps[SIM_MAXWAVES], g_waveMaxShadSteps[SIM_MAXWAVES];
@@ -445,6 +519,78 @@ void sim_histograms(double *byActive, double *byStep) {
   for (int i = 0; i < 65; i++) byActive[i] = g_costByActive[i];
   for (int i = 0; i < 257; i++) byStep[i] = g_costByStep[i];
 }
+/* Generic scene (any object table): every pixel's sequence of marches; prices, per 8×8 wave, (a) the shipped code-position
+ * schedule — lanes meet at every march of the code (k-th march of every lane together; the normal taps ride with the march
+ * before them) — and (b) a per-lane queue where every lane runs its own marches back to back (one evaluation per trip).
+ * out: [0] lane-level evaluations, [1] wave-level evaluation trips (a), [2] trips (b), [3] waves, [4] pixels. */
+int sim_generic(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                const RmGlobals *g, const RmSettings *s, int W, int H, int stride, double *out, int threads) {
+  RmResources none;
+  memset(&none, 0, sizeof none);
+  double laneEv = 0, tripsA = 0, tripsB = 0, tripsC = 0, nw = 0, npx = 0;
+  const int gx = (W + 7) / 8, gy = (H + 7) / 8;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : laneEv, tripsA, tripsB, tripsC, nw, npx)
+  for (int b = 0; b < gx * gy; b++) {
+    const int bx = b % gx, by = b / gx;
+    if ((bx + 5 * by) % stride != 0) continue;
+    Ctx c;
+    c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
+    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = NULL; c.numTex = 0; c.res = &none; c.W = W;
+    SegTrace st[64];
+    memset(st, 0, sizeof st);
+    t_cullR2 = 0.0f;
+    for (int l = 0; l < 64; l++) {
+      int x = bx * 8 + (l % 8), y = by * 8 + l / 8;
+      if (x >= W || y >= H) continue;
+      float col[4], br[4];
+      t_seg = &st[l]; t_pix = NULL;
+      shadePixel(&c, x, y, W, H, col, br);
+      t_seg = NULL;
+      npx += 1;
+    }
+    int maxSeg = 0;
+    for (int l = 0; l < 64; l++) if (st[l].n > maxSeg) maxSeg = st[l].n;
+    for (int k = 0; k < maxSeg; k++) {
+      int mx = 0;
+      for (int l = 0; l < 64; l++) if (k < st[l].n && st[l].evals[k] > mx) mx = st[l].evals[k];
+      tripsA += mx;
+    }
+    int mxTot = 0;
+    for (int l = 0; l < 64; l++) {
+      int tot = 0;
+      for (int k = 0; k < st[l].n; k++) tot += st[l].evals[k];
+      laneEv += tot;
+      if (tot > mxTot) mxTot = tot;
+    }
+    tripsB += mxTot;
+    /* (c) lanes still meet at every raymarch of the code (primary, bounces), but the shadow marches that follow it run as a
+     * per-lane queue: group g of a lane = its g-th raymarch segment, then the sum of the shadow segments up to the next one */
+    {
+      int pos[64], done = 0;
+      for (int l = 0; l < 64; l++) pos[l] = 0;
+      while (!done) {
+        int mxR = 0, mxS = 0;
+        done = 1;
+        for (int l = 0; l < 64; l++) {
+          int k = pos[l];
+          if (k >= st[l].n) continue;
+          done = 0;
+          if (st[l].evals[k] > mxR) mxR = st[l].evals[k]; /* the raymarch (kind 0) — or an orphan shadow segment */
+          k++;
+          int sh = 0;
+          while (k < st[l].n && st[l].kind[k] == 1) sh += st[l].evals[k++];
+          if (sh > mxS) mxS = sh;
+          pos[l] = k;
+        }
+        tripsC += mxR + mxS;
+      }
+    }
+    nw += 1;
+  }
+  out[0] = laneEv; out[1] = tripsA; out[2] = tripsB; out[3] = nw; out[4] = npx; out[5] = tripsC;
+  return RM_OK;
+}
+
 int sim_num_schedules(void) { return NSCHED; }
 const char *sim_schedule_name(int s) { return (s >= 0 && s < NSCHED) ? kSchedNames[s] : ""; }
 
@@ -462,6 +608,7 @@ int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmL
   memset(g_costByActive, 0, sizeof g_costByActive);
   memset(g_costByStep, 0, sizeof g_costByStep);
   memset(g_deferOut, 0, sizeof g_deferOut);
+  memset(g_unified, 0, sizeof g_unified);
   const int gx = (W + 31) / 32, gy = (H + 7) / 8;
   SimOut tot;
   memset(&tot, 0, sizeof tot);
@@ -493,6 +640,14 @@ int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmL
       for (int w = 0; w < 4; w++) {
         const double c = wave_cost_shipped(px + 64 * w, numLights, &kh);
         for (int t = 0; t < NDEFER; t++) wave_cost_defer(px + 64 * w, numLights, kDeferT[t], &k, &da[t]);
+        {
+          static const int uT[4] = {1, 8, 16, 32};
+          for (int t = 0; t < 4; t++) {
+            const double cu = wave_cost_unified(px + 64 * w, numLights, &k, uT[t], k.cHit);
+#pragma omp atomic
+            g_unified[t] += cu;
+          }
+        }
         int slot;
 #pragma omp atomic capture
         slot = g_nWaves++;
