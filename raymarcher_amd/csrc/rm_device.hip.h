@@ -702,6 +702,53 @@ RM_DEV bool lightTerm(const RmLight &li, const LightGeom &g, const Material &mat
   return lit;
 }
 
+// The hard-shadow marches of ONE shading point as a per-lane queue (directional lights only).  In getPhong's light loop a
+// wave marches light 0's rays, then light 1's, …: every light costs the LONGEST of its rays, and lanes whose light is
+// dropped (N·L <= 0.005) idle through it.  Here every lane marches its own rays back to back — bit i of `need` = light i
+// wants a march — one evaluation per trip; a lane whose ray ends starts its next one in the same trip.  Each ray is the very
+// same sequence of evaluations as in march<…, SHADOW = true>: same origin, direction, cull end, step cap, hit test.
+// Returns the mask of lights whose ray hit.  (The schedule simulators, scripts/sim/, price this at ×0.95 of the
+// instructions of the per-light loop on the bench frame and ×0.87 on the 8K Menger frame.)
+template <bool BULB, int COUNT, bool CULLS>
+RM_DEV uint32_t shadowQueue(const SceneBlock *sb, V3 so, uint32_t need, float far, Counters &cnt) {
+  const int maxSteps = sb->s.maxSteps;
+  if (maxSteps <= 0) return 0u;  // march() then evaluates nothing and reports a miss
+  uint32_t hitMask = 0u, rest = need;
+  int cur = -1, step = 0;
+  V3 L = v3(0.0f, 0.0f, 0.0f);
+  float depth = 0.0f, end = 0.0f;
+  auto nextRay = [&]() {
+    cur = rest ? (__builtin_ctz(rest)) : -1;
+    rest &= rest - 1u;
+    if (cur >= 0) {
+      const RmLight &li = sb->lights[cur];  // per-lane index: a vector load, once per ray
+      L = normalize(v3(-li.dir[0], -li.dir[1], -li.dir[2]));  // lightSetup's direction of a directional light
+      end = far;
+      if (CULLS) end = BULB ? bulbCullEnd(sb, so, L, far) : sceneCullEnd(sb, so, L, far, sb->cullR2);
+      depth = 0.0f;
+      step = 0;
+    }
+  };
+  nextRay();
+  while (__ballot(cur >= 0) != 0ull) {
+    if (cur >= 0) {
+      const SceneMin c = sdScene<BULB, COUNT, false>(sb, madd(L, depth, so), cnt);
+      const bool hit = fabs_(c.d) < kSurfaceDist;
+      bool fin = hit || depth > end;
+      if (!fin) {
+        depth = depth + fabs_(c.d);
+        step++;
+        fin = step >= maxSteps;  // the loop of march() runs out: a miss
+      }
+      if (fin) {
+        hitMask |= (hit ? 1u : 0u) << cur;
+        nextRay();
+      }
+    }
+  }
+  return hitMask;
+}
+
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
 // RES = true adds the area-light branch (frag:1884-1905); `objs` is only read there.
 // CULLS: end marches at the scene's bounding ball (off in the ENV instantiations, whose register budget it would break).
@@ -715,6 +762,29 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
   const V3 so = shadowOrigin(p, N);
   const int nl = sb->numLights;
   const bool soft = sb->s.enableSoftShadow != 0;
+  if (BULB && !RES && COUNT != 1) {
+    // hard shadows from directional lights only (wave-uniform test): the shadow marches run as a per-lane queue.  Single-bulb
+    // class only: measured 2.46 → 2.37 ms on the 4K bulb frame, but 60 → 63 ms on the 8K Menger frame, whose evaluations are
+    // too cheap to pay for the ray set-up inside the loop
+    bool queue = !soft && nl > 0;
+    for (int i = 0; i < nl; i++) queue = queue && sb->lights[i].type == RM_LIGHT_DIRECTIONAL;
+    if (queue) {
+      uint32_t need = 0u;
+      for (int i = 0; i < nl; i++) {
+        const RmLight &li = sb->lights[i];
+        const V3 L = normalize(v3(-li.dir[0], -li.dir[1], -li.dir[2]));
+        if (!(dot(N, L) <= 0.005f)) need |= 1u << i;  // a light that N·L drops is not marched (see below)
+      }
+      const uint32_t hitMask = shadowQueue<BULB, COUNT, CULLS>(sb, so, need, far, cnt);
+      for (int i = 0; i < nl; i++) {
+        const RmLight &li = sb->lights[i];
+        const LightGeom g = lightSetup(li, p, far);
+        V3 cur;
+        if (lightTerm(li, g, mat, N, V, ks, ((hitMask >> i) & 1u) ? 0 : -1, 1.0f, false, cur)) total = add(total, cur);
+      }
+      return total;
+    }
+  }
   for (int i = 0; i < nl; i++) {
     const RmLight &li = sb->lights[i];  // uniform index → scalar loads
     if (RES && li.type == RM_LIGHT_AREA) {  // AREA_LIGHT_SAMPLES = 1; the "random" uv is rd.xy (frag:1889)
