@@ -34,15 +34,17 @@ def main():
     t = Scene(path=a.scene).tables(a.W, a.H)
     s = abi.default_settings(mengerLevels=a.levels, numReflection=a.bounces, enableReflection=int(a.reflection),
                              enableSoftShadow=int(a.soft), enableAmbientOcclusion=int(a.ao))
-    out = (C.c_double * 6)()
+    out = (C.c_double * 10)()
     st = sim.sim_generic(C.byref(t.camera), t.objects, t.num_objects, t.lights, t.num_lights, C.byref(t.globals_), C.byref(s),
                          a.W, a.H, a.stride, out, len(os.sched_getaffinity(0)))
     assert st == 0
-    lane, ta, tb, nw, npx, tc = list(out)
+    lane, ta, tb, nw, npx, tc, ta2, d1, d8, d16 = list(out)
     print(f"{os.path.basename(a.scene)} {a.W}x{a.H}: {lane / npx:.1f} evaluations per pixel; "
           f"shipped schedule {ta / nw:.0f} evaluation trips per wave (lane utilisation {lane / (64 * ta):.3f}); "
           f"per-lane queue {tb / nw:.0f} trips (utilisation {lane / (64 * tb):.3f}) — {tb / ta:.3f} of the shipped trips; "
           f"shadow rays of one shading point as a per-lane queue: {tc / ta:.3f}")
+    print(f"  with the blocks between marches priced (surface block 3.3, light block 0.7 evaluations): shipped {(ta + ta2) / nw:.0f} per wave; "
+          f"per-lane queue, surface block parked until T lanes wait: T=1 {d1 / (ta + ta2):.3f}, T=8 {d8 / (ta + ta2):.3f}, T=16 {d16 / (ta + ta2):.3f} of it")
 
 
 if __name__ == "__main__":

@@ -527,9 +527,11 @@ int sim_generic(const RmCamera *cam, const RmObject *objs, int numObjects, const
                 const RmGlobals *g, const RmSettings *s, int W, int H, int stride, double *out, int threads) {
   RmResources none;
   memset(&none, 0, sizeof none);
-  double laneEv = 0, tripsA = 0, tripsB = 0, tripsC = 0, nw = 0, npx = 0;
+  double laneEv = 0, tripsA = 0, tripsB = 0, tripsC = 0, nw = 0, npx = 0, tripsA2 = 0;
+  double tripsD[3] = {0, 0, 0};
+  const double cSurf = 3.3, cLight = 0.7; /* in evaluations of a Menger-class scene (≈300 instructions each) */
   const int gx = (W + 7) / 8, gy = (H + 7) / 8;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : laneEv, tripsA, tripsB, tripsC, nw, npx)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : laneEv, tripsA, tripsB, tripsC, nw, npx, tripsA2, tripsD[:3])
   for (int b = 0; b < gx * gy; b++) {
     const int bx = b % gx, by = b / gx;
     if ((bx + 5 * by) % stride != 0) continue;
@@ -585,9 +587,55 @@ int sim_generic(const RmCamera *cam, const RmObject *objs, int numObjects, const
         tripsC += mxR + mxS;
       }
     }
+    /* (d) per-lane queue WITH the price of the blocks between marches, in units of one evaluation: after a raymarch that is
+     * followed by shadow rays (= a hit) the surface block (normal finalisation, bump, material: cSurf), after every shadow
+     * march the light term + next-ray set-up (cLight).  A block runs once per trip in which any lane needs it; the surface
+     * block is parked until >= T lanes wait or nobody marches.  The shipped schedule pays the same blocks once per code
+     * position: added to (a) as tripsA2 for a like-for-like ratio. */
+    for (int v = 0; v < 3; v++) {
+      const int T = (v == 0) ? 1 : (v == 1 ? 8 : 16);
+      int seg[64], e[64], parked[64], live = 0;
+      double cost = 0;
+      for (int l = 0; l < 64; l++) { seg[l] = 0; e[l] = 0; parked[l] = 0; if (st[l].n > 0) live++; else seg[l] = -1; }
+      while (live) {
+        int marching = 0, needLight = 0, nparked = 0;
+        for (int l = 0; l < 64; l++) {
+          if (seg[l] < 0 || parked[l]) { if (seg[l] >= 0) nparked++; continue; }
+          marching++;
+          if (st[l].evals[seg[l]] == 0 || ++e[l] >= st[l].evals[seg[l]]) { /* this march ends with this evaluation */
+            const int k = seg[l];
+            e[l] = 0;
+            if (k + 1 >= st[l].n) { seg[l] = -1; live--; if (st[l].kind[k] == 1) needLight = 1; continue; }
+            if (st[l].kind[k] == 1) needLight = 1;
+            else if (st[l].kind[k + 1] == 1) { parked[l] = 1; nparked++; }
+            seg[l] = k + 1;
+          }
+        }
+        if (marching) cost += 1.0 + (needLight ? cLight : 0.0);
+        marching = 0;
+        for (int l = 0; l < 64; l++) if (seg[l] >= 0 && !parked[l]) marching++;
+        if (nparked && (nparked >= T || marching == 0)) {
+          cost += cSurf;
+          for (int l = 0; l < 64; l++) parked[l] = 0;
+        }
+      }
+      tripsD[v] += cost;
+    }
+    {
+      /* blocks of the shipped schedule: one surface block per raymarch position where any lane hit, one light block per shadow position */
+      int pos[64], done = 0;
+      for (int l = 0; l < 64; l++) pos[l] = 0;
+      for (int k = 0; k < maxSeg; k++) {
+        int anyShadow = 0, anyHit = 0;
+        for (int l = 0; l < 64; l++) if (k < st[l].n) { if (st[l].kind[k] == 1) anyShadow = 1; else if (k + 1 < st[l].n && st[l].kind[k + 1] == 1) anyHit = 1; }
+        tripsA2 += (anyShadow ? cLight : 0.0) + (anyHit ? cSurf : 0.0);
+      }
+      (void)pos; (void)done;
+    }
     nw += 1;
   }
   out[0] = laneEv; out[1] = tripsA; out[2] = tripsB; out[3] = nw; out[4] = npx; out[5] = tripsC;
+  out[6] = tripsA2; out[7] = tripsD[0]; out[8] = tripsD[1]; out[9] = tripsD[2];
   return RM_OK;
 }
 
