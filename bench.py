@@ -137,7 +137,9 @@ def main():
     frame_holder = {}
     # N > 1: frames are independent, so frame i's gather (xGMI) runs under frame i+1's render; every frame still ends as a
     # complete float4 frame on rank 0 (rm_deinterleave), and the timed region ends only when the last one has.
-    pipe = FramePipeline(plan, rank, (W, 4), torch.float32, r.device,
+    # three frames in flight, each on its own stream: the renders of consecutive frames overlap as well (a shard's frame
+    # cannot end before its longest ray chain, ≈0.7–0.9 ms, which is 3× the shard's work at N = 8; dist.FramePipeline)
+    pipe = FramePipeline(plan, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True,
                          finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows))) \
         if distributed else None
 
@@ -251,9 +253,11 @@ def main():
         flops_launch = flops_frame / world
         # with tile-order feedback a launch is two sort kernels (stage 0, ~0.02 ms) + the render kernel (stage 1): the roofline is
         # the render kernel's, `kernel_ms` stays the whole launch
-        ordered = world == 1 and path in (0, 1) and stages[1] > 0.0
+        ordered = path in (0, 1) and stages[1] > 0.0
         render_ms = stages[1] if ordered else kernel_ms
-        secs = render_ms * 1e-3
+        # with several frames in flight (N > 1) the launches overlap and their event spans are not kernel time: the roofline is
+        # then taken over the wall time one frame of this rank's shard costs
+        secs = (dt / args.steps if distributed else render_ms * 1e-3)
         achieved = flops_launch / secs / 1e12 if kernel_ms > 0 else 0.0
         executed = flops_exec / world / secs / 1e12 if kernel_ms > 0 else 0.0
         bytes_launch = W * H * 16 / world
@@ -265,8 +269,9 @@ def main():
             "config": {"workload": "Mandelbulb power 8, 12 iters, 3840x2160, 256 steps, 3 directional lights, "
                                    "Perlin bump, white background (unit_mandelbulb.json as constants)"
                                    + ("; step evaluated with RM_FEAT_BULB_POWER8_ALGEBRAIC" if args.bulb_eval == "algebraic" else ""),
-                       "rows": "whole frame" if world == 1 else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; RCCL gather of "
-                               "frame i to rank 0 overlapped with the render of frame i+1; every frame de-interleaved on rank 0",
+                       "rows": "whole frame" if not distributed else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; three frames in "
+                               "flight per GPU on three streams (renders of consecutive frames overlap, RCCL gather of frame i "
+                               "to rank 0 runs under later renders); every frame de-interleaved on rank 0",
                        "tile_order": "feedback: each frame records its tiles' shader-cycle costs, the next frame starts heavy tiles "
                                      "first (same pixels, same work; variants.raster_tile_order = no history)",
                        "parity": "bit-exact vs CPU oracle (rm_math contract)"},
@@ -289,6 +294,8 @@ def main():
                          "traffic": None,
                          "traffic_source": "not collected by bench.py; rocprofv3 PMC: profiles/r01_k_hbm_pmc.md",
                          "kernel": kernel_name, "kernel_ms": round(render_ms, 4), "launch_ms": round(kernel_ms, 4),
+                         "time_base": ("wall time per frame (three overlapping frames in flight: event spans of single launches "
+                                       "are longer than their share of the GPU)" if distributed else "HIP events around the render kernel"),
                          "stage_ms": ({"tile_order_sort": round(stages[0], 4), "render_kernel": round(stages[1], 4)} if ordered else
                                       {"primary": round(stages[0], 4), "surface": round(stages[1], 4),
                                        "shadow": round(stages[2], 4), "shade": round(stages[3], 4)}),

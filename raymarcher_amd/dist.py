@@ -47,51 +47,75 @@ def gather_to_root(local_slot, plan, rank, gathered=None):
 
 
 class FramePipeline:
-    """Frames are independent, so the gather of frame i (xGMI) runs under the render of frame i+1 (CUs): two slots,
-    the gather is issued asynchronously and only joined when its slot is about to be reused / its frame finished.
+    """Frames are independent, so several are in flight: `depth` slots (local tiles + gather buffer each); the gather of
+    frame i (xGMI) is issued asynchronously and runs under the render of frame i+1 (CUs), and it is only joined `depth − 1`
+    submits later.
 
         for i in range(K): pipe.submit(render_into)        # render_into(slot_tensor) renders this rank's tiles
         pipe.drain()
 
     `finish(gathered_slots)` runs on rank 0 once per frame (de-interleave); everything is stream-ordered on the
-    device (Work.wait() on the "nccl" backend blocks the current stream, not the host)."""
+    device (Work.wait() on the "nccl" backend blocks the current stream, not the host).
 
-    def __init__(self, plan, rank, slot_shape, dtype, device, finish=None):
+    multi_stream=True gives every slot its own CUDA stream, so consecutive frames' RENDER kernels overlap too.  That is what
+    lets a sharded frame scale: a frame holds a few rays that march all 256 steps without converging — a serial chain of
+    ≈0.7–0.9 ms — and on one stream a 1/8-frame shard (0.3 ms of work) cannot end before its longest chain does
+    (measured: 0.93 ms per shard-frame on one stream, 0.33 ms with three frames in flight on three streams;
+    scripts/shard_probe.py).  The library keeps scratch and the tile-order feedback per stream, so the slots do not interfere."""
+
+    def __init__(self, plan, rank, slot_shape, dtype, device, finish=None, depth=2, multi_stream=False):
         import torch
-        self.plan, self.rank, self.finish = plan, rank, finish
-        self.local = [torch.zeros((plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device) for _ in range(2)]
+        assert depth >= 2
+        self.plan, self.rank, self.finish, self.depth = plan, rank, finish, depth
+        self.local = [torch.zeros((plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.gathered = [torch.empty((plan.world * plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device)
-                         for _ in range(2)] if rank == 0 else [None, None]
-        self.work = [None, None]
+                         for _ in range(depth)] if rank == 0 else [None] * depth
+        self.work = [None] * depth
+        self.streams = None
+        if multi_stream and torch.device(device).type == "cuda":
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
+            for st in self.streams:
+                st.wait_stream(torch.cuda.current_stream(device))  # the buffers above were filled on the current stream
         self.i = 0
         self.frames_finished = 0
+
+    def _on(self, b):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.streams[b]) if self.streams is not None else contextlib.nullcontext()
 
     def _join(self, b):
         if self.work[b] is None:
             return
-        self.work[b].wait()
-        self.work[b] = None
-        self.frames_finished += 1
-        if self.rank == 0 and self.finish is not None:
-            self.finish(self.gathered[b])
+        with self._on(b):
+            self.work[b].wait()
+            self.work[b] = None
+            self.frames_finished += 1
+            if self.rank == 0 and self.finish is not None:
+                self.finish(self.gathered[b])
 
     def submit(self, render_into):
         import torch.distributed as dist
-        b = self.i & 1
-        self._join(b)                       # frame i-2 used this slot (normally already joined below)
-        render_into(self.local[b])
-        if self.rank == 0:
-            outs = list(self.gathered[b].view(self.plan.world, self.plan.slot_rows, *self.local[b].shape[1:]).unbind(0))
-            self.work[b] = dist.gather(self.local[b], outs, dst=0, async_op=True)
-        else:
-            self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
-        self._join(b ^ 1)                   # finish frame i-1 while frame i's gather is in flight
+        b = self.i % self.depth
+        self._join(b)                       # frame i-depth used this slot (normally already joined below)
+        with self._on(b):
+            render_into(self.local[b])
+            if self.rank == 0:
+                outs = list(self.gathered[b].view(self.plan.world, self.plan.slot_rows, *self.local[b].shape[1:]).unbind(0))
+                self.work[b] = dist.gather(self.local[b], outs, dst=0, async_op=True)
+            else:
+                self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
+        if self.i >= self.depth - 1:        # finish the oldest frame in flight while the newer ones render / travel
+            self._join((self.i - (self.depth - 1)) % self.depth)
         self.i += 1
 
     def drain(self):
-        b = self.i & 1
-        self._join(b)
-        self._join(b ^ 1)
+        for k in range(self.depth):         # oldest first
+            self._join((self.i + k) % self.depth)
+        if self.streams is not None:
+            import torch
+            for st in self.streams:
+                torch.cuda.current_stream(st.device).wait_stream(st)
 
 
 def deinterleave_host(gathered, plan):

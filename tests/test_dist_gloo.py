@@ -64,13 +64,14 @@ W, H, T, K = 6, 53, 8, 5
 plan = ShardPlan(H, T, world)
 rows = torch.tensor(plan.frame_rows(rank), dtype=torch.float32)
 frames = []
-pipe = FramePipeline(plan, rank, (W, 4), torch.float32, torch.device("cpu"),
+DEPTH = int(os.environ.get("RM_TEST_DEPTH", "2"))
+pipe = FramePipeline(plan, rank, (W, 4), torch.float32, torch.device("cpu"), depth=DEPTH,
                      finish=lambda g: frames.append(deinterleave_host(g, plan).clone()))
 for k in range(K):
     def render_into(slot, k=k):   # pixel value = 1000·frame + frame row: any mix-up of slots, frames or rows shows
         slot[:len(rows)] = (1000.0 * k + rows)[:, None, None].expand(len(rows), W, 4)
     pipe.submit(render_into)
-    assert pipe.frames_finished == max(k, 0), (k, pipe.frames_finished)   # frame k-1 is joined inside submit(k)
+    assert pipe.frames_finished == max(k - (DEPTH - 2), 0), (k, pipe.frames_finished)   # frame k-(DEPTH-1) is joined inside submit(k)
 pipe.drain()
 ok = pipe.frames_finished == K
 if rank == 0:
@@ -86,14 +87,14 @@ sys.exit(0 if int(flag.item()) == 1 else 3)
 '''
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_frame_pipeline_gloo(world, tmp_path):
-    """The double-buffered gather bench.py uses for N > 1 (frame i's gather under frame i+1's render): every frame
-    arrives complete, in order, through the right slot."""
+@pytest.mark.parametrize("world,depth", [(2, 2), (4, 2), (2, 3), (3, 4)])
+def test_frame_pipeline_gloo(world, depth, tmp_path):
+    """The pipelined gather bench.py uses for N > 1 (`depth` frames in flight: frame i's gather under the renders of the
+    frames after it): every frame arrives complete, in order, through the right slot."""
     script = tmp_path / "pipe_worker.py"
     script.write_text(PIPE_WORKER.format(root=ROOT))
-    port = 29900 + world + (os.getpid() % 500)
+    port = 29900 + world + 10 * depth + (os.getpid() % 400)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth)), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

@@ -883,18 +883,18 @@ r = Renderer(0)
 W, H, T = 320, 180, 8
 plan = ShardPlan(H, T, 1)
 frames = []
-pipe = FramePipeline(plan, 0, (W, 4), torch.float32, r.device,
+pipe = FramePipeline(plan, 0, (W, 4), torch.float32, r.device, depth=3, multi_stream=True,   # as bench.py runs it for N > 1
                      finish=lambda g: frames.append(r.deinterleave(g, W, H, T, 1, plan.slot_rows).clone()))
 want = []
-for k in range(4):
+for k in range(7):
     t = scenes.mandelbulb(W, H)
-    t.globals_.power = 8.0 - k                      # a different image per frame
+    t.globals_.power = 8.0 - 0.5 * k                # a different image per frame
     s = abi.default_settings(fractalIters=12)
     want.append(r.render(t, s, W, H).clone())
     pipe.submit(lambda slot, t=t, s=s: r.render_tiles(t, s, W, H, T, 0, 1, out=slot[:plan.rows(0)]))
 pipe.drain()
 torch.cuda.synchronize()
-ok = len(frames) == 4 and all(bool((a.view(dtype=torch.int32) == b.view(dtype=torch.int32)).all()) for a, b in zip(frames, want))
+ok = len(frames) == 7 and all(bool((a.view(dtype=torch.int32) == b.view(dtype=torch.int32)).all()) for a, b in zip(frames, want))
 ok = ok and not bool((want[0] == want[1]).all())
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
