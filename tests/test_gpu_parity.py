@@ -990,9 +990,9 @@ def test_random_scenes_bit_exact(renderer):
     """24 seeded random scenes over the whole ABI surface (every primitive and fractal type, all four light kinds, object
     textures, sky box, night sky, sea, every option and loop-bound knob): the GPU equals the oracle in every bit."""
     W, H = 56, 40
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(int(os.environ.get("RM_FUZZ_SEED", "20261003")))
     kinds = set()
-    for i in range(24):
+    for i in range(int(os.environ.get("RM_FUZZ_CASES", "24"))):  # a long soak: RM_FUZZ_CASES=400 RM_FUZZ_SEED=…
         scene, s, res = _random_case(rng, W, H)
         ref, ref_b = h.oracle_render(scene, s, W, H, bright=True, **res)
         t = tables_of(scene)
@@ -1003,6 +1003,71 @@ def test_random_scenes_bit_exact(renderer):
         assert_bit_equal(br.cpu().numpy(), ref_b, f"random scene {i} bright")
         kinds |= {scene[1][k].type for k in range(scene[2])}
     assert len(kinds) >= 10
+
+
+def _random_bulb_case(rng, W, H):
+    """A random scene of the single-Mandelbulb class (its own kernel instantiation: bounding-ball culls of two radii,
+    v_min orbit trap, per-lane shadow-ray queue): model transform incl. anisotropic scales and tiny objects, Julia seeds
+    inside and outside the tight ball's bound, powers, 1–5 lights of any kind (all-directional sets take the queue), every
+    option, camera anywhere around — also inside the ball."""
+    f = rng.uniform
+    sc = float(rng.choice([1.0, 1.0, 1.7, 0.4, 0.04, 0.008]))
+    an = (1.0, 1.0, 1.0) if f() < 0.7 else tuple(f(0.6, 2.5, 3))
+    M = h.translate(*(f(-0.4, 0.4, 3) * sc)) @ rot_x(f(-1.0, 1.0)) @ h.scale(sc * an[0], sc * an[1], sc * an[2])
+    o = h.make_object(abi.RM_MANDELBULB, model=M, scale_factor=sc * min(an), ambient=tuple(f(0, .4, 3)), diffuse=tuple(f(.2, 1, 3)),
+                      specular=tuple(f(0, 1, 3)), shininess=float(rng.choice([0, 7.5, 25, 100])),
+                      reflective=tuple(f(0, .8, 3)) if f() < 0.3 else (0, 0, 0),
+                      transparent=tuple(f(0, .8, 3)) if f() < 0.2 else (0, 0, 0), ior=float(f(1.05, 1.6)))
+    lights = []
+    all_dir = f() < 0.6
+    for _ in range(int(rng.integers(1, 6))):
+        kind = abi.RM_LIGHT_DIRECTIONAL if all_dir else int(rng.integers(0, 3))
+        col = tuple(f(.3, 1.6, 3))
+        if kind == abi.RM_LIGHT_DIRECTIONAL:
+            d = f(-1, 1, 3)
+            lights.append(h.make_light(kind, col, direction=tuple(d if np.abs(d).max() > 0.1 else (0, -1, 0))))
+        elif kind == abi.RM_LIGHT_POINT:
+            lights.append(h.make_light(kind, col, pos=tuple(f(-4, 4, 3) * max(sc, 0.2)), func=(f(.5, 1), f(0, .1), f(0, .02))))
+        else:
+            lights.append(h.make_light(kind, col, direction=(f(-.3, .3), -1, f(-.6, 0)), pos=(f(-2, 2) * sc, f(3, 5) * sc, f(0, 3) * sc),
+                                       func=(f(.5, 1), f(0, .1), 0), angle=float(f(.4, .9)), penumbra=float(f(.05, .3))))
+    feats = int(rng.choice([abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND, 0])) | (abi.RM_FEAT_PERLIN_BUMP if f() < 0.6 else 0)
+    if f() < 0.2:
+        feats |= abi.RM_FEAT_BULB_POWER8_ALGEBRAIC
+    s = abi.default_settings(features=feats, enableSoftShadow=int(f() < 0.25), enableAmbientOcclusion=int(f() < 0.3),
+                             enableReflection=int(f() < 0.4), enableRefraction=int(f() < 0.3),
+                             maxSteps=int(rng.choice([1, 17, 64, 256])), fractalIters=int(rng.choice([1, 4, 12, 20])),
+                             numReflection=int(rng.choice([1, 2])))
+    julia = (0, 0) if f() < 0.6 else (tuple(f(-.6, .6, 2)) if f() < 0.6 else tuple(f(-1.6, 1.6, 2)))
+    g = h.make_globals(ka=f(.2, .8), kd=f(.3, 1), ks=f(.2, 1), kt=f(.2, 1), power=float(rng.choice([8.0, 8.0, 8.0, 6.0, 3.5])), julia=julia)
+    dist = float(rng.choice([4.5, 3.0, 1.6, 0.8])) * sc * max(an)
+    dirv = f(-1, 1, 3)
+    dirv = dirv / (np.linalg.norm(dirv) + 1e-9)
+    pos = tuple(dirv * dist)
+    look = tuple(-dirv + f(-0.15, 0.15, 3))
+    cam = h.make_camera(pos, look, (0.1, 1, 0.05), float(f(25, 70)), W, H, near=0.02 * dist, far=float(rng.choice([100.0, 100.0, 6.0 * dist])))
+    return (cam, (abi.RmObject * 1)(o), 1, (abi.RmLight * len(lights))(*lights), len(lights), g), s
+
+
+def test_random_bulb_scenes_bit_exact(renderer):
+    """Seeded random scenes of the single-Mandelbulb class — the benchmark's kernel with all its bit-identical shortcuts —
+    against the oracle in every bit, plus the BrightColor plane; counters of the executed-work build stay below the
+    reference-work ones."""
+    W, H = 48, 40
+    rng = np.random.default_rng(int(os.environ.get("RM_FUZZ_SEED", "20261004")))
+    hits = 0
+    for i in range(int(os.environ.get("RM_FUZZ_CASES", "24"))):
+        scene, s = _random_bulb_case(rng, W, H)
+        ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+        out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+        assert_bit_equal(out.cpu().numpy(), ref, f"random bulb scene {i}")
+        assert_bit_equal(br.cpu().numpy(), ref_b, f"random bulb scene {i} bright")
+        hits += int((ref[..., 3] > 0).any() and (ref[..., :3] != ref[0, 0, :3]).any())
+        if i % 8 == 0:
+            _, c1 = renderer.render_counted(tables_of(scene), s, W, H, abi.RM_COUNT_REFERENCE)
+            _, c2 = renderer.render_counted(tables_of(scene), s, W, H, abi.RM_COUNT_EXECUTED)
+            assert c2.sceneEvals <= c1.sceneEvals and c2.bulbIters <= c1.bulbIters and c2.hitPixels == c1.hitPixels
+    assert hits >= 0.5 * int(os.environ.get("RM_FUZZ_CASES", "24"))  # most random views see the bulb
 
 
 def test_bounding_ball_cull_edge_cases(renderer):
