@@ -137,19 +137,31 @@ int rm_gather_tiles(RmGather *g, const float *const *d_tiles, float *d_gathered,
     if (count) HIP_OK(hipMemcpyAsync(d_gathered + root * slotFloats, d_tiles[root], count * sizeof(float), hipMemcpyDeviceToDevice, stream(root)));
   }
   if (n > 1) {
-    NCCL_OK(g_rccl.GroupStart());
-    for (int k = 0; k < n; k++) {
+    // a failure inside the group still closes it (an open group would swallow the process's next RCCL calls) and restores
+    // the caller's device
+    int rc = RM_OK;
+    std::string why;
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) { set_error(std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r)); (void)hipSetDevice(caller); return RM_ERR_DEVICE; }
+    for (int k = 0; k < n && rc == RM_OK; k++) {
       if (k == root) continue;
       const size_t count = (size_t)shard_rows(H, tileRows, k, n) * W * 4;
       if (!count) continue;
-      if (!d_tiles[k]) { (void)g_rccl.GroupEnd(); set_error("null tile buffer"); return RM_ERR_INVALID_ARGUMENT; }
+      if (!d_tiles[k]) { rc = RM_ERR_INVALID_ARGUMENT; why = "null tile buffer"; break; }
       // the send is ordered behind shard k's render on ITS stream; the receive lands in slot k of the root's buffer
-      HIP_OK(hipSetDevice(g->devices[k]));
-      NCCL_OK(g_rccl.Send(d_tiles[k], count, ncclFloat, root, g->comms[k], stream(k)));
-      HIP_OK(hipSetDevice(g->devices[root]));
-      NCCL_OK(g_rccl.Recv(d_gathered + k * slotFloats, count, ncclFloat, k, g->comms[root], stream(root)));
+      hipError_t e = hipSetDevice(g->devices[k]);
+      if (e == hipSuccess) {
+        r = g_rccl.Send(d_tiles[k], count, ncclFloat, root, g->comms[k], stream(k));
+        if (r != ncclSuccess) { rc = RM_ERR_DEVICE; why = std::string("ncclSend: ") + g_rccl.GetErrorString(r); break; }
+        e = hipSetDevice(g->devices[root]);
+      }
+      if (e != hipSuccess) { rc = RM_ERR_DEVICE; why = std::string("hipSetDevice: ") + hipGetErrorString(e); break; }
+      r = g_rccl.Recv(d_gathered + k * slotFloats, count, ncclFloat, k, g->comms[root], stream(root));
+      if (r != ncclSuccess) { rc = RM_ERR_DEVICE; why = std::string("ncclRecv: ") + g_rccl.GetErrorString(r); break; }
     }
-    NCCL_OK(g_rccl.GroupEnd());
+    r = g_rccl.GroupEnd();
+    if (rc == RM_OK && r != ncclSuccess) { rc = RM_ERR_DEVICE; why = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r); }
+    if (rc != RM_OK) { set_error(why); (void)hipSetDevice(caller); return rc; }
   }
   HIP_OK(hipSetDevice(caller));
   return RM_OK;
