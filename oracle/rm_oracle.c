@@ -99,6 +99,33 @@ static inline v4 mat4_mul_v4(const float *M, float x, float y, float z, float w)
   return r;
 }
 
+/* nearClip / farClip are VARYINGS (vert:9-10): the vertex shader evaluates vert:23-24 at the four corners of the full-screen
+ * quad only — two triangles, TL-BL-BR and TR-TL-BR (realtimerender.cpp:225-238) — and the rasteriser hands every fragment
+ * the affine interpolation over ITS triangle, P0 + I·(P1 − P0) + J·(P2 − P0) (gl_Position.w = 1: perspective-correct =
+ * linear).  Restated with P0 the triangle's right-angle corner: below the diagonal (tx + ty <= 1) P0 = BL, P1 = BR, P2 = TL,
+ * I = tx, J = ty; above it P0 = TR, P1 = TL, P2 = BR, I = 1 − tx, J = 1 − ty, with (tx, ty) the pixel centre in [0,1]².
+ * This matters: invProjView·(x, y, ±1, 1) cancels from terms of magnitude |eye|·(far+near)/(2·far·near) down to ~far⁻¹, so
+ * evaluating it PER PIXEL (what a first restatement did) puts an independent ~1e-5 relative error on every primary ray,
+ * which bump-mapped reflections amplify to visible speckle (84 of 2304 pixels of lighting/reflections_complex.json more
+ * than 1e-3 away from the reference shader's frame; 3 with this form).  In the real pipeline those rounding errors sit in
+ * the four corner values — a camera nudge common to the whole frame — and the per-pixel part is two fused multiply-adds. */
+static void rayPlanes(const float *M, v4 P[2][2][3]) {
+  for (int tri = 0; tri < 2; tri++) {
+    const float sg = tri ? 1.0f : -1.0f; /* P0 = (sg, sg), P1 = (−sg, sg), P2 = (sg, −sg) */
+    for (int k = 0; k < 2; k++) {
+      const float z = k ? 1.0f : -1.0f;
+      const v4 p0 = mat4_mul_v4(M, sg, sg, z, 1.0f), p1 = mat4_mul_v4(M, -sg, sg, z, 1.0f), p2 = mat4_mul_v4(M, sg, -sg, z, 1.0f);
+      P[tri][k][0] = p0;
+      P[tri][k][1] = V4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, p1.w - p0.w);
+      P[tri][k][2] = V4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, p2.w - p0.w);
+    }
+  }
+}
+static inline v4 interpolateVarying(const v4 *P, float I, float J) {
+  return V4(rm_fma(J, P[2].x, rm_fma(I, P[1].x, P[0].x)), rm_fma(J, P[2].y, rm_fma(I, P[1].y, P[0].y)),
+            rm_fma(J, P[2].z, rm_fma(I, P[1].z, P[0].z)), rm_fma(J, P[2].w, rm_fma(I, P[1].w, P[0].w)));
+}
+
 /* ---------------------------------------------------------------- context */
 #define SURFACE_DIST 0.001f /* frag:32 */
 #define OUTSIDE 1.0f        /* frag:26 */
@@ -116,6 +143,7 @@ typedef struct {
   int numTex;
   const RmResources *res; /* noise / skybox / LTC tables (host pointers); never NULL inside the renderer */
   int W;                  /* screenDimensions.x (frag:246, realtimerender.cpp:622-629) */
+  v4 rayPlane[2][2][3];   /* [triangle][near, far][P0, P1 − P0, P2 − P0] of nearClip / farClip, see rayPlanes */
   uint64_t nEval, nIter, nHit; /* per-thread work counters */
 } Ctx;
 
@@ -1240,9 +1268,13 @@ static v4 brightOf(v3 color) {
 
 /* raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for pixel (px,py), py = 0 at the bottom */
 static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, float *outBright) {
-  /* NDC of the pixel centre */
-  float ndcx = rm_fma(((float)px + 0.5f) / (float)W, 2.0f, -1.0f);
-  float ndcy = rm_fma(((float)py + 0.5f) / (float)H, 2.0f, -1.0f);
+  /* The pixel centre in the full-screen quad: which triangle, and the weights of that triangle's vertices 1 and 2
+   * (see rayPlanes).  twoDFragCoord = pos (vert:18) is a varying too: −1 + 2·I + 0·J below the diagonal, 1 − 2·I above. */
+  const float tx = ((float)px + 0.5f) / (float)W, ty = ((float)py + 0.5f) / (float)H;
+  const int upper = (tx + ty) > 1.0f;
+  const float I = upper ? 1.0f - tx : tx, J = upper ? 1.0f - ty : ty;
+  const float ndcx = upper ? rm_fma(I, -2.0f, 1.0f) : rm_fma(I, 2.0f, -1.0f);
+  const float ndcy = upper ? rm_fma(J, -2.0f, 1.0f) : rm_fma(J, 2.0f, -1.0f);
   v4 fragColor, bright = V4(0.0f, 0.0f, 0.0f, 1.0f);
   if (c->g.isTwoD) { /* frag:2431, 2377-2380 */
     float scol = sdMandelBrot(c, ndcx, ndcy);
@@ -1251,8 +1283,9 @@ static void shadePixel(Ctx *c, int px, int py, int W, int H, float *outColor, fl
   }
   {
     /* vert:23-24 */
-    v4 nearClip = mat4_mul_v4(c->cam->invProjView, ndcx, ndcy, -1.0f, 1.0f);
-    v4 farClip = mat4_mul_v4(c->cam->invProjView, ndcx, ndcy, 1.0f, 1.0f);
+    /* vert:23-24 at the corners (c->rayPlane), interpolated by the rasteriser */
+    v4 nearClip = interpolateVarying(c->rayPlane[upper][0], I, J);
+    v4 farClip = interpolateVarying(c->rayPlane[upper][1], I, J);
     /* frag:2388-2392 */
     v3 ro = V3(nearClip.x / nearClip.w, nearClip.y / nearClip.w, nearClip.z / nearClip.w);
     v3 farC = V3(farClip.x / farClip.w, farClip.y / farClip.w, farClip.z / farClip.w);
@@ -1595,6 +1628,7 @@ int rmo_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, co
     c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
     c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = res->textures; c.numTex = res->numTextures;
     c.res = res; c.W = W;
+    rayPlanes(cam->invProjView, c.rayPlane);
     for (int x = 0; x < W; x++) {
       size_t o = ((size_t)(y - rowBegin) * W + x) * 4;
       shadePixel(&c, x, y, W, H, rgba + o, bright ? bright + o : NULL);

@@ -185,6 +185,19 @@ SCENEFILE_CASES = {
     "c5_unit_mengersponge_l5_refl2": ("simple/unit_mengersponge.json", 96, 54, dict(mengerLevels=5, numReflection=2, enableReflection=1), {}),
     "unit_mengersponge_defaults": ("simple/unit_mengersponge.json", 96, 54, {}, {}),
 }
+# The sweep: every other scenefile of the reference that needs no image asset beyond blackmarble.png, no LTC table (area
+# lights: lighting/bloom.json, arealight.json, simple/unit_plane.json) and no sky-box, with the reference's default settings
+# (reflection scenes: reflection switched on, which is what they are for).
+_SWEEP = {
+    "lighting": ["directional_light_1", "point_light_1", "point_light_2", "simple_shadow", "spot_light_1", "spot_light_2"],
+    "lighting+reflect": ["reflections_basic", "reflections_complex", "test_reflectiveness"],
+    "simple": ["blank", "parse_matrix", "phong_total", "unit_capsule", "unit_cone", "unit_cube", "unit_cylinder", "unit_deathstar",
+               "unit_mandelbrot", "unit_octa", "unit_sierpinski", "unit_torus"],
+}
+for _grp, _names in _SWEEP.items():
+    for _n in _names:
+        SCENEFILE_CASES[f"sweep_{_n}"] = (f"{_grp.split('+')[0]}/{_n}.json", 64, 36,
+                                          dict(enableReflection=1) if _grp.endswith("+reflect") else {}, {})
 
 
 def reference_tables(rel, W, H):

@@ -197,9 +197,7 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
             int x, r;
             if (decodePixel(pixCur + rank, tilesX, W, nRows, x, r)) {
               pix = r * W + x;
-              float ndcx, ndcy;
-              pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
-              primaryRay(sb, ndcx, ndcy, ro, rd);
+              primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
               t = 0.0f;
               steps = 0;
               deStart(de, k, madd(rd, t, ro));
@@ -244,10 +242,8 @@ __global__ __launch_bounds__(256) void bulb_surface_kernel(const SceneBlock *__r
     if (pix < 0) continue;
     const float4 rec = ws.hitRec[h];
     const int r = pix / W, x = pix - r * W;
-    float ndcx, ndcy;
-    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
     V3 ro, rd;
-    primaryRay(sb, ndcx, ndcy, ro, rd);
+    primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
     const V3 p = madd(rd, rec.x, ro);                    // frag:2333
     V3 n = getNormal<true, false>(sb, p, cnt);           // frag:1436-1444
     if (sb->s.features & RM_FEAT_PERLIN_BUMP) n = bumpNormal(n, p);  // frag:2334-2336
@@ -361,10 +357,8 @@ __global__ __launch_bounds__(256) void bulb_shade_kernel(const SceneBlock *__res
     if (pix < 0) continue;
     const float4 rec = ws.hitRec[h], P = ws.surfP[h], Nn = ws.surfN[h];
     const int r = pix / W, x = pix - r * W;
-    float ndcx, ndcy;
-    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
     V3 ro, rd;
-    primaryRay(sb, ndcx, ndcy, ro, rd);
+    primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
     const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
     const float ao = P.w;
     V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);  // frag:1860
@@ -433,10 +427,8 @@ __global__ __launch_bounds__(256) void bulbB_primary_kernel(const SceneBlock *__
   MarchRes res;
   res.obj = -1; res.d = 0.0f; res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
   if (inside) {
-    float ndcx, ndcy;
-    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
     V3 ro, rd;
-    primaryRay(sb, ndcx, ndcy, ro, rd);
+    primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
     Counters cnt{0, 0};
     res = march<true, false, false>(sb, ro, rd, sb->cam.initialFar, 1.0f, cnt);  // frag:2322
     hit = res.obj != -1;
@@ -471,10 +463,8 @@ __global__ __launch_bounds__(256) void bulbB_surface_kernel(const SceneBlock *__
       const int pix = ws.hitPix[h];
       const float4 rec = ws.hitRec[h];
       const int r = pix / W, x = pix - r * W;
-      float ndcx, ndcy;
-      pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
       V3 ro, rd;
-      primaryRay(sb, ndcx, ndcy, ro, rd);
+      primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
       p = madd(rd, rec.x, ro);                                             // frag:2333
       n = getNormal<true, false>(sb, p, cnt);                              // frag:1436-1444
       if (sb->s.features & RM_FEAT_PERLIN_BUMP) n = bumpNormal(n, p);      // frag:2334-2336
@@ -534,10 +524,8 @@ __global__ __launch_bounds__(256) void bulbB_shade_kernel(const SceneBlock *__re
     const int pix = ws.hitPix[h];
     const float4 rec = ws.hitRec[h], P = ws.surfP[h], Nn = ws.surfN[h];
     const int r = pix / W, x = pix - r * W;
-    float ndcx, ndcy;
-    pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
     V3 ro, rd;
-    primaryRay(sb, ndcx, ndcy, ro, rd);
+    primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
     const V3 p = v3(P.x, P.y, P.z), N = v3(Nn.x, Nn.y, Nn.z);
     const float ao = P.w;
     V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);  // frag:1860
@@ -628,10 +616,8 @@ __global__ __launch_bounds__(256) void bulbC_primary_kernel(const SceneBlock *__
     res.obj = -1; res.d = 0.0f; res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) {
       const int r = pix / W, x = pix - r * W;
-      float ndcx, ndcy;
-      pixelNdc(x, map.frameRow(r), W, H, ndcx, ndcy);
       V3 ro, rd;
-      primaryRay(sb, ndcx, ndcy, ro, rd);
+      primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
       state = marchBudget(sb, ro, rd, far, maxSteps, budget, t, steps, res);
       if (state == 1) {
         const V3 bg = backgroundColor(sb);

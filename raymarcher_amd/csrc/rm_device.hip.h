@@ -67,6 +67,9 @@ struct SceneBlock {
   const uint8_t *ltc1, *ltc2;      // RM_LTC_SIZE² RGBA8 tables of the area lights
   // World-space ball outside which no object can be hit (computed by the launcher, see scene_cull_ball); cullOk = 0
   // when the scene holds an object without a known bound.
+  // nearClip / farClip at the corners of the full-screen quad, per triangle: [below / above the TL-BR diagonal][near, far]
+  // [P0, P1 − P0, P2 − P0][xyzw]; filled by the launcher (ray_planes), interpolated per pixel by primaryRay.
+  float rayPlane[2][2][3][4];
   float cullC[3];
   float cullR2;
   float cullR2Soft;  // larger ball for soft-shadow rays (0 = none): beyond it 8·d/t >= 1, so the penumbra min() is settled
@@ -865,22 +868,41 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   return out;
 }
 
-// NDC of a pixel centre, then raymarch.vert:23-24 + frag:2388-2392: ro on the near plane, rd toward the far plane.
-RM_DEV void pixelNdc(int px, int py, int W, int H, float &ndcx, float &ndcy) {
-  ndcx = fma(((float)px + 0.5f) / (float)W, 2.0f, -1.0f);
-  ndcy = fma(((float)py + 0.5f) / (float)H, 2.0f, -1.0f);
+// The vertex shader's outputs are varyings: raymarch.vert:18-24 is evaluated at the four corners of the full-screen quad
+// (triangles TL-BL-BR and TR-TL-BR, realtimerender.cpp:225-238) and every fragment receives the affine interpolation over
+// its own triangle, P0 + I·(P1 − P0) + J·(P2 − P0).  With P0 the triangle's right-angle corner: below the diagonal
+// (tx + ty <= 1) P0 = BL, I = tx, J = ty; above it P0 = TR, I = 1 − tx, J = 1 − ty; (tx, ty) = the pixel centre in [0,1]².
+struct QuadCoord { float I, J; bool upper; };
+RM_DEV QuadCoord quadCoord(int px, int py, int W, int H) {
+  const float tx = ((float)px + 0.5f) / (float)W, ty = ((float)py + 0.5f) / (float)H;
+  QuadCoord q;
+  q.upper = (tx + ty) > 1.0f;
+  q.I = q.upper ? 1.0f - tx : tx;
+  q.J = q.upper ? 1.0f - ty : ty;
+  return q;
 }
-RM_DEV void primaryRay(const SceneBlock *sb, float ndcx, float ndcy, V3 &ro, V3 &rd) {
-  const float *M = sb->cam.invProjView;
-  // invProjView · (x, y, ∓1, 1): ((M0·x + M1·y) + M2·z) + M3·w
-  float bx = fma(M[4], ndcy, M[0] * ndcx), by = fma(M[5], ndcy, M[1] * ndcx), bz = fma(M[6], ndcy, M[2] * ndcx),
-        bw = fma(M[7], ndcy, M[3] * ndcx);
-  float nw = fma(M[15], 1.0f, fma(M[11], -1.0f, bw)), fw = fma(M[15], 1.0f, fma(M[11], 1.0f, bw));
-  ro = v3(fma(M[12], 1.0f, fma(M[8], -1.0f, bx)) / nw, fma(M[13], 1.0f, fma(M[9], -1.0f, by)) / nw,
-          fma(M[14], 1.0f, fma(M[10], -1.0f, bz)) / nw);  // frag:2388
-  V3 fc = v3(fma(M[12], 1.0f, fma(M[8], 1.0f, bx)) / fw, fma(M[13], 1.0f, fma(M[9], 1.0f, by)) / fw,
-             fma(M[14], 1.0f, fma(M[10], 1.0f, bz)) / fw);  // frag:2389
-  rd = normalize(sub(fc, ro));                              // frag:2392
+// twoDFragCoord = pos (vert:18): −1 + 2·I below the diagonal, 1 − 2·I above
+RM_DEV void pixelNdc(int px, int py, int W, int H, float &ndcx, float &ndcy) {
+  const QuadCoord q = quadCoord(px, py, W, H);
+  ndcx = q.upper ? fma(q.I, -2.0f, 1.0f) : fma(q.I, 2.0f, -1.0f);
+  ndcy = q.upper ? fma(q.J, -2.0f, 1.0f) : fma(q.J, 2.0f, -1.0f);
+}
+// nearClip / farClip (vert:23-24) interpolated from the corner values the launcher staged in sb->rayPlane, then
+// frag:2388-2392: ro on the near plane, rd toward the far plane.
+RM_DEV void primaryRay(const SceneBlock *sb, int px, int py, int W, int H, V3 &ro, V3 &rd) {
+  const QuadCoord q = quadCoord(px, py, W, H);
+  float nc[4], fc4[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // both triangles from scalar registers, then a per-lane select (wave-uniform almost everywhere)
+    const float (*A)[3][4] = sb->rayPlane[0], (*B)[3][4] = sb->rayPlane[1];
+    const float p0n = q.upper ? B[0][0][k] : A[0][0][k], p1n = q.upper ? B[0][1][k] : A[0][1][k], p2n = q.upper ? B[0][2][k] : A[0][2][k];
+    const float p0f = q.upper ? B[1][0][k] : A[1][0][k], p1f = q.upper ? B[1][1][k] : A[1][1][k], p2f = q.upper ? B[1][2][k] : A[1][2][k];
+    nc[k] = fma(q.J, p2n, fma(q.I, p1n, p0n));
+    fc4[k] = fma(q.J, p2f, fma(q.I, p1f, p0f));
+  }
+  ro = v3(nc[0] / nc[3], nc[1] / nc[3], nc[2] / nc[3]);          // frag:2388
+  V3 fc = v3(fc4[0] / fc4[3], fc4[1] / fc4[3], fc4[2] / fc4[3]);  // frag:2389
+  rd = normalize(sub(fc, ro));                                    // frag:2392
 }
 RM_DEV V3 backgroundColor(const SceneBlock *sb) {  // frag:2405-2419 without SKY_BACKGROUND; later #ifdefs override earlier ones
   V3 bg = v3(0.0f, 0.0f, 0.0f);
@@ -913,7 +935,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
     return;
   }
   V3 ro, rd;
-  primaryRay(sb, ndcx, ndcy, ro, rd);
+  primaryRay(sb, px, py, W, H, ro, rd);
   const V3 bg = ENV ? backgroundColor(sb, rd) : backgroundColor(sb);
   const uint32_t feat = sb->s.features;
   const bool env = ENV && (feat & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SEA)) != 0;

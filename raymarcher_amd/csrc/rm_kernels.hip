@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -541,6 +542,30 @@ void scene_cull_ball(SceneBlock *h) {
   }
 }
 
+// nearClip / farClip (raymarch.vert:23-24) at the corners of the full-screen quad, as the vertex shader computes them, per
+// triangle: P0, P1 − P0, P2 − P0 with P0 = (sg, sg), P1 = (−sg, sg), P2 = (sg, −sg), sg = −1 below the TL-BR diagonal and
+// +1 above it.  invProjView·(x, y, z, 1) = ((M0·x + M1·y) + M2·z) + M3, fused — the oracle's mat4_mul_v4, on the host's
+// binary32 FMA (the same bits on any IEEE machine).
+void ray_planes(SceneBlock *h) {
+  const float *M = h->cam.invProjView;
+  auto corner = [&](float x, float y, float z, float out[4]) {
+    for (int c = 0; c < 4; c++) out[c] = std::fmaf(M[12 + c], 1.0f, std::fmaf(M[8 + c], z, std::fmaf(M[4 + c], y, M[c] * x)));
+  };
+  for (int tri = 0; tri < 2; tri++) {
+    const float sg = tri ? 1.0f : -1.0f;
+    for (int k = 0; k < 2; k++) {
+      const float z = k ? 1.0f : -1.0f;
+      float p0[4], p1[4], p2[4];
+      corner(sg, sg, z, p0); corner(-sg, sg, z, p1); corner(sg, -sg, z, p2);
+      for (int c = 0; c < 4; c++) {
+        h->rayPlane[tri][k][0][c] = p0[c];
+        h->rayPlane[tri][k][1][c] = p1[c] - p0[c];
+        h->rayPlane[tri][k][2][c] = p2[c] - p0[c];
+      }
+    }
+  }
+}
+
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, hipStream_t stream, DeviceState &ds, Slot **slotOut,
                 const RmResources &res, const int32_t *tileOrder = nullptr, uint32_t *tileCost = nullptr,
@@ -559,6 +584,7 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   for (int f = 0; f < 6; f++) h->skybox[f] = res.skybox[f];
   h->ltc1 = res.ltc1; h->ltc2 = res.ltc2;
   scene_cull_ball(h);
+  ray_planes(h);
   h->tileOrder = tileOrder; h->tileCost = tileCost; h->tileCount = tileCount;
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   *slotOut = slot;

@@ -1,4 +1,5 @@
-"""Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile the fixture
+"""Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
+other scenefile of the reference that runs without further image assets (29 fixtures, 25 distinct files) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -23,16 +24,29 @@ from raymarcher_amd.render import Scene
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = {
-    # name: (smooth?, min fraction of pixels within 1e-3 of the SwiftShader frame, min fraction of bytes-within-one-level pixels)
-    "c1_unit_sphere_64steps": (True, 1.0, 1.0),
-    "unit_sphere_defaults": (True, 1.0, 1.0),
-    "c2_directional_light_2_soft_ao_ub1": (True, 1.0, 1.0),
-    "directional_light_2_defaults": (True, 1.0, 1.0),
-    "c3_unit_mandelbulb_12iters": (False, 0.84, 0.95),
-    "unit_mandelbulb_defaults": (False, 0.84, 0.95),
-    "c5_unit_mengersponge_l5_refl2": (False, 0.975, 0.98),
-    "unit_mengersponge_defaults": (False, 0.998, 0.998),
+    # name: (class, min fraction of pixels within 1e-3 of the SwiftShader frame, min fraction of bytes-within-one-level pixels)
+    "c1_unit_sphere_64steps": ("smooth", 1.0, 1.0),
+    "unit_sphere_defaults": ("smooth", 1.0, 1.0),
+    "c2_directional_light_2_soft_ao_ub1": ("smooth", 1.0, 1.0),
+    "directional_light_2_defaults": ("smooth", 1.0, 1.0),
+    "c3_unit_mandelbulb_12iters": ("fractal", 0.84, 0.95),
+    "unit_mandelbulb_defaults": ("fractal", 0.84, 0.95),
+    "c5_unit_mengersponge_l5_refl2": ("fractal", 0.975, 0.98),
+    "unit_mengersponge_defaults": ("fractal", 0.998, 0.998),
 }
+# The sweep (64×36, reference defaults; reflection on for the three reflection scenes): every other scenefile the reference
+# ships that needs no image asset beyond blackmarble.png, no LTC table and no sky-box.  Thirteen of them agree with the
+# reference shader to 1e-3 on EVERY pixel; "edge" scenes on all but 1-3 silhouette / reflection-edge pixels of 2304 (where
+# the arbiter sides with the oracle as often as with SwiftShader).  unit_mandelbrot.json marches a 2-D escape-time field
+# as if it were a distance: the three evaluations (binary32 oracle, SwiftShader, binary64) disagree with EACH OTHER on a
+# third of the pixels, so that frame is compared statistically.
+for _n in ("blank", "directional_light_1", "parse_matrix", "point_light_1", "point_light_2", "simple_shadow", "spot_light_1",
+           "spot_light_2", "unit_capsule", "unit_cylinder", "unit_deathstar", "unit_octa", "unit_torus"):
+    CASES[f"sweep_{_n}"] = ("smooth", 1.0, 1.0)
+for _n in ("phong_total", "reflections_basic", "reflections_complex", "test_reflectiveness", "unit_cone", "unit_cube"):
+    CASES[f"sweep_{_n}"] = ("edge", 0.998, 1.0)
+CASES["sweep_unit_sierpinski"] = ("fractal", 0.99, 0.995)
+CASES["sweep_unit_mandelbrot"] = ("chaotic", 0.6, 0.6)
 
 
 def product_tables(z):
@@ -42,21 +56,28 @@ def product_tables(z):
 
 
 def check(name, frame, z, scene_ref, s, textures):
-    smooth, min_close, min_bytes = CASES[name]
+    klass, min_close, min_bytes = CASES[name]
     ref = z["rgba"]
     W, H = int(z["W"]), int(z["H"])
+    if klass == "chaotic":  # NaN where the escape-time "distance" is 0·inf (80 pixels; SwiftShader's min/max drop them)
+        assert np.isfinite(frame[..., 3]).all()
+        frame = np.nan_to_num(frame, nan=0.0)
     d = np.abs(frame - ref).max(-1)
     assert np.isfinite(frame).all()
     assert (d <= 1e-3).mean() >= min_close, f"{name}: {(d > 1e-3).sum()} of {d.size} px beyond 1e-3 of the reference frame (max {d.max():.2e})"
-    assert ((frame[..., 3] != ref[..., 3]).mean()) <= (0.0 if smooth else 0.02)  # same hit / miss / bounce count
+    assert ((frame[..., 3] != ref[..., 3]).mean()) <= (0.02 if klass == "fractal" else 0.0)  # same hit / miss / bounce count
     png = (np.clip(frame[::-1], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
     lv = np.abs(png.astype(int) - z["png8"].astype(int)).max(-1)
     assert (lv <= 1).mean() >= min_bytes, f"{name}: {(lv > 1).sum()} px more than one 8-bit level off"
-    if not smooth:
-        f64 = h.arbiter_render(scene_ref, s, W, H, textures=textures)
+    if klass != "smooth":
+        f64 = np.nan_to_num(h.arbiter_render(scene_ref, s, W, H, textures=textures), nan=0.0)
         d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
-        assert ((d32 <= 1e-3) | (d32 <= dss)).mean() >= 0.985, f"{name}: further from the arbiter than SwiftShader on too many pixels"
-        assert (d32 <= 1e-3).mean() >= (dss <= 1e-3).mean() - 0.005
+        if klass == "chaotic":  # as close to the arbiter as SwiftShader is, and the same picture on average
+            assert (d32 <= 1e-3).mean() >= (dss <= 1e-3).mean() - 0.03
+            assert np.abs(frame[..., :3].mean((0, 1)) - ref[..., :3].mean((0, 1))).max() <= 5e-3
+        else:
+            assert ((d32 <= 1e-3) | (d32 <= dss)).mean() >= (0.995 if klass == "edge" else 0.985), f"{name}: further from the arbiter than SwiftShader on too many pixels"
+            assert (d32 <= 1e-3).mean() >= (dss <= 1e-3).mean() - 0.005
     return png
 
 
@@ -87,4 +108,4 @@ def test_scenefile_to_pixels_on_the_gpu(renderer, name):
     png = check(name, frame, z, scene_ref, s, t.textures)
     assert (renderer.to_rgba8(dev).cpu().numpy() == png).all()  # the kernel's 8-bit conversion = clamp, ×255, round, flip
     ref = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures)
-    assert (frame.view(np.uint32) == ref.view(np.uint32)).all()
+    assert ((frame.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(frame) & np.isnan(ref))).all()  # NaN payloads: "both NaN"
