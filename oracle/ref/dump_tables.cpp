@@ -58,7 +58,8 @@ int main(int argc, char **argv) {
     std::printf("\"scaleFactor\": %.9g, \"shininess\": %.9g, \"blend\": %.9g, \"ior\": %.9g, ", sf, m.shininess, m.blend, m.ior);
     vec("cAmbient", m.cAmbient, 3); vec("cDiffuse", m.cDiffuse, 3); vec("cSpecular", m.cSpecular, 3);
     vec("cReflective", m.cReflective, 3); vec("cTransparent", m.cTransparent, 3);
-    std::printf("\"textured\": %s, \"repeatU\": %.9g, \"repeatV\": %.9g}", m.textureMap.isUsed ? "true" : "false",
+    std::printf("\"textured\": %s, \"textureFile\": \"%s\", \"repeatU\": %.9g, \"repeatV\": %.9g}", m.textureMap.isUsed ? "true" : "false",
+                m.textureMap.isUsed ? m.textureMap.filename.c_str() : "",
                 m.textureMap.isUsed ? m.textureMap.repeatU : 0.f, m.textureMap.isUsed ? m.textureMap.repeatV : 0.f);
   }
   std::printf("], \"lights\": [");

@@ -194,6 +194,11 @@ _SWEEP = {
     "simple": ["blank", "parse_matrix", "phong_total", "unit_capsule", "unit_cone", "unit_cube", "unit_cylinder", "unit_deathstar",
                "unit_mandelbrot", "unit_octa", "unit_sierpinski", "unit_torus"],
 }
+# ... and the single-texture scenes whose image is small enough to keep as a fixture (board.png 8-bit grey, topleft.png /
+# mandril.png / marsTexture.png RGB, colorGrid.png RGBA: the product's PNG reader against QImage's conversions)
+_SWEEP["textures_tests"] = ["texture_cone", "texture_cone2", "texture_cube", "texture_cube2", "texture_cube_sample", "texture_cyl",
+                            "texture_cyl2", "texture_cyl3", "texture_sphere", "texture_sphere2"]
+_SWEEP["simple"] += ["recursive_sphere_2"]  # recursive_sphere_3: more uniforms than SwiftShader links
 for _grp, _names in _SWEEP.items():
     for _n in _names:
         SCENEFILE_CASES[f"sweep_{_n}"] = (f"{_grp.split('+')[0]}/{_n}.json", 64, 36,
@@ -217,7 +222,7 @@ def reference_tables(rel, W, H):
     for i in range(4):
         cam.eyePosition[i] = t["camPos"][i]
     objs = (abi.RmObject * max(len(t["objects"]), 1))()
-    tex_slots = 0
+    tex_files = {}
     for i, o in enumerate(t["objects"]):
         d = objs[i]
         d.type = o["type"]
@@ -228,9 +233,8 @@ def reference_tables(rel, W, H):
             d.cAmbient[k], d.cDiffuse[k], d.cSpecular[k] = o["cAmbient"][k], o["cDiffuse"][k], o["cSpecular"][k]
             d.cReflective[k], d.cTransparent[k] = o["cReflective"][k], o["cTransparent"][k]
         d.texLoc, d.lightIdx = -1, -1
-        if o["textured"]:  # configureShapesUniforms hands out texture units in first-use order (realtimerender.cpp:735-806)
-            d.texLoc, d.repeatU, d.repeatV = tex_slots, o["repeatU"], o["repeatV"]
-            tex_slots += 1
+        if o["textured"]:  # configureShapesUniforms: one texture unit per FILE NAME, in first-use order (realtimerender.cpp:735-806)
+            d.texLoc, d.repeatU, d.repeatV = tex_files.setdefault(o["textureFile"], len(tex_files)), o["repeatU"], o["repeatV"]
     lights = (abi.RmLight * max(len(t["lights"]), 1))()
     for i, l in enumerate(t["lights"]):
         d = lights[i]
@@ -238,8 +242,8 @@ def reference_tables(rel, W, H):
         for k in range(3):
             d.color[k], d.dir[k], d.pos[k], d.func[k] = l["color"][k], l["dir"][k], l["pos"][k], l["func"][k]
     g = abi.RmGlobals(t["ka"], t["kd"], t["ks"], t["kt"], 8.0)  # power 8, juliaSeed 0, iTime 0: settings.h defaults
-    assert tex_slots <= 1, "the ESSL harness binds one object texture"
-    return (cam, objs, len(t["objects"]), lights, len(t["lights"]), g), tex_slots
+    assert len(tex_files) <= 1, "the ESSL harness binds one object texture"
+    return (cam, objs, len(t["objects"]), lights, len(t["lights"]), g), list(tex_files)
 
 
 def scenefile_cases(only=None):
@@ -247,22 +251,11 @@ def scenefile_cases(only=None):
     for name, (rel, W, H, over, flags) in SCENEFILE_CASES.items():
         if only and name not in only:
             continue
-        scene, ntex = reference_tables(rel, W, H)
+        scene, tex_files = reference_tables(rel, W, H)
         s = abi.default_settings(**over)
         tex = None
-        if ntex:  # QImage::load + convertToFormat(RGBA8888) + mirrored() (raymarchscene.cpp:198-209), decoded here with PIL
-            import json
-            sc = json.load(open(os.path.join(REF_SCENES, rel)))
-            files = []
-
-            def walk(node):
-                for p in node.get("primitives", []):
-                    if "textureFile" in p:
-                        files.append(p["textureFile"])
-                for ch in node.get("groups", []):
-                    walk(ch)
-            walk({"groups": sc.get("groups", [])})
-            tex = np.ascontiguousarray(np.asarray(Image.open(os.path.join(REF_SCENES, files[0])).convert("RGBA"))[::-1])
+        if tex_files:  # QImage::load + convertToFormat(RGBA8888) + mirrored() (raymarchscene.cpp:198-209), decoded here with PIL
+            tex = np.ascontiguousarray(np.asarray(Image.open(tex_files[0]).convert("RGBA"))[::-1])
         rgba, bright = run_ref.render(scene, s, W, H, tex, **flags)
         # what saveViewportImage writes (realtime.cpp:284-350): clamp, ×255, round, rows top-down
         png8 = (np.clip(rgba[::-1], 0, 1) * 255.0 + 0.5).astype(np.uint8)

@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that runs without further image assets (29 fixtures, 25 distinct files) — the fixture
+other scenefile of the reference that the harness can run (40 fixtures, 36 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -35,7 +35,8 @@ CASES = {
     "unit_mengersponge_defaults": ("fractal", 0.998, 0.998),
 }
 # The sweep (64×36, reference defaults; reflection on for the three reflection scenes): every other scenefile the reference
-# ships that needs no image asset beyond blackmarble.png, no LTC table and no sky-box.  Thirteen of them agree with the
+# ships that needs no LTC table, no sky-box, at most ONE image (the ESSL harness binds one object texture) of at most a
+# few hundred kB, and fewer uniforms than SwiftShader links (recursive_sphere_3.json does not).  Thirteen of them agree with the
 # reference shader to 1e-3 on EVERY pixel; "edge" scenes on all but 1-3 silhouette / reflection-edge pixels of 2304 (where
 # the arbiter sides with the oracle as often as with SwiftShader).  unit_mandelbrot.json marches a 2-D escape-time field
 # as if it were a distance: the three evaluations (binary32 oracle, SwiftShader, binary64) disagree with EACH OTHER on a
@@ -45,6 +46,14 @@ for _n in ("blank", "directional_light_1", "parse_matrix", "point_light_1", "poi
     CASES[f"sweep_{_n}"] = ("smooth", 1.0, 1.0)
 for _n in ("phong_total", "reflections_basic", "reflections_complex", "test_reflectiveness", "unit_cone", "unit_cube"):
     CASES[f"sweep_{_n}"] = ("edge", 0.998, 1.0)
+# single-texture scenes (the reference's image files, decoded by the product's PNG reader: 8-bit grey, RGB, RGBA).  Where the
+# frames differ by more than 1e-3 (texel borders: SwiftShader blends RGBA8 texels with 8-bit weights) the arbiter sides
+# with the oracle on every pixel.
+for _n in ("texture_cone", "texture_cyl", "texture_sphere"):
+    CASES[f"sweep_{_n}"] = ("smooth", 1.0, 1.0)
+for _n, _close in (("texture_cone2", 0.998), ("texture_cube", 0.998), ("texture_cube2", 0.995), ("texture_cube_sample", 0.994),
+                   ("texture_cyl2", 0.995), ("texture_cyl3", 0.998), ("texture_sphere2", 0.998), ("recursive_sphere_2", 0.998)):
+    CASES[f"sweep_{_n}"] = ("edge", _close, 1.0)
 CASES["sweep_unit_sierpinski"] = ("fractal", 0.99, 0.995)
 CASES["sweep_unit_mandelbrot"] = ("chaotic", 0.6, 0.6)
 
