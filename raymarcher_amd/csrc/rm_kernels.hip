@@ -49,11 +49,27 @@ constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 // stamps: every wave adds its (s_memtime, s_memrealtime) spans to counters[3], counters[4] — shader cycles and 100 MHz
 // ticks — from which rm_render_clocked derives the clock the chip held under this kernel's own load.  The stamps go to a
 // buffer of their own and no output value depends on them.
-// Register budget = waves per SIMD (second launch bound): 4 (≤128 VGPRs) for the plain and single-bulb classes, 3 (≤168) with
-// the procedural layers, 2 with samplers — the occupancies the kernels were tuned at; without the bound a few registers
-// more (131 instead of 128) silently cost a quarter of the resident waves.
+// Register budget = waves per SIMD (second launch bound), MEASURED per kernel class (profiles/r02_m_occupancy.md): the
+// compiler's own choice for these kernels is 121-219 VGPRs (2-4 waves); bounding them tighter spills 29-90 registers, but
+// the spills land outside the march / iteration loops (shading prologues and epilogues) and the extra resident waves hide the
+// serial latency of an evaluation (scalar loads per object, dependent transcendental chains): at 3840x2160 a 5-object Phong
+// scene gains 26 %, bump + reflection 28 %, textured / sky-box scenes 83-90 %, the 8K Menger frame 18 %, the terrain and
+// sea frames 5-7 %, the headline bulb frame 2.3 % (5 waves; its hot loops stay spill-free).  Frames too small to fill the
+// chip (256x256, 1080p tails) lose 1-2 %.  -DRM_*_WAVES=n overrides, for the experiment script scripts/gpu_variants.sh.
+#ifndef RM_GENERIC_WAVES
+#define RM_GENERIC_WAVES 6
+#endif
+#ifndef RM_BULB_WAVES
+#define RM_BULB_WAVES 5
+#endif
+#ifndef RM_ENV_WAVES
+#define RM_ENV_WAVES 5
+#endif
+#ifndef RM_TEX_WAVES
+#define RM_TEX_WAVES 5
+#endif
 template <bool BULB, int COUNT, bool ENV, bool TEX>
-__global__ __launch_bounds__(256, (TEX ? 2 : (ENV ? 3 : 4))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+__global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? RM_BULB_WAVES : RM_GENERIC_WAVES)))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
                                                       unsigned long long *__restrict__ counters) {
