@@ -640,11 +640,12 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
   // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
-  // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident
-  // (measured, profiles/r02_c_waves_per_block.md: the 4K bulb frame 3.34 / 3.13 / 3.18 ms at 4 / 2 / 1 waves, the 8K
-  // Menger frame 105 / 97 / 89 ms): two for the bulb class, one for everything else.  RM_WAVES_PER_BLOCK overrides.
+  // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident: one wave
+  // per workgroup for every class (measured at the register budgets above: the 4K bulb frame 2.31 / 2.34 / 2.58 ms at
+  // 1 / 2 / 4 waves, the 8K Menger frame 51.0 / 51.8 / 58.6 ms, bump + reflection at 4K 19.4 / 19.8 / 22.1 ms; at the
+  // compiler's own budgets two waves were best for the bulb, profiles/r02_c_waves_per_block.md).  RM_WAVES_PER_BLOCK overrides.
   static const int wpb = std::getenv("RM_WAVES_PER_BLOCK") ? std::atoi(std::getenv("RM_WAVES_PER_BLOCK")) : 0;
-  const int nw = (wpb == 1 || wpb == 2 || wpb == 4) ? wpb : ((bulb && !envFeatures && !textured) ? 2 : 1);
+  const int nw = (wpb == 1 || wpb == 2 || wpb == 4) ? wpb : 1;
   const dim3 rgrid((W + nw * kTileW - 1) / (nw * kTileW), (nRows + kBlockH - 1) / kBlockH), rblock(64 * nw);
   // Tile order ("tile order" above): 0 raster order, 1 feedback — tiles start heaviest-first by the costs the previous frame
   // of this size on this stream recorded.  Plain and single-bulb scenes; small frames are not worth the two extra launches.
