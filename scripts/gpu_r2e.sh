@@ -2,7 +2,7 @@
 # PMC passes for the other BASELINE configurations (one configuration per process), then all configs with work counters.
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for cfg in C1 C2 "C4 same" "C4 vol" C5; do
+for cfg in C1 C1@4K C2 C2@4K C3 "C4 same" "C4 volumetric.json" C5 RC; do
   i=0
   for set in "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
     i=$((i+1))
