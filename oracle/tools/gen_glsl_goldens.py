@@ -184,6 +184,11 @@ SCENEFILE_CASES = {
     "unit_mandelbulb_defaults": ("simple/unit_mandelbulb.json", 96, 54, {}, {}),
     "c5_unit_mengersponge_l5_refl2": ("simple/unit_mengersponge.json", 96, 54, dict(mengerLevels=5, numReflection=2, enableReflection=1), {}),
     "unit_mengersponge_defaults": ("simple/unit_mengersponge.json", 96, 54, {}, {}),
+    # BASELINE configuration 4: volumetric.json as the file is, with the TERRAIN / CLOUD / SKY_BACKGROUND layers compiled in
+    # (`nnd` given the UB10 value) — and the terrain + sky layers alone, which need no such edit
+    "c4_volumetric_terrain_cloud_sky_ub10": ("simple/volumetric.json", 96, 54, dict(features=tg.ENV_ALL), dict(ub10=True)),
+    "c4_volumetric_terrain_sky": ("simple/volumetric.json", 96, 54,
+                                  dict(features=abi.RM_FEAT_SKY_BACKGROUND | abi.RM_FEAT_TERRAIN), {}),
 }
 # The sweep: every other scenefile of the reference that needs no image asset beyond blackmarble.png, no LTC table (area
 # lights: lighting/bloom.json, arealight.json, simple/unit_plane.json) and no sky-box, with the reference's default settings

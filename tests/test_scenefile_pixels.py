@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that the harness can run (40 fixtures, 36 of the reference's 52 scenefiles) — the fixture
+other scenefile of the reference that the harness can run (42 fixtures, 37 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -33,6 +33,12 @@ CASES = {
     "unit_mandelbulb_defaults": ("fractal", 0.84, 0.95),
     "c5_unit_mengersponge_l5_refl2": ("fractal", 0.975, 0.98),
     "unit_mengersponge_defaults": ("fractal", 0.998, 0.998),
+    # C4: volumetric.json as the file is (camera below the terrain surface, looking down).  Terrain + sky: every pixel within
+    # 1e-7.  With the cloud layer ("env": no arbiter — the cloud noise hashes with fract(sin(x)·43758.5453), which binary32
+    # DEFINES; a binary64 evaluation of it disagrees with both binary32 implementations on a third of the pixels while they
+    # agree with each other on 98 %).
+    "c4_volumetric_terrain_sky": ("smooth", 1.0, 1.0),
+    "c4_volumetric_terrain_cloud_sky_ub10": ("env", 0.975, 0.99),
 }
 # The sweep (64×36, reference defaults; reflection on for the three reflection scenes): every other scenefile the reference
 # ships that needs no LTC table, no sky-box, at most ONE image (the ESSL harness binds one object texture) of at most a
@@ -78,7 +84,7 @@ def check(name, frame, z, scene_ref, s, textures):
     png = (np.clip(frame[::-1], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
     lv = np.abs(png.astype(int) - z["png8"].astype(int)).max(-1)
     assert (lv <= 1).mean() >= min_bytes, f"{name}: {(lv > 1).sum()} px more than one 8-bit level off"
-    if klass != "smooth":
+    if klass not in ("smooth", "env"):
         f64 = np.nan_to_num(h.arbiter_render(scene_ref, s, W, H, textures=textures), nan=0.0)
         d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
         if klass == "chaotic":  # as close to the arbiter as SwiftShader is, and the same picture on average
