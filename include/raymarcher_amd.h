@@ -319,6 +319,10 @@ int rm_set_tile_order(int mode);
 /* Experiments: force a given launch order (d_order: a device permutation of 0..tileCount-1, or NULL) and / or collect the
  * tiles' costs (d_cost: tileCount device words, accumulated, or NULL) for subsequent launches on the current device. */
 int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCount);
+/* Tests: the 48 coefficients [triangle][near, far][P0, P1 − P0, P2 − P0][xyzw] from which the kernels interpolate nearClip /
+ * farClip (raymarch.vert:23-24 evaluated at the corners of the full-screen quad, realtimerender.cpp:225-238; DESIGN.md
+ * §2.3), computed on the host exactly as the launcher stages them.  No GPU needed. */
+int rm_debug_ray_planes(const RmCamera *cam, float *out48);
 
 /*
  * rm_frame_to_rgba8 — clamp→×255→round and vertical flip, the read-back of

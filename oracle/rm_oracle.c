@@ -1722,6 +1722,18 @@ int rmo_probe_env2(int kind, float iTime, const RmTexture *noise, const float *p
   return RM_OK;
 }
 
+/* the 48 coefficients of rayPlanes ([triangle][near, far][P0, P1 − P0, P2 − P0][xyzw]) for tests */
+void rmo_ray_planes(const RmCamera *cam, float *out) {
+  v4 P[2][2][3];
+  rayPlanes(cam->invProjView, P);
+  for (int t = 0; t < 2; t++)
+    for (int k = 0; k < 2; k++)
+      for (int j = 0; j < 3; j++) {
+        float *o = out + ((t * 2 + k) * 3 + j) * 4;
+        o[0] = P[t][k][j].x; o[1] = P[t][k][j].y; o[2] = P[t][k][j].z; o[3] = P[t][k][j].w;
+      }
+}
+
 /* bits of the contract's constants, for tests */
 /* Exhaustive check behind the product's constant-divisor sequence (rm_math.hip.h, RM_DIVC): for EVERY binary32 mantissa
  * of x, q = x·fl(1/c) followed by one fma-residual correction equals the correctly rounded x / c.  Rounding commutes with

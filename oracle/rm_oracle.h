@@ -32,6 +32,7 @@ int rmo_probe_env2(int kind, float iTime, const RmTexture *noise, const float *p
 uint32_t rmo_const_bits(int which);
 /* Mismatches of the three-instruction constant-divisor sequence against IEEE division over all mantissas (0 = exact). */
 long rmo_check_const_div(float c);
+void rmo_ray_planes(const RmCamera *cam, float *out48);
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -962,6 +963,16 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
   for (auto &t : timed)
     for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
   return rc;
+}
+int rm_debug_ray_planes(const RmCamera *cam, float *out48) {
+  if (!cam || !out48) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
+  static SceneBlock blk;  // host-only scratch; the planes are a pure function of the camera
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  blk.cam = *cam;
+  ray_planes(&blk);
+  std::memcpy(out48, blk.rayPlane, sizeof(blk.rayPlane));
+  return RM_OK;
 }
 int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCount) {
   DeviceState *ds;

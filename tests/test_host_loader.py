@@ -208,3 +208,33 @@ def test_self_referencing_template_groups_terminate():
     sc = Scene(text=text)
     assert time.perf_counter() - t0 < 2.0
     assert 2 <= sc.num_objects <= 30
+
+
+def test_ray_planes_of_launcher_and_oracle_are_the_same_bits():
+    """The corner values of nearClip / farClip from which every primary ray is interpolated: the launcher
+    computes them on the host (rm_debug_ray_planes = what it stages for the kernels), the oracle in C — the same fused
+    sequence, so the same 48 words for every camera; and in float64 they are what raymarch.vert:23-24 says."""
+    L = lib()
+    rng = np.random.default_rng(5)
+    cams = [Scene(path=os.path.join(GOLD, "scenes", rel)).tables(W, H).camera
+            for rel, W, H in (("simple/unit_mandelbulb.json", 3840, 2160), ("lighting/reflections_complex.json", 64, 36),
+                              ("simple/volumetric.json", 96, 54))]
+    for _ in range(20):
+        eye = rng.uniform(-30, 30, 3)
+        cams.append(h.make_camera(tuple(eye), tuple(rng.normal(size=3)), (0, 1, 0), float(rng.uniform(20, 90)), 640, 360,
+                                  far=float(rng.choice([100.0, 2000.0]))))
+    for cam in cams:
+        got = np.zeros(48, dtype=np.float32)
+        ref = np.zeros(48, dtype=np.float32)
+        assert L.rm_debug_ray_planes(C.byref(cam), got.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        h.oracle().rmo_ray_planes(C.byref(cam), h.fptr(ref))
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+        M = np.array(list(cam.invProjView), dtype=np.float64).reshape(4, 4).T  # column-major
+        P = got.reshape(2, 2, 3, 4).astype(np.float64)
+        for tri, sg in enumerate((-1.0, 1.0)):
+            for k, z in enumerate((-1.0, 1.0)):
+                p0, p1, p2 = (M @ np.array([x, y, z, 1.0]) for x, y in ((sg, sg), (-sg, sg), (sg, -sg)))
+                scale = np.abs(M).max() * 4
+                assert np.abs(P[tri, k, 0] - p0).max() <= 1e-6 * scale
+                assert np.abs(P[tri, k, 1] - (p1 - p0)).max() <= 2e-6 * scale
+                assert np.abs(P[tri, k, 2] - (p2 - p0)).max() <= 2e-6 * scale
