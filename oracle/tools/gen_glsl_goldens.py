@@ -204,6 +204,13 @@ _SWEEP = {
 _SWEEP["textures_tests"] = ["texture_cone", "texture_cone2", "texture_cube", "texture_cube2", "texture_cube_sample", "texture_cyl",
                             "texture_cyl2", "texture_cyl3", "texture_sphere", "texture_sphere2"]
 _SWEEP["simple"] += ["recursive_sphere_2"]  # recursive_sphere_3: more uniforms than SwiftShader links
+# ... and a second pass over the scenes whose materials are transparent / reflective or whose lights cast visible shadows,
+# with EVERY shading option on: soft shadows (r.d given the UB1 value), ambient occlusion, reflection, refraction
+_FULL = dict(enableSoftShadow=1, enableAmbientOcclusion=1, enableReflection=1, enableRefraction=1)
+for _rel in ("simple/unit_capsule", "simple/unit_cone", "simple/unit_cylinder", "simple/unit_deathstar", "simple/unit_octa",
+             "simple/unit_torus", "simple/unit_cube", "simple/phong_total", "lighting/point_light_2", "lighting/spot_light_2",
+             "lighting/simple_shadow", "lighting/reflections_basic"):
+    SCENEFILE_CASES[f"sweepfull_{_rel.split('/')[1]}_ub1"] = (_rel + ".json", 64, 36, _FULL, dict(ub1=True))
 for _grp, _names in _SWEEP.items():
     for _n in _names:
         SCENEFILE_CASES[f"sweep_{_n}"] = (f"{_grp.split('+')[0]}/{_n}.json", 64, 36,

@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that the harness can run (42 fixtures, 37 of the reference's 52 scenefiles) — the fixture
+other scenefile of the reference that the harness can run (54 fixtures, 37 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -60,6 +60,13 @@ for _n in ("texture_cone", "texture_cyl", "texture_sphere"):
 for _n, _close in (("texture_cone2", 0.998), ("texture_cube", 0.998), ("texture_cube2", 0.995), ("texture_cube_sample", 0.994),
                    ("texture_cyl2", 0.995), ("texture_cyl3", 0.998), ("texture_sphere2", 0.998), ("recursive_sphere_2", 0.998)):
     CASES[f"sweep_{_n}"] = ("edge", _close, 1.0)
+# the second pass: every shading option on (soft shadows with r.d given the UB1 value, ambient occlusion, reflection,
+# refraction — the unit_* materials are transparent and reflective) on twelve of those scenes
+for _n in ("point_light_2", "simple_shadow", "spot_light_2", "unit_capsule", "unit_deathstar", "unit_torus"):
+    CASES[f"sweepfull_{_n}_ub1"] = ("smooth", 1.0, 1.0)
+for _n in ("phong_total", "unit_cone", "unit_cube", "unit_cylinder", "unit_octa"):
+    CASES[f"sweepfull_{_n}_ub1"] = ("edge", 0.998, 1.0)
+CASES["sweepfull_reflections_basic_ub1"] = ("edge", 0.998, 0.999)
 CASES["sweep_unit_sierpinski"] = ("fractal", 0.99, 0.995)
 CASES["sweep_unit_mandelbrot"] = ("chaotic", 0.6, 0.6)
 
