@@ -52,6 +52,13 @@ namespace rm {
 
 
 // Everything a frame needs, in one constant block (uploaded once per launch by the launcher).
+struct EvalRecord {
+  float m[12];  // invModel[0..2], [4..6], [8..10], [12..14]
+  float scaleFactor;
+  int32_t type;
+  int32_t pad[2];
+};
+static_assert(sizeof(EvalRecord) == 64, "one cache line");
 struct SceneBlock {
   RmCamera cam;
   RmGlobals g;
@@ -67,6 +74,9 @@ struct SceneBlock {
   const uint8_t *ltc1, *ltc2;      // RM_LTC_SIZE² RGBA8 tables of the area lights
   // World-space ball outside which no object can be hit (computed by the launcher, see scene_cull_ball); cullOk = 0
   // when the scene holds an object without a known bound.
+  // What an evaluation reads of an object, packed into one 64-byte line (ONE s_load_dwordx16 instead of seven scattered
+  // loads from RmObject): the three rows of invModel that sdScene uses, scaleFactor, type.  Filled by the launcher.
+  alignas(64) EvalRecord evalRec[RM_MAX_OBJECTS];
   // nearClip / farClip at the corners of the full-screen quad, per triangle: [below / above the TL-BR diagonal][near, far]
   // [P0, P1 − P0, P2 − P0][xyzw]; filled by the launcher (ray_planes), interpolated per pixel by primaryRay.
   float rayPlane[2][2][3][4];
@@ -321,11 +331,17 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
   if (COUNT) cnt.evals++;
   const int n = BULB ? 1 : sb->numObjects;
   for (int i = 0; i < n; i++) {
-    const RmObject &o = sb->objs[i];  // uniform index → scalar loads
-    const float *M = o.invModel;
-    V3 po = v3(fma(M[8], p.z, fma(M[4], p.y, fma(M[0], p.x, M[12]))),
-               fma(M[9], p.z, fma(M[5], p.y, fma(M[1], p.x, M[13]))),
-               fma(M[10], p.z, fma(M[6], p.y, fma(M[2], p.x, M[14]))));  // frag:1417
+    // uniform index → scalar loads; the table walk reads the packed line (three loads instead of seven), the single-bulb
+    // class its one RmObject (hoisted out of the march loops either way)
+    const EvalRecord &o = sb->evalRec[i];
+    float M[12];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 3; r++) M[c * 3 + r] = BULB ? sb->objs[0].invModel[c * 4 + r] : o.m[c * 3 + r];
+    const float scaleFactor = BULB ? sb->objs[0].scaleFactor : o.scaleFactor;
+    V3 po = v3(fma(M[6], p.z, fma(M[3], p.y, fma(M[0], p.x, M[9]))),
+               fma(M[7], p.z, fma(M[4], p.y, fma(M[1], p.x, M[10]))),
+               fma(M[8], p.z, fma(M[5], p.y, fma(M[2], p.x, M[11]))));  // frag:1417
     float d;
     const int type = BULB ? (int)RM_MANDELBULB : o.type;
     switch (type) {  // sdMatch, frag:1262-1293 — wave-uniform branch
@@ -344,7 +360,7 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
       case RM_SIERPINSKI: d = sdSierpinski(po); break;
       default: continue;
     }
-    float cur = d * o.scaleFactor;  // frag:1419
+    float cur = d * scaleFactor;  // frag:1419
     if (cur < res.d) { res.d = cur; res.idx = i; }
   }
   return res;

@@ -593,7 +593,15 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   SceneBlock *h = slot->host;
   h->cam = *cam; h->g = *g; h->s = *s;
   h->numObjects = numObjects; h->numLights = numLights;
-  for (int i = 0; i < numObjects; i++) h->objs[i] = objs[i];
+  for (int i = 0; i < numObjects; i++) {
+    h->objs[i] = objs[i];
+    EvalRecord &e = h->evalRec[i];
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 3; r++) e.m[c * 3 + r] = objs[i].invModel[c * 4 + r];
+    e.scaleFactor = objs[i].scaleFactor;
+    e.type = objs[i].type;
+    e.pad[0] = e.pad[1] = 0;
+  }
   for (int i = 0; i < numLights; i++) h->lights[i] = lights[i];
   h->numTextures = res.numTextures;
   for (int i = 0; i < res.numTextures; i++) h->tex[i] = res.textures[i];
