@@ -8,6 +8,7 @@
 
 #include "camera/camera.h"
 #include "settings.h"
+#include "utils/ltc_matrix.h"
 #include "utils/sceneparser.h"
 
 Settings settings;  // the reference declares it extern (src/settings.h:55)
@@ -25,6 +26,17 @@ static void vec(const char *name, const glm::vec4 &v, int n, bool comma = true) 
 }
 
 int main(int argc, char **argv) {
+  // --ltc FILE: the two 64×64 RGBA float tables Realtime::loadMTexture / loadLTUTexture hand to glTexImage2D
+  // (realtimerender.cpp:896-930), raw binary32, LTC1 then LTC2 — for the fixture generator to quantise as GL_RGBA8 does
+  if (argc == 3 && std::string(argv[1]) == "--ltc") {
+    FILE *f = std::fopen(argv[2], "wb");
+    if (!f) return 3;
+    static_assert(sizeof(LTC1) == 64 * 64 * 4 * sizeof(float) && sizeof(LTC2) == sizeof(LTC1), "64x64 RGBA");
+    std::fwrite(LTC1, 1, sizeof(LTC1), f);
+    std::fwrite(LTC2, 1, sizeof(LTC2), f);
+    std::fclose(f);
+    return 0;
+  }
   if (argc < 4) return 2;
   Settings s;
   s.sceneFilePath = argv[1];
@@ -68,7 +80,12 @@ int main(int argc, char **argv) {
     std::printf("%s{\"type\": %d, ", i ? ", " : "", (int)l.type);
     vec("color", l.color, 3); vec("pos", l.pos, 3); vec("dir", l.dir, 3);
     vec("func", glm::vec4(l.function, 0.f), 3);
-    std::printf("\"angle\": %.9g, \"penumbra\": %.9g}", l.angle, l.penumbra);
+    std::printf("\"angle\": %.9g, \"penumbra\": %.9g", l.angle, l.penumbra);
+    if (l.type == LightType::LIGHT_AREA) {  // what the emissive rectangle and the `points` uniforms are built from
+      std::printf(", \"width\": %.9g, \"height\": %.9g, \"intensity\": %.9g, ", l.width, l.height, l.intensity);
+      mat("ctm", l.ctm); mat("ctmInv", glm::inverse(l.ctm), false);
+    }
+    std::printf("}");
   }
   std::printf("]}\n");
   return 0;

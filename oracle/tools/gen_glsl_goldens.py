@@ -211,6 +211,10 @@ for _rel in ("simple/unit_capsule", "simple/unit_cone", "simple/unit_cylinder", 
              "simple/unit_torus", "simple/unit_cube", "simple/phong_total", "lighting/point_light_2", "lighting/spot_light_2",
              "lighting/simple_shadow", "lighting/reflections_basic"):
     SCENEFILE_CASES[f"sweepfull_{_rel.split('/')[1]}_ub1"] = (_rel + ".json", 64, 36, _FULL, dict(ub1=True))
+# ... and the area-light scenes (the LTC tables travel in the fixture as the 8-bit textures the reference uploads);
+# lighting/arealight.json also has the blackmarble floor
+_SWEEP["lighting"] += ["bloom", "arealight"]
+# (simple/unit_plane.json, the third area-light scene: SwiftShader did not finish it in 30 minutes)
 for _grp, _names in _SWEEP.items():
     for _n in _names:
         SCENEFILE_CASES[f"sweep_{_n}"] = (f"{_grp.split('+')[0]}/{_n}.json", 64, 36,
@@ -248,14 +252,37 @@ def reference_tables(rel, W, H):
         if o["textured"]:  # configureShapesUniforms: one texture unit per FILE NAME, in first-use order (realtimerender.cpp:735-806)
             d.texLoc, d.repeatU, d.repeatV = tex_files.setdefault(o["textureFile"], len(tex_files)), o["repeatU"], o["repeatV"]
     lights = (abi.RmLight * max(len(t["lights"]), 1))()
+    n_objs = len(t["objects"])
+    area = [i for i, l in enumerate(t["lights"]) if l["type"] == abi.RM_LIGHT_AREA]
+    if area:  # RayMarchScene::initScene appends one emissive RECTANGLE per area light (raymarchscene.cpp:126-133, raymarchobj.h:16-23)
+        grown = (abi.RmObject * (n_objs + len(area)))()
+        for i in range(n_objs):
+            grown[i] = objs[i]
+        objs = grown
     for i, l in enumerate(t["lights"]):
         d = lights[i]
         d.type, d.angle, d.penumbra = l["type"], l["angle"], l["penumbra"]
         for k in range(3):
             d.color[k], d.dir[k], d.pos[k], d.func[k] = l["color"][k], l["dir"][k], l["pos"][k], l["func"][k]
+        if l["type"] == abi.RM_LIGHT_AREA:
+            # configureLightsUniforms, realtimerender.cpp:682-693: intensity, twoSided = true, points[k] = ctm · corner k
+            # (realtime.h:136-141: tl, tr, br, bl of the unit square), glm's mat4·vec4 in binary32: (m0·x + m1·y) + (m2·z + m3·w)
+            d.intensity, d.twoSided = l["intensity"], 1
+            m = np.array(l["ctm"], dtype=np.float32).reshape(4, 4)  # m[c] = column c
+            for k, (cx, cy) in enumerate(((-0.5, 0.5), (0.5, 0.5), (0.5, -0.5), (-0.5, -0.5))):
+                v = (m[0] * np.float32(cx) + m[1] * np.float32(cy)) + (m[2] * np.float32(0.0) + m[3] * np.float32(1.0))
+                for j in range(3):
+                    d.points[k][j] = float(v[j])
+            o = objs[n_objs + area.index(i)]
+            o.type, o.scaleFactor, o.texLoc, o.isEmissive, o.lightIdx = abi.RM_RECTANGLE, 1.0, -1, 1, i
+            for k in range(16):
+                o.invModel[k] = l["ctmInv"][k]
+            for k in range(3):
+                o.color[k] = l["color"][k]
+    n_objs += len(area)
     g = abi.RmGlobals(t["ka"], t["kd"], t["ks"], t["kt"], 8.0)  # power 8, juliaSeed 0, iTime 0: settings.h defaults
     assert len(tex_files) <= 1, "the ESSL harness binds one object texture"
-    return (cam, objs, len(t["objects"]), lights, len(t["lights"]), g), list(tex_files)
+    return (cam, objs, n_objs, lights, len(t["lights"]), g), list(tex_files)
 
 
 def scenefile_cases(only=None):
@@ -268,11 +295,25 @@ def scenefile_cases(only=None):
         tex = None
         if tex_files:  # QImage::load + convertToFormat(RGBA8888) + mirrored() (raymarchscene.cpp:198-209), decoded here with PIL
             tex = np.ascontiguousarray(np.asarray(Image.open(tex_files[0]).convert("RGBA"))[::-1])
+        extra = {}
+        if any(scene[3][i].type == abi.RM_LIGHT_AREA for i in range(scene[4])):
+            # the LTC tables as the reference uploads them: 64×64 RGBA floats into a GL_RGBA (8-bit unorm) texture
+            # (loadMTexture / loadLTUTexture, realtimerender.cpp:896-930): dumped from the reference's header by
+            # oracle/_ref/dump_tables --ltc, quantised as the GL does (rmo_ltc_quantise)
+            import subprocess
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+                subprocess.run([os.path.join(ROOT, "oracle", "_ref", "dump_tables"), "--ltc", f.name], check=True,
+                               env=dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib"))
+                raw = np.fromfile(f.name, dtype=np.float32).reshape(2, 64, 64, 4)
+            extra = {"ltc1": h.oracle_ltc_quantise(raw[0]), "ltc2": h.oracle_ltc_quantise(raw[1])}
+            flags = dict(flags, ltc=(extra["ltc1"], extra["ltc2"]))
         rgba, bright = run_ref.render(scene, s, W, H, tex, **flags)
+        flags = {k: v for k, v in flags.items() if k != "ltc"}
         # what saveViewportImage writes (realtime.cpp:284-350): clamp, ×255, round, rows top-down
         png8 = (np.clip(rgba[::-1], 0, 1) * 255.0 + 0.5).astype(np.uint8)
         np.savez_compressed(os.path.join(OUT, f"scenefile_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, png8=png8,
-                            scenefile=rel, **{k: int(v) for k, v in flags.items()}, **pack(scene, s))
+                            scenefile=rel, **{k: int(v) for k, v in flags.items()}, **extra, **pack(scene, s))
         print("scenefile", name, rgba.shape, float(np.nanmean(rgba[..., :3])))
 
 

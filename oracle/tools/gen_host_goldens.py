@@ -48,6 +48,8 @@ def main():
                     break
                 if not entry:
                     entry = {k: v for k, v in t.items() if k not in ("view", "proj", "invProjView")}
+                    for o in entry["objects"]:  # resolved against the scenefile's grand-parent directory: keep the tail
+                        o["textureFile"] = os.path.relpath(o["textureFile"], os.path.dirname(d)) if o["textureFile"] else ""
                     entry["camera"] = {}
                 entry["camera"][f"{w}x{h}"] = {k: t[k] for k in ("view", "proj", "invProjView")}
             golden[rel] = entry

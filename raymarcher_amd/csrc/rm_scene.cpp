@@ -515,6 +515,16 @@ struct Reader {
       out.angle = l.angle; out.penumbra = l.penumbra;
       out.intensity = 0.0f;  // dropped by the aggregate initialiser, sceneparser.cpp:18-30
       out.twoSided = (l.type == RM_LIGHT_AREA) ? 1 : 0;
+      if (l.type == RM_LIGHT_AREA) {
+        // configureLightsUniforms, realtimerender.cpp:682-693: points[k] = ctm · corner k of the unit square in the
+        // light's plane (realtime.h:136-141: tl, tr, br, bl) — the rectangle the LTC integral runs over
+        static const float kCorners[4][4] = {{-0.5f, 0.5f, 0.0f, 1.0f}, {0.5f, 0.5f, 0.0f, 1.0f}, {0.5f, -0.5f, 0.0f, 1.0f}, {-0.5f, -0.5f, 0.0f, 1.0f}};
+        for (int k = 0; k < 4; k++) {
+          float w[4];
+          mulVec(ctm, kCorners[k], w);
+          for (int i = 0; i < 3; i++) out.points[k][i] = w[i];
+        }
+      }
       sc.lights.push_back(out);
       lightCtms.push_back(ctm);
     }

@@ -51,9 +51,16 @@ def test_loader_matches_reference_tables(rel):
         if ro["textured"]:
             assert (o.repeatU, o.repeatV) == (ro["repeatU"], ro["repeatV"])
         assert o.isEmissive == 0 and o.lightIdx == -1
-    for i in range(n_area):
-        o = objs[len(ref_objs) + i]
-        assert o.type == abi.RM_RECTANGLE and o.isEmissive == 1
+    area = [i for i, l in enumerate(g["lights"]) if l["type"] == abi.RM_LIGHT_AREA]
+    for k, li in enumerate(area):
+        # raymarchscene.cpp:126-133 / raymarchobj.h:16-23: rectangle with the light's transform, colour and index
+        o, rl = objs[len(ref_objs) + k], g["lights"][li]
+        assert o.type == abi.RM_RECTANGLE and o.isEmissive == 1 and o.lightIdx == li and o.texLoc == -1
+        assert close(list(o.invModel), rl["ctmInv"], rel=2e-5, abs_=2e-6) and o.scaleFactor == 1.0
+        assert list(o.color) == [float(np.float32(v)) for v in rl["color"]]
+    for i, ro in enumerate(ref_objs):  # the image every textured primitive names (resolved path, tail compared)
+        tex = sc.texture_of(i)
+        assert (tex or "").replace(os.sep, "/").endswith(ro["textureFile"]) and bool(tex) == bool(ro["textureFile"])
     for i, rl in enumerate(g["lights"]):
         li = lights[i]
         assert li.type == rl["type"]
@@ -61,6 +68,13 @@ def test_loader_matches_reference_tables(rel):
         assert close(list(li.pos), rl["pos"]) and close(list(li.dir), rl["dir"])
         assert list(li.func) == [float(np.float32(v)) for v in rl["func"]]
         assert close(li.angle, rl["angle"], rel=1e-7) and close(li.penumbra, rl["penumbra"], rel=1e-7)
+        if rl["type"] == abi.RM_LIGHT_AREA:
+            # configureLightsUniforms, realtimerender.cpp:682-693: twoSided = true, the parsed intensity (which the reference's
+            # reader never stores: 0), points[k] = ctm · corner k of the unit square (realtime.h:136-141: tl, tr, br, bl)
+            assert li.twoSided == 1 and li.intensity == np.float32(rl["intensity"])
+            m = np.array(rl["ctm"], dtype=np.float64).reshape(4, 4).T
+            for k, (cx, cy) in enumerate(((-0.5, 0.5), (0.5, 0.5), (0.5, -0.5), (-0.5, -0.5))):
+                assert close([li.points[k][j] for j in range(3)], list((m @ np.array([cx, cy, 0.0, 1.0]))[:3]), rel=2e-6, abs_=2e-6)
     gl = abi.RmGlobals()
     assert lib().rm_scene_globals(sc._h, None, C.byref(gl)) == 0
     assert (gl.ka, gl.kd, gl.ks) == tuple(float(np.float32(g[k])) for k in ("ka", "kd", "ks"))

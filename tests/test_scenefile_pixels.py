@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that the harness can run (54 fixtures, 37 of the reference's 52 scenefiles) — the fixture
+other scenefile of the reference that the harness can run (56 fixtures, 39 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -67,20 +67,48 @@ for _n in ("point_light_2", "simple_shadow", "spot_light_2", "unit_capsule", "un
 for _n in ("phong_total", "unit_cone", "unit_cube", "unit_cylinder", "unit_octa"):
     CASES[f"sweepfull_{_n}_ub1"] = ("edge", 0.998, 1.0)
 CASES["sweepfull_reflections_basic_ub1"] = ("edge", 0.998, 0.999)
+# area lights, with the reference's own LTC tables as the 8-bit textures it uploads (lighting/arealight.json also has the
+# textured floor; simple/unit_plane.json, the third such scene, SwiftShader did not finish compiling)
+CASES["sweep_bloom"] = ("ltc", 0.98, 0.0)
+CASES["sweep_arealight"] = ("ltc", 0.88, 0.0)
 CASES["sweep_unit_sierpinski"] = ("fractal", 0.99, 0.995)
 CASES["sweep_unit_mandelbrot"] = ("chaotic", 0.6, 0.6)
 
 
 def product_tables(z):
-    """The product's own path from the JSON file: loader, camera, texture decoder."""
+    """The product's own path from the JSON file: loader, camera, texture decoder.  Area-light scenes: the two LTC tables are
+    resources the caller supplies (RmResources.ltc1 / ltc2) — here the 8-bit textures the reference uploads, from the fixture."""
     W, H = int(z["W"]), int(z["H"])
-    return Scene(path=os.path.join(GOLD, "scenes", str(z["scenefile"]))).tables(W, H), W, H
+    t = Scene(path=os.path.join(GOLD, "scenes", str(z["scenefile"]))).tables(W, H)
+    if "ltc1" in z.files:
+        t.ltc1, t.ltc2 = np.ascontiguousarray(z["ltc1"]), np.ascontiguousarray(z["ltc2"])
+    return t, W, H
 
 
-def check(name, frame, z, scene_ref, s, textures):
+def resources(t):
+    return {} if t.ltc1 is None else {"ltc1": t.ltc1, "ltc2": t.ltc2}
+
+
+def check(name, frame, z, scene_ref, s, textures, **res):
     klass, min_close, min_bytes = CASES[name]
     ref = z["rgba"]
     W, H = int(z["W"]), int(z["H"])
+    if klass == "ltc":
+        # The reference uploads the LTC matrices into an 8-bit unorm texture (entries outside [0,1] are clamped), which makes
+        # the specular transform singular at grazing angles: the clipped polygon collapses to a segment whose signed areas
+        # cancel EXACTLY in binary32 and the form factor is 0/0.  Those pixels (1-2 %) are NaN in the oracle and on the GPU,
+        # rounding residue elsewhere; they are compared as "NaN on both" by the GPU test and left out here.
+        nan = np.isnan(frame).any(-1)
+        assert nan.mean() <= 0.02 and np.isfinite(frame[..., 3]).all()
+        f64 = h.arbiter_render(scene_ref, s, W, H, textures=textures, **res)
+        d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
+        assert (d32[~nan] <= 1e-3).all(), f"{name}: the oracle is not within 1e-3 of the arbiter ({np.nanmax(d32):.2e})"
+        # SwiftShader blends the LTC texels with 8-bit weights: it is the one that is off (DESIGN.md §2.1)
+        d = np.abs(frame - ref).max(-1)
+        assert (d[~nan] <= 1e-3).mean() >= min_close and (d[~nan] <= 1e-2).mean() >= 0.99
+        assert (d32[~nan] <= dss[~nan] + 1e-3).all()
+        assert (frame[..., 3] == ref[..., 3]).all()
+        return (np.clip(np.nan_to_num(frame[::-1]), 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
     if klass == "chaotic":  # NaN where the escape-time "distance" is 0·inf (80 pixels; SwiftShader's min/max drop them)
         assert np.isfinite(frame[..., 3]).all()
         frame = np.nan_to_num(frame, nan=0.0)
@@ -92,7 +120,7 @@ def check(name, frame, z, scene_ref, s, textures):
     lv = np.abs(png.astype(int) - z["png8"].astype(int)).max(-1)
     assert (lv <= 1).mean() >= min_bytes, f"{name}: {(lv > 1).sum()} px more than one 8-bit level off"
     if klass not in ("smooth", "env"):
-        f64 = np.nan_to_num(h.arbiter_render(scene_ref, s, W, H, textures=textures), nan=0.0)
+        f64 = np.nan_to_num(h.arbiter_render(scene_ref, s, W, H, textures=textures, **res), nan=0.0)
         d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
         if klass == "chaotic":  # as close to the arbiter as SwiftShader is, and the same picture on average
             assert (d32 <= 1e-3).mean() >= (dss <= 1e-3).mean() - 0.03
@@ -114,8 +142,13 @@ def test_scenefile_to_pixels_on_the_cpu(name):
         assert a.type == b.type and a.texLoc == b.texLoc
         assert np.allclose(list(a.invModel), list(b.invModel), rtol=2e-5, atol=2e-6) and np.isclose(a.scaleFactor, b.scaleFactor)
     assert np.allclose(list(t.camera.invProjView), list(scene_ref[0].invProjView), rtol=2e-5, atol=1e-6)
-    frame = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures)
-    check(name, frame, z, scene_ref, s, t.textures)
+    for i in range(t.num_lights):  # area lights: the corner points of the rectangle, intensity, two-sidedness
+        a, b = t.lights[i], scene_ref[3][i]
+        assert (a.type, a.twoSided, a.intensity) == (b.type, b.twoSided, b.intensity)
+        assert np.allclose([[a.points[k][j] for j in range(3)] for k in range(4)], [[b.points[k][j] for j in range(3)] for k in range(4)], atol=1e-5)
+    frame = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures,
+                            **resources(t))
+    check(name, frame, z, scene_ref, s, t.textures, **resources(t))
 
 
 @pytest.mark.gpu
@@ -127,7 +160,9 @@ def test_scenefile_to_pixels_on_the_gpu(renderer, name):
     t, W, H = product_tables(z)
     dev = renderer.render(t, s, W, H)
     frame = dev.cpu().numpy()
-    png = check(name, frame, z, scene_ref, s, t.textures)
-    assert (renderer.to_rgba8(dev).cpu().numpy() == png).all()  # the kernel's 8-bit conversion = clamp, ×255, round, flip
-    ref = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures)
+    png = check(name, frame, z, scene_ref, s, t.textures, **resources(t))
+    if not np.isnan(frame).any():
+        assert (renderer.to_rgba8(dev).cpu().numpy() == png).all()  # the kernel's 8-bit conversion = clamp, ×255, round, flip
+    ref = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures,
+                          **resources(t))
     assert ((frame.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(frame) & np.isnan(ref))).all()  # NaN payloads: "both NaN"
