@@ -213,7 +213,7 @@ for _rel in ("simple/unit_capsule", "simple/unit_cone", "simple/unit_cylinder", 
     SCENEFILE_CASES[f"sweepfull_{_rel.split('/')[1]}_ub1"] = (_rel + ".json", 64, 36, _FULL, dict(ub1=True))
 # ... and the area-light scenes (the LTC tables travel in the fixture as the 8-bit textures the reference uploads);
 # lighting/arealight.json also has the blackmarble floor
-_SWEEP["lighting"] += ["bloom", "arealight"]
+_SWEEP["lighting"] += ["bloom", "arealight", "depth_of_field"]
 # (simple/unit_plane.json, the third area-light scene: SwiftShader did not finish it in 30 minutes)
 for _grp, _names in _SWEEP.items():
     for _n in _names:

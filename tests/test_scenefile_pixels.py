@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that the harness can run (56 fixtures, 39 of the reference's 52 scenefiles) — the fixture
+other scenefile of the reference that the harness can run (57 fixtures, 40 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -69,6 +69,7 @@ for _n in ("phong_total", "unit_cone", "unit_cube", "unit_cylinder", "unit_octa"
 CASES["sweepfull_reflections_basic_ub1"] = ("edge", 0.998, 0.999)
 # area lights, with the reference's own LTC tables as the 8-bit textures it uploads (lighting/arealight.json also has the
 # textured floor; simple/unit_plane.json, the third such scene, SwiftShader did not finish compiling)
+CASES["sweep_depth_of_field"] = ("edge", 0.998, 1.0)  # ten objects, one of them textured
 CASES["sweep_bloom"] = ("ltc", 0.98, 0.0)
 CASES["sweep_arealight"] = ("ltc", 0.88, 0.0)
 CASES["sweep_unit_sierpinski"] = ("fractal", 0.99, 0.995)
