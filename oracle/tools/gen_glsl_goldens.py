@@ -213,7 +213,7 @@ for _rel in ("simple/unit_capsule", "simple/unit_cone", "simple/unit_cylinder", 
     SCENEFILE_CASES[f"sweepfull_{_rel.split('/')[1]}_ub1"] = (_rel + ".json", 64, 36, _FULL, dict(ub1=True))
 # ... and the area-light scenes (the LTC tables travel in the fixture as the 8-bit textures the reference uploads);
 # lighting/arealight.json also has the blackmarble floor
-_SWEEP["lighting"] += ["bloom", "arealight", "depth_of_field"]
+_SWEEP["lighting"] += ["bloom", "arealight", "depth_of_field", "shadow_test"]  # shadow_test: two images
 # (simple/unit_plane.json, the third area-light scene: SwiftShader did not finish it in 30 minutes)
 for _grp, _names in _SWEEP.items():
     for _n in _names:
@@ -281,7 +281,6 @@ def reference_tables(rel, W, H):
                 o.color[k] = l["color"][k]
     n_objs += len(area)
     g = abi.RmGlobals(t["ka"], t["kd"], t["ks"], t["kt"], 8.0)  # power 8, juliaSeed 0, iTime 0: settings.h defaults
-    assert len(tex_files) <= 1, "the ESSL harness binds one object texture"
     return (cam, objs, n_objs, lights, len(t["lights"]), g), list(tex_files)
 
 
@@ -294,7 +293,8 @@ def scenefile_cases(only=None):
         s = abi.default_settings(**over)
         tex = None
         if tex_files:  # QImage::load + convertToFormat(RGBA8888) + mirrored() (raymarchscene.cpp:198-209), decoded here with PIL
-            tex = np.ascontiguousarray(np.asarray(Image.open(tex_files[0]).convert("RGBA"))[::-1])
+            tex = [np.ascontiguousarray(np.asarray(Image.open(f).convert("RGBA"))[::-1]) for f in tex_files]
+            tex = tex[0] if len(tex) == 1 else tex  # several: a selection chain over the units (essl_adapt E4)
         extra = {}
         if any(scene[3][i].type == abi.RM_LIGHT_AREA for i in range(scene[4])):
             # the LTC tables as the reference uploads them: 64×64 RGBA floats into a GL_RGBA (8-bit unorm) texture

@@ -103,7 +103,7 @@ def define_ub1(text):
     return new
 
 
-def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4, probe=None):
+def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4, probe=None, n_textures=1):
     """Return ESSL 3.00 source.  `defines`: {name: bool} for the #define block (frag:4-15);
     `consts`: {MAX_STEPS: n, MAX_STEPS_FRACTALS: n, NUM_REFLECTION: n, MENGER_LEVELS: n}."""
     defines = defines or {}
@@ -128,7 +128,15 @@ def adapt(src, defines=None, consts=None, max_objects=6, max_lights=4, probe=Non
     text = re.sub(r"^\s*float\s+SEA_TIME\s*=\s*([^;]+);", r"#define SEA_TIME (\1)", text, flags=re.M)
     # E4
     text = re.sub(r"texture\(customTextures\[[^\]]+\]", "texture(customTextures[0]", text)
-    text = re.sub(r"objTextures\[texLoc\]", "objTextures[0]", text)
+    if n_textures <= 1:
+        text = re.sub(r"objTextures\[texLoc\]", "objTextures[0]", text)
+    else:  # ESSL 3.00 indexes sampler arrays with constant expressions only: a selection chain over the bound units
+        def chain(m):
+            uv, expr = m.group(1), f"texture(objTextures[{n_textures - 1}], {m.group(1)})"
+            for k in range(n_textures - 2, -1, -1):
+                expr = f"((texLoc == {k}) ? texture(objTextures[{k}], {uv}) : {expr})"
+            return expr
+        text = re.sub(r"texture\(objTextures\[texLoc\],\s*([^)]+)\)", chain, text)
     # E5
     text = re.sub(r"uniform\s+RayMarchObject\s+objects\[\d+\]", f"uniform RayMarchObject objects[{max_objects}]", text)
     text = re.sub(r"uniform\s+LightSource\s+lights\[\d+\]", f"uniform LightSource lights[{max_lights}]", text)

@@ -19,10 +19,10 @@ def ctx():
     return _CTX
 
 
-def build_program(defines, consts, max_objects=6, max_lights=4, spec=None, probe=None, ub10=False, ub1=False):
+def build_program(defines, consts, max_objects=6, max_lights=4, spec=None, probe=None, ub10=False, ub1=False, n_textures=1):
     c = ctx()
     vert = open(os.path.join(REF, "raymarch.vert")).read().replace("#version 330 core", "#version 300 es\nprecision highp float;")
-    frag = essl_adapt.adapt(open(os.path.join(REF, "raymarch.frag")).read(), defines, consts, max_objects, max_lights, probe)
+    frag = essl_adapt.adapt(open(os.path.join(REF, "raymarch.frag")).read(), defines, consts, max_objects, max_lights, probe, n_textures)
     if ub10:
         frag = essl_adapt.define_ub10(frag)
     if ub1:
@@ -203,11 +203,17 @@ def render(scene, settings, W, H, texture=None, noise=None, skybox=None, ltc=Non
         false_u.append("isTwoD")
     spec = {"false_uniforms": false_u, "present_types": sorted({objs[i].type for i in range(no)}),
             "has_area_light": any(lights[i].type == abi.RM_LIGHT_AREA for i in range(nl))}
-    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec, ub10=ub10, ub1=ub1)
+    textures = texture if isinstance(texture, (list, tuple)) else None
+    prog = build_program(defines, consts, max_objects=max(no, 1), max_lights=max(nl, 1), spec=spec, ub10=ub10, ub1=ub1,
+                         n_textures=len(textures) if textures else 1)
     c = ctx()
     c.target(W, H, 2)
     set_uniforms(prog, cam, objs, no, lights, nl, g, settings, W, H)
-    if texture is not None:
+    if textures:  # several object textures: unit k = texLoc k, as configureShapesUniforms binds them (realtimerender.cpp:795-803)
+        for k, a in enumerate(textures):
+            _tex2d(k, a, 0x2901)
+            c.gl.glUniform1i(c.gl.glGetUniformLocation(prog, f"objTextures[{k}]".encode()), k)
+    elif texture is not None:
         bind_object_texture(texture)
     if noise is not None:
         bind_noise(noise)

@@ -24,7 +24,7 @@ def main():
     dur = (t1 - t0) / 100.0  # µs
     lines = [f"4K bulb frame, stamped build: {len(sp)} waves, kernel span {dur:.0f} us, shader clock {mhz:.0f} MHz",
              f"wave life: mean {(sp[:, 1] - sp[:, 0]).mean() / 100:.1f} us, median {np.median(sp[:, 1] - sp[:, 0]) / 100:.1f} us, "
-             f"max {(sp[:, 1] - sp[:, 0]).max() / 100:.0f} us; sum of lives / span = {(sp[:, 1] - sp[:, 0]).sum() / (t1 - t0):.0f} waves resident on average (4096 slots)",
+             f"max {(sp[:, 1] - sp[:, 0]).max() / 100:.0f} us; sum of lives / span = {(sp[:, 1] - sp[:, 0]).sum() / (t1 - t0):.0f} waves resident on average (5120 slots at 5 waves/SIMD)",
              "", "| time (% of span) | resident waves |", "|---|---|"]
     edges = np.linspace(t0, t1, 21)
     for a, b in zip(edges[:-1], edges[1:]):
@@ -33,7 +33,7 @@ def main():
     last_start = sp[:, 0].max()
     lines.append("")
     lines.append(f"last wave starts at {100 * (last_start - t0) / (t1 - t0):.1f} % of the span; "
-                 f"time with < 2048 resident waves: {100 * sum(1 for m in np.linspace(t0, t1, 400) if ((sp[:, 0] <= m) & (sp[:, 1] > m)).sum() < 2048) / 400:.1f} % of the span")
+                 f"time with < 2560 resident waves: {100 * sum(1 for m in np.linspace(t0, t1, 400) if ((sp[:, 0] <= m) & (sp[:, 1] > m)).sum() < 2560) / 400:.1f} % of the span")
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 1:

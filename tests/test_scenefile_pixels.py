@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that the harness can run (57 fixtures, 40 of the reference's 52 scenefiles) — the fixture
+other scenefile of the reference that the harness can run (58 fixtures, 41 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -41,8 +41,8 @@ CASES = {
     "c4_volumetric_terrain_cloud_sky_ub10": ("env", 0.975, 0.99),
 }
 # The sweep (64×36, reference defaults; reflection on for the three reflection scenes): every other scenefile the reference
-# ships that needs no LTC table, no sky-box, at most ONE image (the ESSL harness binds one object texture) of at most a
-# few hundred kB, and fewer uniforms than SwiftShader links (recursive_sphere_3.json does not).  Thirteen of them agree with the
+# ships that needs no sky-box, images of at most a few hundred kB, and fewer uniforms than SwiftShader links
+# (recursive_sphere_3.json does not).  Thirteen of them agree with the
 # reference shader to 1e-3 on EVERY pixel; "edge" scenes on all but 1-3 silhouette / reflection-edge pixels of 2304 (where
 # the arbiter sides with the oracle as often as with SwiftShader).  unit_mandelbrot.json marches a 2-D escape-time field
 # as if it were a distance: the three evaluations (binary32 oracle, SwiftShader, binary64) disagree with EACH OTHER on a
@@ -70,6 +70,7 @@ CASES["sweepfull_reflections_basic_ub1"] = ("edge", 0.998, 0.999)
 # area lights, with the reference's own LTC tables as the 8-bit textures it uploads (lighting/arealight.json also has the
 # textured floor; simple/unit_plane.json, the third such scene, SwiftShader did not finish compiling)
 CASES["sweep_depth_of_field"] = ("edge", 0.998, 1.0)  # ten objects, one of them textured
+CASES["sweep_shadow_test"] = ("smooth", 1.0, 1.0)      # two images on two objects: texture units 0 and 1
 CASES["sweep_bloom"] = ("ltc", 0.98, 0.0)
 CASES["sweep_arealight"] = ("ltc", 0.88, 0.0)
 CASES["sweep_unit_sierpinski"] = ("fractal", 0.99, 0.995)
