@@ -124,6 +124,7 @@ def main():
     distributed = world > 1 or args.force_dist
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")  # only missing in the one-process rehearsal (--force-dist without a launcher)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     r = Renderer(local_rank)
