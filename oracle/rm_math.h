@@ -148,14 +148,22 @@ static inline float rm__atan_p(float s) {
   p = rm_fma(s, p, -3.333315253e-01f);
   return p;
 }
-/* GLSL atan(y,x).  0/0 → 0; inf/inf and NaN ratios are treated as t = 1.  x is "negative" iff
+/* x / y as x · RN(1/y): the correctly rounded reciprocal, then one multiplication (error <= 1 ulp instead of 1/2; GLSL allows
+ * 2.5).  Used where a quotient sits inside the Mandelbulb iteration (acos argument, atan ratio) and its distance estimate:
+ * on the GPU RN(1/y) is three instructions (v_rcp_f32 + one Newton step, exact over the whole normal range — checked for
+ * every input), the IEEE quotient ten.  Same special values as x / y except where 1/y over- or underflows (|y| < 2^-128
+ * or > 2^126), which none of the three sites can reach with a meaningful value. */
+static inline float rm_divr(float x, float y) { return x * (1.0f / y); }
+
+/* GLSL atan(y,x).  0/0 → 0; inf/inf and NaN ratios are treated as t = 1, as is a ratio that overflows (denormal x and y).  x is "negative" iff
  * x < 0 (so −0 counts as +0); the result carries the sign bit of y. */
 static inline float rm_atan2(float y, float x) {
   float ax = fabsf(x), ay = fabsf(y);
   float mx = (ax < ay) ? ay : ax;
   float mn = (ax < ay) ? ax : ay;
-  float t = mn / mx;
-  if (!(t == t)) t = (mx == 0.0f) ? 0.0f : 1.0f;
+  float t = rm_divr(mn, mx);
+  if (!(t <= 1.0f)) t = 1.0f; /* NaN, +inf */
+  if (mx == 0.0f) t = 0.0f;
   float s = t * t;
   float a = rm_fma(t * s, rm__atan_p(s), t);
   if (ay > ax) a = RM_PIO2 - a;

@@ -268,7 +268,7 @@ static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
       if (m > 2.0f) break;
     }
     *resColor = V4(m, trap.y, trap.z, trap.w);
-    return ((0.25f * rm_log(m)) * rm_sqrt(m)) / dz;
+    return rm_divr((0.25f * rm_log(m)) * rm_sqrt(m), dz);
   }
   int nTrace = 0;
   for (int i = 0; i < c->s.fractalIters; i++) {
@@ -278,7 +278,7 @@ static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
     dz = rm_fma(power * rm_pow(m, pexp), dz, 1.0f);
     /* frag:789-793 */
     float r = len3(w);
-    float b = power * rm_acos(w.y / r);
+    float b = power * rm_acos(rm_divr(w.y, r));
     float a = power * rm_atan2(w.x, w.z);
     float pr = rm_pow(r, power);
     float sb = rm_sin(b), cb = rm_cos(b), sa = rm_sin(a), ca = rm_cos(a);
@@ -293,7 +293,7 @@ static float sdMandelBulb(Ctx *c, v3 pos, v4 *resColor) {
   RMO_TRACE_EVAL(c, nTrace);
   *resColor = V4(m, trap.y, trap.z, trap.w);
   /* frag:802 */
-  return ((0.25f * rm_log(m)) * rm_sqrt(m)) / dz;
+  return rm_divr((0.25f * rm_log(m)) * rm_sqrt(m), dz);
 }
 
 /* frag:808-827 */

@@ -60,6 +60,7 @@ static inline double rm_cos(double x) { return cos(x); }
 static inline double rm_acos(double x) { return (fabs(x) < 1.0) ? acos(x) : ((x > 0.0) ? 0.0 : RM_PI); }
 static inline double rm_asin(double x) { return (fabs(x) < 1.0) ? asin(x) : ((x > 0.0) ? RM_PIO2 : -RM_PIO2); }
 static inline double rm_atan2(double y, double x) { return atan2(y, x); }
+static inline double rm_divr(double x, double y) { return x / y; }
 static inline double rm_log2(double x) { return (x > 0.0) ? log2(x) : -INFINITY; }
 static inline double rm_exp2(double x) { return exp2(x); }
 static inline double rm_pow(double x, double y) { return pow(x, y); }

@@ -105,7 +105,7 @@ RM_DEV void deStart(BulbDE &s, const BulbParams &k, V3 p) {
 RM_DEV bool deStep(BulbDE &s, const BulbParams &k) {
   s.dz = fma(k.power * pow_(s.m, k.pexp), s.dz, 1.0f);
   float r = sqrt_fast_(s.m);
-  float b = k.power * acos_(s.w.y / r);
+  float b = k.power * acos_(divr_(s.w.y, r));
   float a = k.power * atan2_(s.w.x, s.w.z);
   float pr = pow_(r, k.power);
   float sb_, cb_, sa_, ca_;
@@ -121,7 +121,7 @@ RM_DEV bool deStep(BulbDE &s, const BulbParams &k) {
 }
 // frag:802 then sdScene's scale and nearest-object select (frag:1419-1423) for a one-object table.
 RM_DEV float deDistance(const BulbDE &s, const BulbParams &k) {
-  float d = ((0.25f * log_(s.m)) * sqrt_fast_(s.m)) / s.dz;
+  float d = divr_((0.25f * log_(s.m)) * sqrt_fast_(s.m), s.dz);
   float cur = d * k.scale;
   return (cur < 1000000.0f) ? cur : 1000000.0f;
 }

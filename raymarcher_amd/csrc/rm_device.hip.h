@@ -32,7 +32,7 @@ RM_DEV float dot2(float ax, float ay, float bx, float by) { return fma(ay, by, a
 RM_DEV float dot(V3 a, V3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
 RM_DEV float len2(float x, float y) { return sqrt_(dot2(x, y, x, y)); }
 RM_DEV float len(V3 a) { return sqrt_(dot(a, a)); }
-RM_DEV V3 normalize(V3 a) { float inv = 1.0f / len(a); return scale(a, inv); }
+RM_DEV V3 normalize(V3 a) { float inv = rcp_(len(a)); return scale(a, inv); }
 RM_DEV V3 reflect(V3 I, V3 N) { float k = 2.0f * dot(N, I); return madd(N, -k, I); }
 RM_DEV V3 refract(V3 I, V3 N, float eta) {
   float d = dot(N, I);
@@ -206,7 +206,7 @@ RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &c
       // m^3.5 = m³·√m — no acos/atan/sin/cos/pow in the loop
       dz = fma(8.0f * (((m * m) * m) * r), dz, 1.0f);
       float rho = sqrt_fast_(dot2(w.x, w.z, w.x, w.z));
-      float inv = 1.0f / rho;
+      float inv = rcp_(rho);
       float cz = (rho == 0.0f) ? 1.0f : w.z * inv, sx = (rho == 0.0f) ? 0.0f : w.x * inv;
       float re = w.y, im = rho;
 #pragma unroll
@@ -230,7 +230,7 @@ RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &c
         pr = powApply(r, power, planPower);
       }
       dz = fma(power * pm, dz, 1.0f);       // frag:787
-      float b = power * acos_(w.y / r);     // frag:790
+      float b = power * acos_(divr_(w.y, r));  // frag:790
       float a = power * atan2_(w.x, w.z);   // frag:791
       float sb_, cb_, sa_, ca_;
       if (angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
@@ -245,7 +245,7 @@ RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &c
     if (m > 2.0f) break;  // frag:798 (FRACTALS_BAILOUT)
   }
   resColor = v4(m, trap.y, trap.z, trap.w);
-  return ((0.25f * log_(m)) * sqrt_fast_(m)) / dz;  // frag:802
+  return divr_((0.25f * log_(m)) * sqrt_fast_(m), dz);  // frag:802
 }
 template <int COUNT, bool TRAPMIN, bool TRAP>
 RM_DEV float sdMandelBulb(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
@@ -554,7 +554,7 @@ RM_DEV float calcAO(const SceneBlock *sb, V3 pos, V3 nor, Counters &cnt) {
 }
 // frag:445-447
 RM_DEV float attenuation(float d, float f0, float f1, float f2) {
-  return min_(1.0f / fma(d * d, f2, fma(d, f1, f0)), 1.0f);
+  return min_(rcp_(fma(d * d, f2, fma(d, f1, f0))), 1.0f);
 }
 // frag:439-442, 450-461
 RM_DEV float angularFalloff(const RmLight &li, V3 L) {
@@ -629,7 +629,7 @@ RM_DEV V3 integrateEdgeVec(V3 v1, V3 v2) {  // frag:349-361
   float a = fma(fma(0.0145206f, y, 0.4965155f), y, 0.8543985f);
   float b = fma(4.1616724f + y, y, 3.4175940f);
   float v = a / b;
-  float ts = (x > 0.0f) ? v : fma(0.5f, 1.0f / sqrt_(max_(fma(-x, x, 1.0f), 1e-7f)), -v);
+  float ts = (x > 0.0f) ? v : fma(0.5f, rcp_(sqrt_(max_(fma(-x, x, 1.0f), 1e-7f))), -v);
   return scale(cross(v1, v2), ts);
 }
 RM_DEV float ltcEvaluate(const SceneBlock *sb, V3 N, V3 V, V3 P, const M3 &MinvIn, const RmLight &li) {  // frag:368-424

@@ -972,6 +972,37 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
     for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
   return rc;
 }
+// rcp_() against the IEEE quotient for EVERY binary32 input: out[0] = inputs where rcp_(y) != 1.0f / y, out[1] = inputs of
+// the fast range 2^-126 <= |y| < 2^126 where the bare v_rcp_f32 + Newton form differs (both must be 0; NaN = NaN).
+__global__ void check_rcp_kernel(unsigned long long *out) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  unsigned long long bad = 0, badFast = 0;
+  for (uint64_t u = tid; u < (1ull << 32); u += stride) {
+    const float y = u2f((uint32_t)u), ref = 1.0f / y, got = rcp_(y);
+    if (f2u(got) != f2u(ref) && !(got != got && ref != ref)) bad++;
+    const float ay = fabs_(y);
+    if (ay >= 1.17549435e-38f && ay < 8.50705917e37f) {
+      const float r = __builtin_amdgcn_rcpf(y), f = rm::fma(rm::fma(-y, r, 1.0f), r, r);
+      if (f2u(f) != f2u(ref)) badFast++;
+    }
+  }
+  if (bad) atomicAdd(&out[0], bad);
+  if (badFast) atomicAdd(&out[1], badFast);
+}
+int rm_debug_check_rcp(unsigned long long *mismatches2) {
+  if (!mismatches2) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
+  unsigned long long *d = nullptr;
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d), 2 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) {
+    check_rcp_kernel<<<4096, 256>>>(d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(mismatches2, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_error(std::string("rm_debug_check_rcp: ") + hipGetErrorString(e)); return RM_ERR_DEVICE; }
+  return RM_OK;
+}
 int rm_debug_ray_planes(const RmCamera *cam, float *out48) {
   if (!cam || !out48) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
   static SceneBlock blk;  // host-only scratch; the planes are a pure function of the camera

@@ -34,6 +34,18 @@ RM_DEV float smoothstep_(float e0, float e1, float x) {
   return (t * t) * fma(-2.0f, t, 3.0f);
 }
 RM_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
+// 1.0f / y, bit for bit.  v_rcp_f32 followed by ONE Newton step is the correctly rounded reciprocal of every y with
+// 2^-126 <= |y| < 2^126 — all 2·253·2^23 of them, checked exhaustively on the device against the IEEE quotient
+// (scripts/microbench/rcp_exhaustive.hip; rm_debug_check_rcp in the test suite) — so the ten-instruction IEEE expansion runs
+// only when some lane of the wave holds zero, a denormal, |y| >= 2^126, an infinity or a NaN (wave-uniform branch).
+RM_DEV float rcp_(float y) {
+  const float ay = fabs_(y);
+  if (__builtin_expect(__ballot(!(ay >= 1.17549435e-38f) || !(ay < 8.50705917e37f)) != 0, 0)) return 1.0f / y;
+  const float r = __builtin_amdgcn_rcpf(y);
+  return fma(fma(-y, r, 1.0f), r, r);
+}
+// x / y of the contract's three hot quotients (oracle rm_divr): x · RN(1/y).
+RM_DEV float divr_(float x, float y) { return x * rcp_(y); }
 // Correctly rounded sqrt for x == ±0, x >= 2^-96, +inf, NaN and negative x: the refinement hipcc itself emits for
 // sqrtf (v_sqrt_f32, then pick among s−1ulp, s, s+1ulp by the sign of the fma residuals) without the 2^32
 // pre-scaling that only inputs below 2^-96 need.  Correct rounding is unique, so the bits equal sqrt_().
@@ -173,9 +185,9 @@ RM_DEV float atan2_(float y, float x) {
   bool sw = ax < ay;
   float mx = sw ? ay : ax;
   float mn = sw ? ax : ay;
-  float t = mn / mx;
-  // contract: a NaN quotient (0/0, inf/inf, NaN operand) is 0 if mx == 0 and 1 otherwise.  mn <= mx, so a non-NaN
-  // quotient is <= 1 and v_min_f32(t, 1) — which ignores a NaN operand — is t itself, or 1 for NaN.
+  float t = divr_(mn, mx);
+  // contract: a NaN quotient (0·inf, inf·0, NaN operand) or one that overflows (denormal operands) is 1, and 0 if mx == 0.
+  // mn <= mx, so any other quotient is <= 1 and v_min_f32(t, 1) — which ignores a NaN operand — is t itself.
   t = hwmin1_(t);
   t = (mx == 0.0f) ? 0.0f : t;
   float s = t * t;
@@ -250,7 +262,7 @@ RM_DEV float powApply(float x, float y, const PowPlan &pl) {
       if (e > 1) b = b * b;
     }
     if (pl.half) p = p * sqrt_fast_(x);
-    return pl.neg ? 1.0f / p : p;
+    return pl.neg ? rcp_(p) : p;
   }
   return exp2_(y * log2_(x));
 }

@@ -101,6 +101,16 @@ def test_math_contract_bit_exact(renderer, fn):
     assert not bad.any(), f"fn {fn}: {bad.sum()} mismatches, e.g. x={x[bad][:4]}, gpu={got[bad][:4]}, cpu={ref[bad][:4]}"
 
 
+def test_reciprocal_is_the_ieee_quotient_for_every_input(renderer):
+    """rcp_() — v_rcp_f32 + one Newton step wherever the whole wave is inside 2^-126 <= |y| < 2^126 — against 1.0f / y for all
+    2^32 inputs, on the device (rm_debug_check_rcp): the function, and the bare fast form over its whole range."""
+    import ctypes as C
+    from raymarcher_amd import lib
+    out = (C.c_ulonglong * 2)()
+    assert lib().rm_debug_check_rcp(out) == 0
+    assert (out[0], out[1]) == (0, 0)
+
+
 def test_pnoise_bit_exact(renderer):
     import torch
     rng = np.random.default_rng(7)
