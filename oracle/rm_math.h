@@ -44,9 +44,16 @@ static inline float rm_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? 
 static inline float rm_step(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }
 /* GLSL mix(x,y,a) = x·(1−a) + y·a, the second product fused. */
 static inline float rm_mix(float x, float y, float a) { return rm_fma(y, a, x * (1.0f - a)); }
+/* x / y as x · RN(1/y): the correctly rounded reciprocal, then one multiplication (error <= 1 ulp instead of 1/2; GLSL allows
+ * 2.5).  Used for the quotients on hot paths — inside the Mandelbulb iteration (acos argument, atan ratio) and its distance estimate,
+ * smoothstep, the soft-shadow and terrain-shadow penumbra, the cone's projection, the terrain / cloud scalings by constants,
+ * the cube-map projection: on the GPU RN(1/y) is three instructions (v_rcp_f32 +
+ * one Newton step, exact over the whole normal range — checked for every input) or a compile-time constant, the IEEE
+ * quotient ten.  Same special values as x / y except where 1/y over- or underflows (|y| < 2^-128 or > 2^126). */
+static inline float rm_divr(float x, float y) { return x * (1.0f / y); }
 /* GLSL smoothstep: t = clamp((x−e0)/(e1−e0),0,1); t·t·(3−2t). */
 static inline float rm_smoothstep(float e0, float e1, float x) {
-  float t = rm_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+  float t = rm_clamp(rm_divr(x - e0, e1 - e0), 0.0f, 1.0f);
   return (t * t) * rm_fma(-2.0f, t, 3.0f);
 }
 static inline float rm_sqrt(float x) { return sqrtf(x); }
@@ -148,12 +155,6 @@ static inline float rm__atan_p(float s) {
   p = rm_fma(s, p, -3.333315253e-01f);
   return p;
 }
-/* x / y as x · RN(1/y): the correctly rounded reciprocal, then one multiplication (error <= 1 ulp instead of 1/2; GLSL allows
- * 2.5).  Used where a quotient sits inside the Mandelbulb iteration (acos argument, atan ratio) and its distance estimate:
- * on the GPU RN(1/y) is three instructions (v_rcp_f32 + one Newton step, exact over the whole normal range — checked for
- * every input), the IEEE quotient ten.  Same special values as x / y except where 1/y over- or underflows (|y| < 2^-128
- * or > 2^126), which none of the three sites can reach with a meaningful value. */
-static inline float rm_divr(float x, float y) { return x * (1.0f / y); }
 
 /* GLSL atan(y,x).  0/0 → 0; inf/inf and NaN ratios are treated as t = 1, as is a ratio that overflows (denormal x and y).  x is "negative" iff
  * x < 0 (so −0 counts as +0); the result carries the sign bit of y. */

@@ -165,7 +165,7 @@ static float sdSphere(v3 p, float r) { return len3(p) - r; }
 static float sdCone(v3 p, float r, float h) {
   float pox = len2(p.x, p.z) - r, poy = p.y + h;
   float ex = -r, ey = 2.0f * h;
-  float t = rm_clamp(dot2(pox, poy, ex, ey) / dot2(ex, ey, ex, ey), 0.0f, 1.0f);
+  float t = rm_clamp(rm_divr(dot2(pox, poy, ex, ey), dot2(ex, ey, ex, ey)), 0.0f, 1.0f);
   float qx = rm_fma(-ex, t, pox), qy = rm_fma(-ey, t, poy);
   float d = len2(qx, qy);
   if (rm_max(qx, qy) > 0.0f) return d;
@@ -513,7 +513,7 @@ static RayMarchRes softshadow(Ctx *c, v3 ro, v3 rd, float mint, float maxt, floa
   for (int i = 0; i < c->s.maxSteps; i++) {
     closest = sdScene(c, v3_madd(rd, rayDepth, ro));
     if (rm_abs(closest.minD) < SURFACE_DIST || rayDepth > maxt) break;
-    res = rm_min(res, (k * closest.minD) / rayDepth);
+    res = rm_min(res, rm_divr(k * closest.minD, rayDepth));
     rayDepth = rayDepth + rm_abs(closest.minD);
   }
   RayMarchRes r;
@@ -665,7 +665,8 @@ static v3 sampleCube(const RmTexture *faces, v3 r) {
   if (ax >= ay && ax >= az) { ma = ax; if (r.x >= 0.0f) { face = 0; sc = -r.z; tc = -r.y; } else { face = 1; sc = r.z; tc = -r.y; } }
   else if (ay >= az)        { ma = ay; if (r.y >= 0.0f) { face = 2; sc = r.x; tc = r.z; } else { face = 3; sc = r.x; tc = -r.z; } }
   else                      { ma = az; if (r.z >= 0.0f) { face = 4; sc = r.x; tc = -r.y; } else { face = 5; sc = -r.x; tc = -r.y; } }
-  v4 c = sampleRGBA8(&faces[face], rm_fma(sc / ma, 0.5f, 0.5f), rm_fma(tc / ma, 0.5f, 0.5f), 1);
+  const float ima = 1.0f / ma; /* rm_divr */
+  v4 c = sampleRGBA8(&faces[face], rm_fma(sc * ima, 0.5f, 0.5f), rm_fma(tc * ima, 0.5f, 0.5f), 1);
   return V3(c.x, c.y, c.z);
 }
 /* frag:1746-1781 */
@@ -897,7 +898,7 @@ static v4 fbmd_8(v3 x) {
 }
 /* frag:737-746 */
 static v2 sdTerrain(float px, float pz) {
-  float e = fbm_9(px / 2000.0f + 1.0f, pz / 2000.0f + -2.0f);
+  float e = fbm_9(rm_divr(px, 2000.0f) + 1.0f, rm_divr(pz, 2000.0f) + -2.0f);
   float a = 1.0f - rm_smoothstep(0.12f, 0.13f, rm_abs(e + 0.12f));
   e = rm_fma(600.0f, e, 600.0f);
   e = rm_fma(90.0f, rm_smoothstep(552.0f, 594.0f, e), e);
@@ -950,7 +951,7 @@ static v4 cloudsMap(const Ctx *c, v3 pos, float *nnd) {
   d = rm_fma(400.0f * n.x, rm_fma(0.3f, gy, 0.7f), d);
   *nnd = -d;
   if (d > 0.0f) return V4(-d, 0.0f, 0.0f, 0.0f);
-  d = rm_min(-d / 100.0f, 0.25f);
+  d = rm_min(rm_divr(-d, 100.0f), 0.25f);
   return V4(d, 0.0f, gy, 0.0f);
 }
 /* frag:1976-2026 */
@@ -972,7 +973,7 @@ static int cloudMarch(const Ctx *c, int steps, v3 ro, v3 rd, float minT, float m
       sha = sha * 1.5f;
       v3 nor = normalize3(V3(denGra.y, denGra.z, denGra.w));
       float dif = rm_clamp(rm_fma(0.6f, dot3(nor, sunDir), 0.4f), 0.0f, 1.0f) * sha;
-      float occ = rm_fma(0.1f, 1.0f - den, rm_fma(0.7f, rm_max(1.0f - kk / 200.0f, 0.0f), 0.2f));
+      float occ = rm_fma(0.1f, 1.0f - den, rm_fma(0.7f, rm_max(1.0f - rm_divr(kk, 200.0f), 0.0f), 0.2f));
       float up = rm_fma(0.5f, nor.y, 0.5f), dn = rm_fma(-0.5f, nor.y, 0.5f);
       v3 lin = V3(0.0f, 0.0f, 0.0f);
       lin = V3(lin.x + ((0.70f * 1.0f) * up) * occ, lin.y + ((0.80f * 1.0f) * up) * occ, lin.z + ((1.00f * 1.0f) * up) * occ);
@@ -1049,7 +1050,7 @@ static float terrainShadow(v3 ro, v3 rd, float mint) {
     v3 pos = v3_madd(rd, t, ro);
     v2 env = sdTerrain(pos.x, pos.z);
     float hei = pos.y - env.x;
-    res = rm_min(res, (32.0f * hei) / t);
+    res = rm_min(res, rm_divr(32.0f * hei, t));
     if (res < 0.0001f || pos.y > 700.0f) break;
     t = t + rm_clamp(hei, rm_fma(t, 0.1f, 2.0f), 100.0f);
   }
@@ -1074,7 +1075,7 @@ static int terrainRender(const Ctx *c, v3 ro, v3 rd, float maxT, v3 bgCol, v3 *c
   col = mix3(col, V3(0.1f * 0.2f, 0.1f * 0.2f, 0.0f * 0.2f), rm_smoothstep(0.7f, 0.9f, nor.y));
   float dif = rm_clamp(dot3(nor, sunDir), 0.0f, 1.0f) * sha1;
   float bac = rm_clamp(dot3(normalize3(V3(-sunDir.x, 0.0f, -sunDir.z)), nor), 0.0f, 1.0f);
-  float foc = rm_clamp((p.y / 2.0f - 180.0f) / 130.0f, 0.0f, 1.0f);
+  float foc = rm_clamp(rm_divr(p.y / 2.0f - 180.0f, 130.0f), 0.0f, 1.0f);
   float dom = rm_clamp(rm_fma(0.5f, nor.y, 0.5f), 0.0f, 1.0f);
   v3 lin = mix3(V3(0.1f * 0.1f, 0.1f * 0.2f, 0.1f * 0.1f), v3_scale(sunColor, 3.0f), dom);
   lin = V3((0.2f * lin.x) * foc, (0.2f * lin.y) * foc, (0.2f * lin.z) * foc);
@@ -1161,7 +1162,7 @@ static float seaMapHeight(const Ctx *c, v3 ro, v3 rd, v3 *p, float maxT) { /* fr
   float hm = seaMap(c, v3_madd(rd, tm, ro), 3);
   float tmid = 0.0f;
   for (int i = 0; i < 8; i++) {
-    float f = hm / (hm - hx);
+    float f = rm_divr(hm, hm - hx);
     tmid = rm_mix(tm, tx, f);
     *p = v3_madd(rd, tmid, ro);
     if (tmid > maxT) return -1.0f;

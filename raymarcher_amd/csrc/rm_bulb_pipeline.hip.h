@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void bulb_shadow_kernel(const SceneBlock *__re
         const bool hit = fabs_(d) < kSurfaceDist;
         bool end = hit || t > maxT;
         if (!end) {
-          pen = min_(pen, (8.0f * d) / t);
+          pen = min_(pen, divr_(8.0f * d, t));
           t = t + fabs_(d);
           steps++;
           if (steps >= maxSteps) end = true;
@@ -646,7 +646,7 @@ RM_DEV int shadowBudget(const SceneBlock *sb, V3 so, V3 L, float maxT, int maxSt
     const SceneMin c = sdScene<true, false>(sb, madd(L, t, so), cnt);
     hit = fabs_(c.d) < kSurfaceDist;
     if (hit || t > maxT) return 1;
-    pen = min_(pen, (8.0f * c.d) / t);
+    pen = min_(pen, divr_(8.0f * c.d, t));
     t = t + fabs_(c.d);
     steps++;
     if (++local >= budget) return 0;

@@ -110,7 +110,7 @@ RM_DEV float sdBox(V3 p, float bx, float by, float bz) {
 RM_DEV float sdCone(V3 p, float r, float h) {
   float pox = len2(p.x, p.z) - r, poy = p.y + h;
   float ex = -r, ey = 2.0f * h;
-  float t = clamp_(dot2(pox, poy, ex, ey) / dot2(ex, ey, ex, ey), 0.0f, 1.0f);
+  float t = clamp_(RM_DIVR_CONST(dot2(pox, poy, ex, ey), dot2(ex, ey, ex, ey)), 0.0f, 1.0f);
   float qx = fma(-ex, t, pox), qy = fma(-ey, t, poy);
   float d = len2(qx, qy);
   return (max_(qx, qy) > 0.0f) ? d : -min_(d, poy);
@@ -459,7 +459,7 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
     c = sdScene<BULB, COUNT, !SHADOW>(sb, madd(rd, depth, ro), cnt);
     if (fabs_(c.d) < kSurfaceDist || depth > end) break;
     if (SHADOW) {
-      if (soft) pen = min_(pen, (8.0f * c.d) / depth);
+      if (soft) pen = min_(pen, divr_(8.0f * c.d, depth));
       depth = depth + fabs_(c.d);
     } else {
       depth = fma(c.d, side, depth);
@@ -916,7 +916,7 @@ RM_DEV void primaryRay(const SceneBlock *sb, int px, int py, int W, int H, V3 &r
     nc[k] = fma(q.J, p2n, fma(q.I, p1n, p0n));
     fc4[k] = fma(q.J, p2f, fma(q.I, p1f, p0f));
   }
-  ro = v3(nc[0] / nc[3], nc[1] / nc[3], nc[2] / nc[3]);          // frag:2388
+  ro = v3(nc[0] / nc[3], nc[1] / nc[3], nc[2] / nc[3]);          // frag:2388 (IEEE: once per pixel, and every bit of rd counts, §2.3)
   V3 fc = v3(fc4[0] / fc4[3], fc4[1] / fc4[3], fc4[2] / fc4[3]);  // frag:2389
   rd = normalize(sub(fc, ro));                                    // frag:2392
 }

@@ -106,7 +106,7 @@ RM_DEV V4 fbmd_8(V3 x) {  // frag:647-667
   return v4(a, d.x, d.y, d.z);
 }
 RM_DEV void sdTerrain(float px, float pz, float &hgt, float &slope) {  // frag:737-746
-  float e = fbm_9(px / 2000.0f + 1.0f, pz / 2000.0f + -2.0f);
+  float e = fbm_9(RM_DIVR_CONST(px, 2000.0f) + 1.0f, RM_DIVR_CONST(pz, 2000.0f) + -2.0f);
   slope = 1.0f - smoothstep_(0.12f, 0.13f, fabs_(e + 0.12f));
   e = fma(600.0f, e, 600.0f);
   hgt = fma(90.0f, smoothstep_(552.0f, 594.0f, e), e);
@@ -151,7 +151,7 @@ RM_DEV void cloudsMap(float iTime, V3 pos, float &den, float &gy, float &nnd) {
   V4 n = cloudsFbm(iTime, pos);
   d = fma(400.0f * n.x, fma(0.3f, gy, 0.7f), d);
   nnd = -d;
-  den = (d > 0.0f) ? -d : min_(-d / 100.0f, 0.25f);
+  den = (d > 0.0f) ? -d : min_(RM_DIVR_CONST(-d, 100.0f), 0.25f);
   gy = (d > 0.0f) ? 0.0f : gy;
 }
 RM_DEV bool cloudMarch(float iTime, int steps, V3 ro, V3 rd, float minT, float maxT, V4 &sum) {  // frag:1976-2026
@@ -172,7 +172,7 @@ RM_DEV bool cloudMarch(float iTime, int steps, V3 ro, V3 rd, float minT, float m
       sha = sha * 1.5f;
       V3 nor = normalize(v3(0.0f, gy, 0.0f));
       float dif = clamp_(fma(0.6f, dot(nor, sunDir), 0.4f), 0.0f, 1.0f) * sha;
-      float occ = fma(0.1f, 1.0f - den, fma(0.7f, max_(1.0f - kk / 200.0f, 0.0f), 0.2f));
+      float occ = fma(0.1f, 1.0f - den, fma(0.7f, max_(1.0f - RM_DIVR_CONST(kk, 200.0f), 0.0f), 0.2f));
       float up = fma(0.5f, nor.y, 0.5f), dn = fma(-0.5f, nor.y, 0.5f);
       V3 lin = v3(0.0f, 0.0f, 0.0f);
       lin = v3(lin.x + ((0.70f * 1.0f) * up) * occ, lin.y + ((0.80f * 1.0f) * up) * occ, lin.z + ((1.00f * 1.0f) * up) * occ);
@@ -248,7 +248,7 @@ RM_DEV float terrainShadow(V3 ro, V3 rd, float mint) {  // frag:2113-2125
   for (int i = 0; i < 32; i++) {
     V3 pos = madd(rd, t, ro);
     float hei = pos.y - terrainHeight(pos.x, pos.z);
-    res = min_(res, (32.0f * hei) / t);
+    res = min_(res, divr_(32.0f * hei, t));
     if (res < 0.0001f || pos.y > 700.0f) break;
     t = t + clamp_(hei, fma(t, 0.1f, 2.0f), 100.0f);
   }
@@ -272,7 +272,7 @@ RM_DEV bool terrainRender(float iTime, V3 ro, V3 rd, float maxT, V3 bg, V3 &colO
   col = mix(col, v3(0.1f * 0.2f, 0.1f * 0.2f, 0.0f * 0.2f), smoothstep_(0.7f, 0.9f, nor.y));
   float dif = clamp_(dot(nor, sunDir), 0.0f, 1.0f) * sha1;
   float bac = clamp_(dot(normalize(v3(-sunDir.x, 0.0f, -sunDir.z)), nor), 0.0f, 1.0f);
-  float foc = clamp_((p.y / 2.0f - 180.0f) / 130.0f, 0.0f, 1.0f);
+  float foc = clamp_(RM_DIVR_CONST(p.y / 2.0f - 180.0f, 130.0f), 0.0f, 1.0f);
   float dom = clamp_(fma(0.5f, nor.y, 0.5f), 0.0f, 1.0f);
   V3 lin = mix(v3(0.1f * 0.1f, 0.1f * 0.2f, 0.1f * 0.1f), scale(sunColor, 3.0f), dom);
   lin = v3((0.2f * lin.x) * foc, (0.2f * lin.y) * foc, (0.2f * lin.z) * foc);
@@ -355,7 +355,7 @@ RM_DEV float seaMapHeight(float iTime, V3 ro, V3 rd, V3 &p, float maxT) {  // fr
   float hm = seaMap(iTime, madd(rd, tm, ro), 3);
   float tmid = 0.0f;
   for (int i = 0; i < 8; i++) {
-    float f = hm / (hm - hx);
+    float f = divr_(hm, hm - hx);
     tmid = mix_(tm, tx, f);
     p = madd(rd, tmid, ro);
     if (tmid > maxT) return -1.0f;

@@ -29,10 +29,6 @@ RM_DEV float fract_(float x) { return x - __builtin_floorf(x); }
 RM_DEV float mod_(float x, float y) { return fma(-y, __builtin_floorf(x / y), x); }
 RM_DEV float step_(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }
 RM_DEV float mix_(float x, float y, float a) { return fma(y, a, x * (1.0f - a)); }
-RM_DEV float smoothstep_(float e0, float e1, float x) {
-  float t = clamp_((x - e0) / (e1 - e0), 0.0f, 1.0f);
-  return (t * t) * fma(-2.0f, t, 3.0f);
-}
 RM_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
 // 1.0f / y, bit for bit.  v_rcp_f32 followed by ONE Newton step is the correctly rounded reciprocal of every y with
 // 2^-126 <= |y| < 2^126 — all 2·253·2^23 of them, checked exhaustively on the device against the IEEE quotient
@@ -44,8 +40,14 @@ RM_DEV float rcp_(float y) {
   const float r = __builtin_amdgcn_rcpf(y);
   return fma(fma(-y, r, 1.0f), r, r);
 }
-// x / y of the contract's three hot quotients (oracle rm_divr): x · RN(1/y).
+// x / y of the contract's hot quotients (oracle rm_divr): x · RN(1/y).
 RM_DEV float divr_(float x, float y) { return x * rcp_(y); }
+// ... by a literal constant: the reciprocal is folded at compile time (the same RN(1/c) the oracle computes)
+#define RM_DIVR_CONST(x, c) ((x) * (1.0f / (c)))
+RM_DEV float smoothstep_(float e0, float e1, float x) {
+  float t = clamp_(divr_(x - e0, e1 - e0), 0.0f, 1.0f);
+  return (t * t) * fma(-2.0f, t, 3.0f);
+}
 // Correctly rounded sqrt for x == ±0, x >= 2^-96, +inf, NaN and negative x: the refinement hipcc itself emits for
 // sqrtf (v_sqrt_f32, then pick among s−1ulp, s, s+1ulp by the sign of the fma residuals) without the 2^32
 // pre-scaling that only inputs below 2^-96 need.  Correct rounding is unique, so the bits equal sqrt_().

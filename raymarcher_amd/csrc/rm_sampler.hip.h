@@ -64,7 +64,8 @@ RM_DEV V3 sampleCube(const RmTexture *faces, V3 r) {
   else if (ay >= az)        { ma = ay; face = (r.y >= 0.0f) ? 2 : 3; sc = r.x; tc = (r.y >= 0.0f) ? r.z : -r.z; }
   else                      { ma = az; face = (r.z >= 0.0f) ? 4 : 5; sc = (r.z >= 0.0f) ? r.x : -r.x; tc = -r.y; }
   const RmTexture &t = faces[face];
-  V4 c = sampleRGBA8<true>(t.pixels, t.width, t.height, fma(sc / ma, 0.5f, 0.5f), fma(tc / ma, 0.5f, 0.5f));
+  const float ima = rcp_(ma);  // contract: rm_divr
+  V4 c = sampleRGBA8<true>(t.pixels, t.width, t.height, fma(sc * ima, 0.5f, 0.5f), fma(tc * ima, 0.5f, 0.5f));
   return v3(c.x, c.y, c.z);
 }
 
