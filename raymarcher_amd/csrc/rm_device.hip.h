@@ -30,8 +30,8 @@ RM_DEV V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 RM_DEV V3 madd(V3 a, float s, V3 b) { return v3(fma(a.x, s, b.x), fma(a.y, s, b.y), fma(a.z, s, b.z)); }
 RM_DEV float dot2(float ax, float ay, float bx, float by) { return fma(ay, by, ax * bx); }
 RM_DEV float dot(V3 a, V3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
-RM_DEV float len2(float x, float y) { return sqrt_(dot2(x, y, x, y)); }
-RM_DEV float len(V3 a) { return sqrt_(dot(a, a)); }
+RM_DEV float len2(float x, float y) { return sqrt_fast_(dot2(x, y, x, y)); }  // = sqrt_(): the cheap exact form unless a lane is below 2^-96
+RM_DEV float len(V3 a) { return sqrt_fast_(dot(a, a)); }
 RM_DEV V3 normalize(V3 a) { float inv = rcp_(len(a)); return scale(a, inv); }
 RM_DEV V3 reflect(V3 I, V3 N) { float k = 2.0f * dot(N, I); return madd(N, -k, I); }
 RM_DEV V3 refract(V3 I, V3 N, float eta) {
@@ -421,7 +421,7 @@ RM_DEV float bulbCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
                    fma(M[10], rd.z, fma(M[6], rd.y, M[2] * rd.x)));
   const float a = dot(pd, pd), b = dot(po, pd), c = dot(po, po) - R2;
   const float disc = fma(b, b, -(a * c));
-  float tExit = (sqrt_(max_(disc, 0.0f)) - b) / a;
+  float tExit = (sqrt_fast_(max_(disc, 0.0f)) - b) / a;
   tExit = fma(tExit, 1.0001f, 1.0e-3f);
   if (c > 0.0f && (b >= 0.0f || disc < 0.0f)) tExit = -1.0f;  // outside and never entering
   if (!(a > 0.0f)) return end;
@@ -436,7 +436,7 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R
   const V3 po = v3(ro.x - sb->cullC[0], ro.y - sb->cullC[1], ro.z - sb->cullC[2]);
   const float a = dot(rd, rd), b = dot(po, rd), c = dot(po, po) - R2;
   const float disc = fma(b, b, -(a * c));
-  float tExit = (sqrt_(max_(disc, 0.0f)) - b) / a;
+  float tExit = (sqrt_fast_(max_(disc, 0.0f)) - b) / a;
   tExit = fma(tExit, 1.0001f, 1.0e-3f);
   if (c > 0.0f && (b >= 0.0f || disc < 0.0f)) tExit = -1.0f;
   if (!(a > 0.0f)) return end;
@@ -629,7 +629,7 @@ RM_DEV V3 integrateEdgeVec(V3 v1, V3 v2) {  // frag:349-361
   float a = fma(fma(0.0145206f, y, 0.4965155f), y, 0.8543985f);
   float b = fma(4.1616724f + y, y, 3.4175940f);
   float v = a / b;
-  float ts = (x > 0.0f) ? v : fma(0.5f, rcp_(sqrt_(max_(fma(-x, x, 1.0f), 1e-7f))), -v);
+  float ts = (x > 0.0f) ? v : fma(0.5f, rcp_(sqrt_noscale_(max_(fma(-x, x, 1.0f), 1e-7f))), -v);
   return scale(cross(v1, v2), ts);
 }
 RM_DEV float ltcEvaluate(const SceneBlock *sb, V3 N, V3 V, V3 P, const M3 &MinvIn, const RmLight &li) {  // frag:368-424
@@ -662,7 +662,7 @@ RM_DEV float ltcEvaluate(const SceneBlock *sb, V3 N, V3 V, V3 P, const M3 &MinvI
 }
 RM_DEV V3 getAreaLight(const SceneBlock *sb, V3 N, V3 V, V3 P, const RmLight &li, const Material &mat) {  // frag:1795-1822
   float dotNV = clamp_(dot(N, V), 0.0f, 1.0f);
-  float u = fma(0.0f, kLutScale, kLutBias), v = fma(sqrt_(1.0f - dotNV), kLutScale, kLutBias);
+  float u = fma(0.0f, kLutScale, kLutBias), v = fma(sqrt_noscale_(1.0f - dotNV), kLutScale, kLutBias)  /* 1 − x, x in [0,1]: 0 or >= 2^-24 */;
   V4 t1 = sampleRGBA8<true>(sb->ltc1, RM_LTC_SIZE, RM_LTC_SIZE, u, v), t2 = sampleRGBA8<true>(sb->ltc2, RM_LTC_SIZE, RM_LTC_SIZE, u, v);
   M3 Minv, I;
 #pragma unroll

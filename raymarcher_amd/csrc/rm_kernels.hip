@@ -972,11 +972,13 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
     for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]);
   return rc;
 }
-// rcp_() against the IEEE quotient for EVERY binary32 input: out[0] = inputs where rcp_(y) != 1.0f / y, out[1] = inputs of
-// the fast range 2^-126 <= |y| < 2^126 where the bare v_rcp_f32 + Newton form differs (both must be 0; NaN = NaN).
-__global__ void check_rcp_kernel(unsigned long long *out) {
+// The cheap exact forms against the IEEE operations for EVERY binary32 input (NaN = NaN): out[0] = inputs where rcp_(y) !=
+// 1.0f / y, out[1] = inputs of the fast range 2^-126 <= |y| < 2^126 where the bare v_rcp_f32 + Newton form differs, out[2] =
+// inputs where sqrt_fast_(x) != sqrtf(x), out[3] = inputs of sqrt_noscale_'s domain (±0, |x| >= 2^-96, ±inf, NaN)
+// where it differs from sqrtf(x).  All four must be 0.
+__global__ void check_math_kernel(unsigned long long *out) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  unsigned long long bad = 0, badFast = 0;
+  unsigned long long bad = 0, badFast = 0, badSqrt = 0, badNoscale = 0;
   for (uint64_t u = tid; u < (1ull << 32); u += stride) {
     const float y = u2f((uint32_t)u), ref = 1.0f / y, got = rcp_(y);
     if (f2u(got) != f2u(ref) && !(got != got && ref != ref)) bad++;
@@ -985,22 +987,30 @@ __global__ void check_rcp_kernel(unsigned long long *out) {
       const float r = __builtin_amdgcn_rcpf(y), f = rm::fma(rm::fma(-y, r, 1.0f), r, r);
       if (f2u(f) != f2u(ref)) badFast++;
     }
+    const float sref = sqrt_(y), sf = sqrt_fast_(y);
+    if (f2u(sf) != f2u(sref) && !(sf != sf && sref != sref)) badSqrt++;
+    if (!(ay > 0.0f && ay < 1.262177448e-29f)) {
+      const float sn = sqrt_noscale_(y);
+      if (f2u(sn) != f2u(sref) && !(sn != sn && sref != sref)) badNoscale++;
+    }
   }
   if (bad) atomicAdd(&out[0], bad);
   if (badFast) atomicAdd(&out[1], badFast);
+  if (badSqrt) atomicAdd(&out[2], badSqrt);
+  if (badNoscale) atomicAdd(&out[3], badNoscale);
 }
-int rm_debug_check_rcp(unsigned long long *mismatches2) {
-  if (!mismatches2) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
+int rm_debug_check_math(unsigned long long *mismatches4) {
+  if (!mismatches4) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
   unsigned long long *d = nullptr;
-  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d), 2 * sizeof(unsigned long long)));
-  hipError_t e = hipMemset(d, 0, 2 * sizeof(unsigned long long));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d), 4 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
   if (e == hipSuccess) {
-    check_rcp_kernel<<<4096, 256>>>(d);
+    check_math_kernel<<<4096, 256>>>(d);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(mismatches2, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(mismatches4, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
-  if (e != hipSuccess) { set_error(std::string("rm_debug_check_rcp: ") + hipGetErrorString(e)); return RM_ERR_DEVICE; }
+  if (e != hipSuccess) { set_error(std::string("rm_debug_check_math: ") + hipGetErrorString(e)); return RM_ERR_DEVICE; }
   return RM_OK;
 }
 int rm_debug_ray_planes(const RmCamera *cam, float *out48) {

@@ -32,7 +32,7 @@ RM_DEV float mix_(float x, float y, float a) { return fma(y, a, x * (1.0f - a));
 RM_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
 // 1.0f / y, bit for bit.  v_rcp_f32 followed by ONE Newton step is the correctly rounded reciprocal of every y with
 // 2^-126 <= |y| < 2^126 — all 2·253·2^23 of them, checked exhaustively on the device against the IEEE quotient
-// (scripts/microbench/rcp_exhaustive.hip; rm_debug_check_rcp in the test suite) — so the ten-instruction IEEE expansion runs
+// (scripts/microbench/rcp_exhaustive.hip; rm_debug_check_math in the test suite) — so the ten-instruction IEEE expansion runs
 // only when some lane of the wave holds zero, a denormal, |y| >= 2^126, an infinity or a NaN (wave-uniform branch).
 RM_DEV float rcp_(float y) {
   const float ay = fabs_(y);
@@ -48,7 +48,7 @@ RM_DEV float smoothstep_(float e0, float e1, float x) {
   float t = clamp_(divr_(x - e0, e1 - e0), 0.0f, 1.0f);
   return (t * t) * fma(-2.0f, t, 3.0f);
 }
-// Correctly rounded sqrt for x == ±0, x >= 2^-96, +inf, NaN and negative x: the refinement hipcc itself emits for
+// Correctly rounded sqrt for x == ±0, |x| >= 2^-96 (NaN for the negative ones), +inf and NaN: the refinement hipcc itself emits for
 // sqrtf (v_sqrt_f32, then pick among s−1ulp, s, s+1ulp by the sign of the fma residuals) without the 2^32
 // pre-scaling that only inputs below 2^-96 need.  Correct rounding is unique, so the bits equal sqrt_().
 RM_DEV float sqrt_noscale_(float x) {
@@ -61,7 +61,8 @@ RM_DEV float sqrt_noscale_(float x) {
 // sqrt_() with a wave-uniform choice of the cheap form: the scaled form runs only if some lane holds a positive
 // input below 2^-96 (practically never).
 RM_DEV float sqrt_fast_(float x) {
-  if (__builtin_expect(__ballot((x > 0.0f) && (x < 1.262177448e-29f)) != 0, 0)) return sqrt_(x);
+  const float ax = fabs_(x);  // negative denormals too: v_sqrt_f32 takes them for −0, the IEEE result is NaN (found by the exhaustive check)
+  if (__builtin_expect(__ballot((ax > 0.0f) && (ax < 1.262177448e-29f)) != 0, 0)) return sqrt_(x);
   return sqrt_noscale_(x);
 }
 

@@ -101,14 +101,15 @@ def test_math_contract_bit_exact(renderer, fn):
     assert not bad.any(), f"fn {fn}: {bad.sum()} mismatches, e.g. x={x[bad][:4]}, gpu={got[bad][:4]}, cpu={ref[bad][:4]}"
 
 
-def test_reciprocal_is_the_ieee_quotient_for_every_input(renderer):
-    """rcp_() — v_rcp_f32 + one Newton step wherever the whole wave is inside 2^-126 <= |y| < 2^126 — against 1.0f / y for all
-    2^32 inputs, on the device (rm_debug_check_rcp): the function, and the bare fast form over its whole range."""
+def test_cheap_reciprocal_and_square_root_are_the_ieee_results_for_every_input(renderer):
+    """rcp_() — v_rcp_f32 + one Newton step wherever the whole wave is inside 2^-126 <= |y| < 2^126 — against 1.0f / y, and
+    sqrt_fast_() / sqrt_noscale_() — v_sqrt_f32 + residual selection without the 2^32 pre-scaling — against sqrtf, for all
+    2^32 inputs on the device (rm_debug_check_math): the guarded functions, and the bare fast forms over their whole ranges."""
     import ctypes as C
     from raymarcher_amd import lib
-    out = (C.c_ulonglong * 2)()
-    assert lib().rm_debug_check_rcp(out) == 0
-    assert (out[0], out[1]) == (0, 0)
+    out = (C.c_ulonglong * 4)()
+    assert lib().rm_debug_check_math(out) == 0
+    assert tuple(out) == (0, 0, 0, 0)
 
 
 def test_pnoise_bit_exact(renderer):
