@@ -98,8 +98,8 @@ def cpu_baseline(settings, gpu_frame):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bulb-eval", choices=["reference", "algebraic"], default="reference",
                     help="reference: acos/atan/sin/cos/pow as the shader writes the step (the headline); algebraic: "

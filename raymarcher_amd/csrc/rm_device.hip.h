@@ -30,8 +30,8 @@ RM_DEV V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 RM_DEV V3 madd(V3 a, float s, V3 b) { return v3(fma(a.x, s, b.x), fma(a.y, s, b.y), fma(a.z, s, b.z)); }
 RM_DEV float dot2(float ax, float ay, float bx, float by) { return fma(ay, by, ax * bx); }
 RM_DEV float dot(V3 a, V3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
-RM_DEV float len2(float x, float y) { return sqrt_fast_(dot2(x, y, x, y)); }  // = sqrt_(): the cheap exact form unless a lane is below 2^-96
-RM_DEV float len(V3 a) { return sqrt_fast_(dot(a, a)); }
+RM_DEV float len2(float x, float y) { return sqrt_(dot2(x, y, x, y)); }
+RM_DEV float len(V3 a) { return sqrt_(dot(a, a)); }  // the guarded cheap form is no faster here (measured: bulb frame +1.4 %)
 RM_DEV V3 normalize(V3 a) { float inv = rcp_(len(a)); return scale(a, inv); }
 RM_DEV V3 reflect(V3 I, V3 N) { float k = 2.0f * dot(N, I); return madd(N, -k, I); }
 RM_DEV V3 refract(V3 I, V3 N, float eta) {
