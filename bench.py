@@ -313,7 +313,7 @@ def main():
                          # HBM bytes are not measured by this run: algorithmic 16 B/pixel written; the PMC measurement of this
                          # kernel (WRITE_SIZE + 2·FETCH_SIZE, separate passes) is in profiles/ (133.26 MB per 4K launch)
                          "traffic": None,
-                         "traffic_source": "not collected by bench.py; rocprofv3 PMC: profiles/r01_k_hbm_pmc.md",
+                         "traffic_source": "not collected by bench.py; rocprofv3 PMC: profiles/r02_r_hbm_pmc.md (218 MB per launch = 1.64 x the 16 B/pixel: register spills of the 5-waves-per-SIMD budget; 1.3 % of the HBM peak)",
                          "kernel": kernel_name, "kernel_ms": round(render_ms, 4), "launch_ms": round(kernel_ms, 4),
                          "time_base": ("wall time per frame (three overlapping frames in flight: event spans of single launches "
                                        "are longer than their share of the GPU)" if distributed else "HIP events around the render kernel"),
