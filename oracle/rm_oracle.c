@@ -1666,6 +1666,9 @@ int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float
       case RM_FN_ASIN: out[i] = rm_asin(x[i]); break;
       case RM_FN_Q16: out[i] = q16(x[i]); break;
       case RM_FN_SQRT_FAST: out[i] = rm_sqrt(x[i]); break;
+      case RM_FN_DIVR: out[i] = rm_divr(x[i], y[i]); break;
+      case RM_FN_RCP: out[i] = 1.0f / x[i]; break;
+      case RM_FN_SMOOTHSTEP: out[i] = rm_smoothstep(x[i], y[i], z[i]); break;
       default: return RM_ERR_INVALID_ARGUMENT;
     }
   }

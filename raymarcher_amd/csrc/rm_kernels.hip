@@ -217,6 +217,9 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
     case RM_FN_ASIN: r = asin_(a); break;
     case RM_FN_Q16: r = __half2float(__float2half_rn(a)); break;
     case RM_FN_SQRT_FAST: r = sqrt_fast_(a); break;
+    case RM_FN_DIVR: r = divr_(a, b); break;
+    case RM_FN_RCP: r = rcp_(a); break;
+    case RM_FN_SMOOTHSTEP: r = smoothstep_(a, b, c); break;
   }
   out[i] = r;
 }

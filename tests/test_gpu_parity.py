@@ -79,11 +79,18 @@ def _math_inputs(fn, n, rng):
         x = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-40, 40, n)), [0, 1, 1, -1, 0, np.inf, 1e-40, 1e38, 1]])
         y = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-40, 40, n)), [1, 0, 3, 7, 0, np.inf, 1e3, 1e-5, 289]])
         return x.astype(f), y.astype(f)
+    if fn in (abi.RM_FN_DIVR, abi.RM_FN_RCP):  # incl. the edges of the reciprocal's fast range, denormals, zeros, infinities
+        edge = [0, -0.0, 1, -1, 3, 7, 289, 2000, 1.17549435e-38, 1.1754942e-38, 1e-40, 1e-45, 8.5070592e37, 8.507059e37, 1.7e38,
+                3.4e38, np.inf, -np.inf, np.nan, 0.5, 2, 1e-20, 1e20]
+        y = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-80, 80, n)), edge, edge]).astype(f)
+        x = np.concatenate([rng.normal(0, 100, n) * np.exp(rng.uniform(-40, 40, n)), edge, edge[::-1]]).astype(f)
+        return (y, None) if fn == abi.RM_FN_RCP else (x, y)
     raise ValueError(fn)
 
 
 @pytest.mark.parametrize("fn", [abi.RM_FN_SIN, abi.RM_FN_COS, abi.RM_FN_ACOS, abi.RM_FN_ASIN, abi.RM_FN_ATAN2, abi.RM_FN_LOG2,
-                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV, abi.RM_FN_Q16, abi.RM_FN_SQRT_FAST])
+                                abi.RM_FN_EXP2, abi.RM_FN_POW, abi.RM_FN_SQRT, abi.RM_FN_DIV, abi.RM_FN_Q16, abi.RM_FN_SQRT_FAST,
+                                abi.RM_FN_DIVR, abi.RM_FN_RCP])
 def test_math_contract_bit_exact(renderer, fn):
     import torch
     rng = np.random.default_rng(1000 + fn)
@@ -110,6 +117,24 @@ def test_cheap_reciprocal_and_square_root_are_the_ieee_results_for_every_input(r
     out = (C.c_ulonglong * 4)()
     assert lib().rm_debug_check_math(out) == 0
     assert tuple(out) == (0, 0, 0, 0)
+
+
+def test_smoothstep_bit_exact(renderer):
+    """smoothstep with the contract's x·RN(1/(e1 − e0)): random edges (also equal, reversed, tiny and non-finite ones)."""
+    import torch
+    rng = np.random.default_rng(77)
+    n = 200000
+    e0 = rng.normal(0, 10, n).astype(np.float32)
+    e1 = (e0 + rng.normal(0, 5, n) * np.exp(rng.uniform(-30, 3, n))).astype(np.float32)
+    x = (e0 + (e1 - e0) * rng.uniform(-0.5, 1.5, n)).astype(np.float32)
+    e1[:50] = e0[:50]
+    e1[50:60] = np.inf
+    e0[60:70] = np.nan
+    ref = np.empty_like(x)
+    assert h.oracle().rmo_probe_math(abi.RM_FN_SMOOTHSTEP, h.fptr(e0), h.fptr(e1), h.fptr(x), h.fptr(ref), n) == 0
+    got = renderer.probe_math(abi.RM_FN_SMOOTHSTEP, torch.from_numpy(e0).cuda(), torch.from_numpy(e1).cuda(), torch.from_numpy(x).cuda()).cpu().numpy()
+    bad = (bits(got) != bits(ref)) & ~(np.isnan(got) & np.isnan(ref))
+    assert not bad.any(), f"{bad.sum()} mismatches, e.g. {e0[bad][:3]}, {e1[bad][:3]}, {x[bad][:3]}: gpu {got[bad][:3]} cpu {ref[bad][:3]}"
 
 
 def test_pnoise_bit_exact(renderer):
