@@ -121,6 +121,25 @@ def test_sqrt_and_division_are_ieee():
     assert (probe(abi.RM_FN_DIV, x, y) == (x / y)).all()
 
 
+def test_hot_path_quotient_is_reciprocal_times_numerator():
+    """rm_divr(x, y) = x · RN(1/y): within 1 ulp of the quotient (two roundings), the IEEE special values, and exactly the
+    IEEE quotient whenever 1/y is a power of two."""
+    rng = np.random.default_rng(4)
+    x = (rng.normal(0, 10, 200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
+    y = (rng.normal(0, 10, 200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
+    got = probe(abi.RM_FN_DIVR, x, y)
+    assert (got == x * (np.float32(1.0) / y)).all()
+    assert ulp_err(got, x.astype(np.float64) / y.astype(np.float64)).max() <= 1.0
+    with np.errstate(all="ignore"):
+        sx = np.array([1, -1, 0, 0, np.inf, 3, 3, np.nan, 5], dtype=np.float32)
+        sy = np.array([0, 0, 0, 5, 7, np.inf, -np.inf, 1, np.nan], dtype=np.float32)
+        want = sx / sy
+    g = probe(abi.RM_FN_DIVR, sx, sy)
+    assert ((g == want) | (np.isnan(g) & np.isnan(want))).all() and (np.signbit(g) == np.signbit(want))[~np.isnan(want)].all()
+    p2 = np.float32(2.0) ** rng.integers(-60, 60, 1000).astype(np.float32)
+    assert (probe(abi.RM_FN_DIVR, x[:1000], p2) == x[:1000] / p2).all()
+
+
 def test_pnoise_matches_an_independent_float64_restatement():
     """Classic Perlin 3-D (frag:1610-1676) re-derived in float64 numpy; the binary32 oracle must agree to 1e-5."""
     rng = np.random.default_rng(4)
