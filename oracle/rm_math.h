@@ -44,7 +44,7 @@ static inline float rm_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? 
 static inline float rm_step(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }
 /* GLSL mix(x,y,a) = x·(1−a) + y·a, the second product fused. */
 static inline float rm_mix(float x, float y, float a) { return rm_fma(y, a, x * (1.0f - a)); }
-/* x / y as x · RN(1/y): the correctly rounded reciprocal, then one multiplication (error <= 1 ulp instead of 1/2; GLSL allows
+/* x / y as x · RN(1/y): the correctly rounded reciprocal, then one multiplication (error < 1.5 ulp instead of 1/2; GLSL allows
  * 2.5).  Used for the quotients on hot paths — inside the Mandelbulb iteration (acos argument, atan ratio) and its distance estimate,
  * smoothstep, the soft-shadow and terrain-shadow penumbra, the cone's projection, the terrain / cloud scalings by constants,
  * the cube-map projection: on the GPU RN(1/y) is three instructions (v_rcp_f32 +

@@ -122,14 +122,14 @@ def test_sqrt_and_division_are_ieee():
 
 
 def test_hot_path_quotient_is_reciprocal_times_numerator():
-    """rm_divr(x, y) = x · RN(1/y): within 1 ulp of the quotient (two roundings), the IEEE special values, and exactly the
-    IEEE quotient whenever 1/y is a power of two."""
+    """rm_divr(x, y) = x · RN(1/y): within 1.5 ulp of the quotient (two roundings; measured 1.46), the IEEE special values, and
+    exactly the IEEE quotient whenever 1/y is a power of two."""
     rng = np.random.default_rng(4)
     x = (rng.normal(0, 10, 200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
     y = (rng.normal(0, 10, 200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
     got = probe(abi.RM_FN_DIVR, x, y)
     assert (got == x * (np.float32(1.0) / y)).all()
-    assert ulp_err(got, x.astype(np.float64) / y.astype(np.float64)).max() <= 1.0
+    assert ulp_err(got, x.astype(np.float64) / y.astype(np.float64)).max() <= 1.5
     with np.errstate(all="ignore"):
         sx = np.array([1, -1, 0, 0, np.inf, 3, 3, np.nan, 5], dtype=np.float32)
         sy = np.array([0, 0, 0, 5, 7, np.inf, -np.inf, 1, np.nan], dtype=np.float32)
