@@ -13,6 +13,8 @@
 // copy of the table.
 #pragma once
 #include "../../include/raymarcher_amd.h"
+#include <type_traits>
+
 #include "rm_math.hip.h"
 
 namespace rm {
@@ -200,43 +202,54 @@ RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &c
   V3 c = julia ? v3(sb->g.juliaSeed[0], sb->g.juliaSeed[1], 0.0f) : pos;
   for (int i = 0; i < iters; i++) {
     if (COUNT) cnt.iters++;
-    float r = sqrt_fast_(m);  // frag:789
-    if (MODE == BULB_ALGEBRAIC8) {
-      // (y + iρ)^8 = r^8·(cos 8θ + i sin 8θ), ((z + ix)/ρ)^8 = cos 8φ + i sin 8φ by three complex squarings each,
-      // m^3.5 = m³·√m — no acos/atan/sin/cos/pow in the loop
-      dz = fma(8.0f * (((m * m) * m) * r), dz, 1.0f);
-      float rho = sqrt_fast_(dot2(w.x, w.z, w.x, w.z));
-      float inv = rcp_(rho);
-      float cz = (rho == 0.0f) ? 1.0f : w.z * inv, sx = (rho == 0.0f) ? 0.0f : w.x * inv;
-      float re = w.y, im = rho;
+    // ONE range check per iteration for its square root and its two reciprocals (trigonometric forms): with
+    // 2^-96 <= m < inf the unscaled sqrt is exact and r = sqrt(m) lies in [2^-48, 2^64), inside the reciprocal's fast range;
+    // max(|w.x|, |w.z|) <= r, so it only needs its lower bound.  Any lane outside (the exact origin, a point on the y axis,
+    // non-finite input): the whole wave takes the individually guarded forms — the same bits either way.
+    const bool raw = (MODE != BULB_ALGEBRAIC8) &&
+                     __ballot(!(m >= 1.262177448e-29f) || !(m < __builtin_inff()) || !(max_(fabs_(w.x), fabs_(w.z)) >= 1.17549435e-38f)) == 0;
+    // the iteration's arithmetic, instantiated twice: RAW (unguarded fast forms) and guarded — a wave-uniform branch
+    auto step = [&](auto rawTag) __attribute__((always_inline)) {
+      constexpr bool RAW = decltype(rawTag)::value;
+      float r = RAW ? sqrt_noscale_(m) : sqrt_fast_(m);  // frag:789
+      if (MODE == BULB_ALGEBRAIC8) {
+        // (y + iρ)^8 = r^8·(cos 8θ + i sin 8θ), ((z + ix)/ρ)^8 = cos 8φ + i sin 8φ by three complex squarings each,
+        // m^3.5 = m³·√m — no acos/atan/sin/cos/pow in the loop
+        dz = fma(8.0f * (((m * m) * m) * r), dz, 1.0f);
+        float rho = sqrt_fast_(dot2(w.x, w.z, w.x, w.z));
+        float inv = rcp_(rho);
+        float cz = (rho == 0.0f) ? 1.0f : w.z * inv, sx = (rho == 0.0f) ? 0.0f : w.x * inv;
+        float re = w.y, im = rho;
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        float t = fma(re, re, -(im * im));
-        im = 2.0f * (re * im);
-        re = t;
-        t = fma(cz, cz, -(sx * sx));
-        sx = 2.0f * (cz * sx);
-        cz = t;
-      }
-      w = v3(fma(im, sx, c.x), re + c.y, fma(im, cz, c.z));
-    } else {
-      float pm, pr;
-      if (MODE == BULB_TRIG8) {
-        pm = (m * (m * m)) * r;             // pow_(m, 3.5): p = m, b = m·m, p = p·b, then ·sqrt(m)
-        float r2 = r * r, r4 = r2 * r2;
-        pr = r4 * r4;                       // pow_(r, 8): three squarings
+        for (int k = 0; k < 3; k++) {
+          float t = fma(re, re, -(im * im));
+          im = 2.0f * (re * im);
+          re = t;
+          t = fma(cz, cz, -(sx * sx));
+          sx = 2.0f * (cz * sx);
+          cz = t;
+        }
+        w = v3(fma(im, sx, c.x), re + c.y, fma(im, cz, c.z));
       } else {
-        pm = powApply(m, pexp, planPexp);
-        pr = powApply(r, power, planPower);
+        float pm, pr;
+        if (MODE == BULB_TRIG8) {
+          pm = (m * (m * m)) * r;             // pow_(m, 3.5): p = m, b = m·m, p = p·b, then ·sqrt(m)
+          float r2 = r * r, r4 = r2 * r2;
+          pr = r4 * r4;                       // pow_(r, 8): three squarings
+        } else {
+          pm = powApply(m, pexp, planPexp);
+          pr = powApply(r, power, planPower);
+        }
+        dz = fma(power * pm, dz, 1.0f);       // frag:787
+        float b = power * acos_(RAW ? w.y * rcp_raw_(r) : divr_(w.y, r));  // frag:790
+        float a = power * atan2_<RAW>(w.x, w.z);                            // frag:791
+        float sb_, cb_, sa_, ca_;
+        if (angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
+        else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
+        w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
       }
-      dz = fma(power * pm, dz, 1.0f);       // frag:787
-      float b = power * acos_(divr_(w.y, r));  // frag:790
-      float a = power * atan2_(w.x, w.z);   // frag:791
-      float sb_, cb_, sa_, ca_;
-      if (angleSafe) { sincos_inrange_(b, sb_, cb_); sincos_inrange_(a, sa_, ca_); }  // wave-uniform
-      else { sincos_(b, sb_, cb_); sincos_(a, sa_, ca_); }
-      w = v3(fma(pr, sb_ * sa_, c.x), fma(pr, cb_, c.y), fma(pr, sb_ * ca_, c.z));  // frag:792-793
-    }
+    };
+    if (raw) step(std::true_type{}); else step(std::false_type{});
     if (TRAP) {  // trap.x is never read (resColor below)
       if (TRAPMIN) trap = v4(trap.x, hwmin_abs_(trap.y, w.y), hwmin_abs_(trap.z, w.z), hwmin_(trap.w, m));
       else trap = v4(trap.x, min_(trap.y, fabs_(w.y)), min_(trap.z, fabs_(w.z)), min_(trap.w, m));

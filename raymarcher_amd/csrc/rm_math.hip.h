@@ -40,6 +40,11 @@ RM_DEV float rcp_(float y) {
   const float r = __builtin_amdgcn_rcpf(y);
   return fma(fma(-y, r, 1.0f), r, r);
 }
+// the fast form alone, for callers that have done the range check themselves (one check for several reciprocals)
+RM_DEV float rcp_raw_(float y) {
+  const float r = __builtin_amdgcn_rcpf(y);
+  return fma(fma(-y, r, 1.0f), r, r);
+}
 // x / y of the contract's hot quotients (oracle rm_divr): x · RN(1/y).
 RM_DEV float divr_(float x, float y) { return x * rcp_(y); }
 // ... by a literal constant: the reciprocal is folded at compile time (the same RN(1/c) the oracle computes)
@@ -183,12 +188,15 @@ RM_DEV float atan_p(float s) {
   p = fma(s, p, -3.333315253e-01f);
   return p;
 }
+// RAW = true: the caller has checked, for the whole wave, that max(|x|, |y|) lies in the reciprocal's fast range
+// (2^-126 <= · < 2^126): the bare v_rcp_f32 + Newton form, no guard of its own.  Same bits as RAW = false there.
+template <bool RAW = false>
 RM_DEV float atan2_(float y, float x) {
   float ax = fabs_(x), ay = fabs_(y);
   bool sw = ax < ay;
   float mx = sw ? ay : ax;
   float mn = sw ? ax : ay;
-  float t = divr_(mn, mx);
+  float t = RAW ? mn * rcp_raw_(mx) : divr_(mn, mx);
   // contract: a NaN quotient (0·inf, inf·0, NaN operand) or one that overflows (denormal operands) is 1, and 0 if mx == 0.
   // mn <= mx, so any other quotient is <= 1 and v_min_f32(t, 1) — which ignores a NaN operand — is t itself.
   t = hwmin1_(t);
