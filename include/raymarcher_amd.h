@@ -324,10 +324,11 @@ int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCo
  * §2.3), computed on the host exactly as the launcher stages them.  No GPU needed. */
 int rm_debug_ray_planes(const RmCamera *cam, float *out48);
 /* Tests: the kernels' cheap exact forms against the IEEE operations for every one of the 2^32 inputs, on the current device
- * (≈2 s).  mismatches4[0]: the reciprocal (v_rcp_f32 + one Newton step inside 2^-126 <= |y| < 2^126, the IEEE expansion
+ * (≈2 s).  mismatches5[0]: the reciprocal (v_rcp_f32 + one Newton step inside 2^-126 <= |y| < 2^126, the IEEE expansion
  * outside) vs 1.0f / y; [1]: the bare fast form over its range; [2]: the square root (v_sqrt_f32 + residual selection, the
- * scaled expansion only below 2^-96) vs sqrtf; [3]: the unscaled form over its domain.  All must be 0. */
-int rm_debug_check_math(unsigned long long *mismatches4);
+ * scaled expansion only below 2^-96) vs sqrtf; [3]: the unscaled form over its domain; [4]: fract (v_fract_f32) vs
+ * x − floor(x) kept below 1.  All must be 0. */
+int rm_debug_check_math(unsigned long long *mismatches5);
 
 /*
  * rm_frame_to_rgba8 — clamp→×255→round and vertical flip, the read-back of

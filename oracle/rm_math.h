@@ -36,7 +36,10 @@ static inline float rm_clamp(float x, float lo, float hi) { return rm_min(rm_max
 static inline float rm_abs(float x) { return fabsf(x); }
 static inline float rm_floor(float x) { return floorf(x); }
 /* GLSL fract(x) = x − floor(x) (may round to 1.0 for tiny negative x; kept as specified). */
-static inline float rm_fract(float x) { return x - floorf(x); }
+/* GLSL fract(x) = x − floor(x), kept inside [0, 1): for a tiny negative x the difference rounds to 1.0, which is returned as
+ * 1 − 2^-24 — what the hardware instruction does (v_fract_f32 equals this for every one of the 2^32 inputs: checked on the
+ * device, rm_debug_check_math) and what the hash-type uses of fract (noise lattices) expect.  inf, NaN → NaN. */
+static inline float rm_fract(float x) { float f = x - floorf(x); return (f >= 1.0f) ? 0.99999994f : f; }
 /* GLSL mod(x,y) = x − y·floor(x/y). */
 static inline float rm_mod(float x, float y) { return rm_fma(-y, floorf(x / y), x); }
 static inline float rm_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }

@@ -978,10 +978,10 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
 // The cheap exact forms against the IEEE operations for EVERY binary32 input (NaN = NaN): out[0] = inputs where rcp_(y) !=
 // 1.0f / y, out[1] = inputs of the fast range 2^-126 <= |y| < 2^126 where the bare v_rcp_f32 + Newton form differs, out[2] =
 // inputs where sqrt_fast_(x) != sqrtf(x), out[3] = inputs of sqrt_noscale_'s domain (±0, |x| >= 2^-96, ±inf, NaN)
-// where it differs from sqrtf(x).  All four must be 0.
+// where it differs from sqrtf(x), out[4] = inputs where fract_(x) (v_fract_f32) != x − floor(x) kept below 1.  All must be 0.
 __global__ void check_math_kernel(unsigned long long *out) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  unsigned long long bad = 0, badFast = 0, badSqrt = 0, badNoscale = 0;
+  unsigned long long bad = 0, badFast = 0, badSqrt = 0, badNoscale = 0, badFract = 0;
   for (uint64_t u = tid; u < (1ull << 32); u += stride) {
     const float y = u2f((uint32_t)u), ref = 1.0f / y, got = rcp_(y);
     if (f2u(got) != f2u(ref) && !(got != got && ref != ref)) bad++;
@@ -990,6 +990,8 @@ __global__ void check_math_kernel(unsigned long long *out) {
       const float r = __builtin_amdgcn_rcpf(y), f = rm::fma(rm::fma(-y, r, 1.0f), r, r);
       if (f2u(f) != f2u(ref)) badFast++;
     }
+    const float fd = y - __builtin_floorf(y), fref = (fd >= 1.0f) ? 0.99999994f : fd, fg = fract_(y);
+    if (f2u(fg) != f2u(fref) && !(fg != fg && fref != fref)) badFract++;
     const float sref = sqrt_(y), sf = sqrt_fast_(y);
     if (f2u(sf) != f2u(sref) && !(sf != sf && sref != sref)) badSqrt++;
     if (!(ay > 0.0f && ay < 1.262177448e-29f)) {
@@ -1001,17 +1003,18 @@ __global__ void check_math_kernel(unsigned long long *out) {
   if (badFast) atomicAdd(&out[1], badFast);
   if (badSqrt) atomicAdd(&out[2], badSqrt);
   if (badNoscale) atomicAdd(&out[3], badNoscale);
+  if (badFract) atomicAdd(&out[4], badFract);
 }
-int rm_debug_check_math(unsigned long long *mismatches4) {
-  if (!mismatches4) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
+int rm_debug_check_math(unsigned long long *mismatches5) {
+  if (!mismatches5) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
   unsigned long long *d = nullptr;
-  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d), 4 * sizeof(unsigned long long)));
-  hipError_t e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d), 5 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 5 * sizeof(unsigned long long));
   if (e == hipSuccess) {
     check_math_kernel<<<4096, 256>>>(d);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(mismatches4, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(mismatches5, d, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) { set_error(std::string("rm_debug_check_math: ") + hipGetErrorString(e)); return RM_ERR_DEVICE; }
   return RM_OK;

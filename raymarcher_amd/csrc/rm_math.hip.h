@@ -25,7 +25,9 @@ RM_DEV float min_(float x, float y) { return (y < x) ? y : x; }
 RM_DEV float max_(float x, float y) { return (x < y) ? y : x; }
 RM_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 RM_DEV float floor_(float x) { return __builtin_floorf(x); }
-RM_DEV float fract_(float x) { return x - __builtin_floorf(x); }
+// contract: x − floor(x) kept below 1 (1 − 2^-24 where the difference rounds to 1.0) = v_fract_f32, for every input
+// (rm_debug_check_math; scripts/microbench/fract_exhaustive.hip)
+RM_DEV float fract_(float x) { return __builtin_amdgcn_fractf(x); }
 RM_DEV float mod_(float x, float y) { return fma(-y, __builtin_floorf(x / y), x); }
 RM_DEV float step_(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }
 RM_DEV float mix_(float x, float y, float a) { return fma(y, a, x * (1.0f - a)); }

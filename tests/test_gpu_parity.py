@@ -111,12 +111,13 @@ def test_math_contract_bit_exact(renderer, fn):
 def test_cheap_reciprocal_and_square_root_are_the_ieee_results_for_every_input(renderer):
     """rcp_() — v_rcp_f32 + one Newton step wherever the whole wave is inside 2^-126 <= |y| < 2^126 — against 1.0f / y, and
     sqrt_fast_() / sqrt_noscale_() — v_sqrt_f32 + residual selection without the 2^32 pre-scaling — against sqrtf, for all
-    2^32 inputs on the device (rm_debug_check_math): the guarded functions, and the bare fast forms over their whole ranges."""
+    2^32 inputs on the device (rm_debug_check_math): the guarded functions, and the bare fast forms over their whole ranges;
+    and fract_() = v_fract_f32 against the contract's "x − floor(x), kept below 1"."""
     import ctypes as C
     from raymarcher_amd import lib
-    out = (C.c_ulonglong * 4)()
+    out = (C.c_ulonglong * 5)()
     assert lib().rm_debug_check_math(out) == 0
-    assert tuple(out) == (0, 0, 0, 0)
+    assert tuple(out) == (0, 0, 0, 0, 0)
 
 
 def test_smoothstep_bit_exact(renderer):
