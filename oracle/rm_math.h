@@ -29,9 +29,29 @@ static inline float rm_fma(float a, float b, float c) { return fmaf(a, b, c); }
 static inline uint32_t rm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float rm_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* GLSL min/max: "y if y < x, otherwise x" / "y if x < y, otherwise x" (GLSL 3.30 §8.3). */
-static inline float rm_min(float x, float y) { return (y < x) ? y : x; }
-static inline float rm_max(float x, float y) { return (x < y) ? y : x; }
+/* min / max: GLSL leaves them undefined for NaN operands; the contract takes the hardware's rule (v_min_f32 / v_max_f32 in
+ * IEEE mode, one instruction instead of compare + select): a signalling NaN operand is returned quieted (first operand
+ * first); otherwise a quiet NaN operand is ignored (the other operand is returned; the first one if both are NaN); −0 orders
+ * below +0; otherwise the smaller / larger operand.  (Observed on gfx950 for every pair of a set of special values, and held
+ * by tests/test_gpu_parity.py::test_min_max_fract_…) */
+static inline int rm__is_snan(float f) { uint32_t u = rm_f2u(f); return (u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu) != 0u && !(u & 0x00400000u); }
+static inline float rm__quiet(float f) { return rm_u2f(rm_f2u(f) | 0x00400000u); }
+static inline float rm_min(float x, float y) {
+  if (rm__is_snan(x)) return rm__quiet(x);
+  if (rm__is_snan(y)) return rm__quiet(y);
+  if (x != x) return (y != y) ? x : y;
+  if (y != y) return x;
+  if (x == 0.0f && y == 0.0f) return (rm_f2u(x) >> 31) ? x : y;
+  return (x < y) ? x : y;
+}
+static inline float rm_max(float x, float y) {
+  if (rm__is_snan(x)) return rm__quiet(x);
+  if (rm__is_snan(y)) return rm__quiet(y);
+  if (x != x) return (y != y) ? x : y;
+  if (y != y) return x;
+  if (x == 0.0f && y == 0.0f) return (rm_f2u(x) >> 31) ? y : x;
+  return (x > y) ? x : y;
+}
 static inline float rm_clamp(float x, float lo, float hi) { return rm_min(rm_max(x, lo), hi); }
 static inline float rm_abs(float x) { return fabsf(x); }
 static inline float rm_floor(float x) { return floorf(x); }

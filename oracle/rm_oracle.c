@@ -1669,6 +1669,9 @@ int rmo_probe_math(int fn, const float *x, const float *y, const float *z, float
       case RM_FN_DIVR: out[i] = rm_divr(x[i], y[i]); break;
       case RM_FN_RCP: out[i] = 1.0f / x[i]; break;
       case RM_FN_SMOOTHSTEP: out[i] = rm_smoothstep(x[i], y[i], z[i]); break;
+      case RM_FN_MIN: out[i] = rm_min(x[i], y[i]); break;
+      case RM_FN_MAX: out[i] = rm_max(x[i], y[i]); break;
+      case RM_FN_FRACT: out[i] = rm_fract(x[i]); break;
       default: return RM_ERR_INVALID_ARGUMENT;
     }
   }

@@ -32,8 +32,8 @@ typedef float rmo_f32; /* the one place that stays binary32: the tie decision of
 static inline double rm_fma(double a, double b, double c) { return fma(a, b, c); }
 static inline uint32_t rm_f2u(double f) { float g = (float)0; (void)f; (void)g; return 0u; } /* bit tricks: unused here */
 static inline double rm_u2f(uint32_t u) { (void)u; return 0.0; }
-static inline double rm_min(double x, double y) { return (y < x) ? y : x; }
-static inline double rm_max(double x, double y) { return (x < y) ? y : x; }
+static inline double rm_min(double x, double y) { return fmin(x, y); } /* a NaN operand is ignored, as in the contract */
+static inline double rm_max(double x, double y) { return fmax(x, y); }
 static inline double rm_clamp(double x, double lo, double hi) { return rm_min(rm_max(x, lo), hi); }
 static inline double rm_abs(double x) { return fabs(x); }
 static inline double rm_floor(double x) { return floor(x); }

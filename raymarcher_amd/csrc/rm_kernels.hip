@@ -220,6 +220,9 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
     case RM_FN_DIVR: r = divr_(a, b); break;
     case RM_FN_RCP: r = rcp_(a); break;
     case RM_FN_SMOOTHSTEP: r = smoothstep_(a, b, c); break;
+    case RM_FN_MIN: r = min_(a, b); break;
+    case RM_FN_MAX: r = max_(a, b); break;
+    case RM_FN_FRACT: r = fract_(a); break;
   }
   out[i] = r;
 }

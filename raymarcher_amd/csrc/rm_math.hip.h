@@ -21,8 +21,11 @@ RM_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 RM_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 RM_DEV float fabs_(float x) { return __builtin_fabsf(x); }
 // GLSL min/max as compare-select: "y if y < x else x" / "y if x < y else x".
-RM_DEV float min_(float x, float y) { return (y < x) ? y : x; }
-RM_DEV float max_(float x, float y) { return (x < y) ? y : x; }
+// contract (oracle rm_min / rm_max): the hardware's rule — a signalling NaN operand comes back quieted, a quiet NaN operand
+// is ignored, −0 < +0.  Inline asm: clang's fminf/fmaxf would put a canonicalising v_max in front (IEEE mode), and the
+// compare + select form of GLSL's text is two instructions.
+RM_DEV float min_(float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+RM_DEV float max_(float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 RM_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 RM_DEV float floor_(float x) { return __builtin_floorf(x); }
 // contract: x − floor(x) kept below 1 (1 − 2^-24 where the difference rounds to 1.0) = v_fract_f32, for every input

@@ -120,6 +120,34 @@ def test_cheap_reciprocal_and_square_root_are_the_ieee_results_for_every_input(r
     assert tuple(out) == (0, 0, 0, 0, 0)
 
 
+def test_min_max_fract_bit_exact_on_every_pair_of_special_values(renderer):
+    """min / max with the hardware's rule (signalling NaN → quieted, quiet NaN ignored, −0 < +0) and fract kept below 1: every
+    ordered pair of ~1500 values (zeros, denormals, infinities, both kinds of NaN with payloads, neighbours) bit for bit —
+    NaN payloads included, which the rule defines."""
+    import torch
+    rng = np.random.default_rng(9)
+    special = np.array([0x00000000, 0x80000000, 0x00000001, 0x80000001, 0x007fffff, 0x807fffff, 0x00800000, 0x80800000,
+                        0x3f800000, 0xbf800000, 0x3f7fffff, 0x3f800001, 0x7f7fffff, 0xff7fffff, 0x7f800000, 0xff800000,
+                        0x7fc00000, 0xffc00000, 0x7fc00001, 0x7fffffff, 0x7f800001, 0xff800001, 0x7fa00000, 0x7fbfffff,
+                        0xffa12345, 0x7fd12345], dtype=np.uint32)
+    vals = np.concatenate([special, rng.integers(0, 2**32, 900, dtype=np.uint64).astype(np.uint32),
+                           (rng.normal(0, 3, 600)).astype(np.float32).view(np.uint32)]).view(np.float32)
+    a, b = np.meshgrid(vals, vals, indexing="ij")
+    a, b = np.ascontiguousarray(a.ravel()), np.ascontiguousarray(b.ravel())
+    for fn in (abi.RM_FN_MIN, abi.RM_FN_MAX):
+        ref = np.empty_like(a)
+        assert h.oracle().rmo_probe_math(fn, h.fptr(a), h.fptr(b), None, h.fptr(ref), a.size) == 0
+        got = renderer.probe_math(fn, torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+        bad = bits(got) != bits(ref)
+        assert not bad.any(), f"fn {fn}: {bad.sum()} mismatches, e.g. {bits(a[bad][:4])}, {bits(b[bad][:4])}: gpu {bits(got[bad][:4])} cpu {bits(ref[bad][:4])}"
+    x = np.concatenate([vals, (rng.normal(0, 1e-7, 100000)).astype(np.float32), rng.normal(0, 100, 100000).astype(np.float32)])
+    ref = np.empty_like(x)
+    assert h.oracle().rmo_probe_math(abi.RM_FN_FRACT, h.fptr(x), None, None, h.fptr(ref), x.size) == 0
+    got = renderer.probe_math(abi.RM_FN_FRACT, torch.from_numpy(x).cuda()).cpu().numpy()
+    bad = (bits(got) != bits(ref)) & ~(np.isnan(got) & np.isnan(ref))
+    assert not bad.any()
+
+
 def test_smoothstep_bit_exact(renderer):
     """smoothstep with the contract's x·RN(1/(e1 − e0)): random edges (also equal, reversed, tiny and non-finite ones)."""
     import torch
