@@ -174,14 +174,8 @@ RM_DEV float sdMandelBrot(const SceneBlock *sb, float px, float py) {
 //                   ((r²)²)², of 3.5 is (m·(m·m))·√m — as straight-line code (identical bits, no bit loop);
 //   BULB_ALGEBRAIC8 power == 8 and RM_FEAT_BULB_POWER8_ALGEBRAIC: the step by complex squarings (see the header).
 //
-// TRAPMIN: the orbit-trap minima (frag:795) as v_min_f32 instead of compare + select (4 instead of 8 instructions per
-// iteration).  v_min_f32 differs from the GLSL select form only when its FIRST operand — the accumulator — is NaN (a
-// NaN second operand is ignored by both forms, and every operand is >= +0, so −0 never occurs).  The accumulators start
-// from |pos| and dot(pos, pos) and stay non-NaN once they are; if one STARTS as NaN then pos holds a NaN, every iterate
-// and m are NaN, the estimate is NaN and the evaluation cannot be a hit (|NaN| < 0.001 is false) — and the trap is read
-// only for a hit.  That argument needs the trap's reader to look at THIS object's distance, which holds in the
-// single-Mandelbulb scene class (BULB); the table walk (where the trap of the last fractal evaluated is read whatever
-// object was hit, UB3) keeps the select form.
+// TRAPMIN: the orbit-trap minima (frag:795) with the |·| folded into the v_min_f32 (source modifier).  Since the contract's
+// min IS v_min_f32 (rm_math), both spellings below produce the same bits; TRAPMIN only picks the one-instruction form.
 enum BulbMode { BULB_GENERIC = 0, BULB_TRIG8 = 1, BULB_ALGEBRAIC8 = 2 };
 // TRAP = false drops the orbit trap altogether: shadow marches, normal taps and AO taps never read it (with the select
 // form the compiler removed it there by itself; the v_min_f32 form is inline asm, so it is spelled out).
