@@ -87,6 +87,31 @@ class RaymarcherError(RuntimeError):
         self.status = status
 
 
+def _share_torchs_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (soname libamdhip64.so.7, loaded by path).  If this
+    library were loaded first it would bring in the system copy, a later `import torch` would add its own, and the process
+    would hold two HIP runtimes — the second one finds no device.  So the bundled copies are loaded (globally) before
+    this library whenever torch is installed, whatever the import order; no torch in the environment: nothing to do."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return  # e.g. a CPU-only torch: fall back to the system runtime
+
+
 def lib():
     """The loaded library with argtypes set; raises if it has not been built."""
     global _LIB
@@ -95,6 +120,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is not built and there is no fallback path. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+        _share_torchs_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError = header/library drift, fail loudly
