@@ -148,6 +148,19 @@ def test_min_max_fract_bit_exact_on_every_pair_of_special_values(renderer):
     assert not bad.any()
 
 
+def test_library_loaded_before_torch_still_finds_the_device():
+    """A host that loads the library first and imports torch afterwards (build() then smoke() in one process): both must end
+    up on ONE HIP runtime (raymarcher_amd._lib shares the copy bundled with the PyTorch wheel)."""
+    import subprocess
+    import sys
+    code = ("from raymarcher_amd import lib, abi; lib(); import torch; from raymarcher_amd import Renderer, scenes; "
+            "r = Renderer(0); o = r.render(scenes.mandelbulb(32, 16), abi.default_settings(), 32, 16); "
+            "print('frame', tuple(o.shape), float(o.sum()) == float(o.sum()))")
+    p = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "frame (16, 32, 4) True" in p.stdout, p.stderr[-2000:]
+
+
 def test_smoothstep_bit_exact(renderer):
     """smoothstep with the contract's x·RN(1/(e1 − e0)): random edges (also equal, reversed, tiny and non-finite ones)."""
     import torch
