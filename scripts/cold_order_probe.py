@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""A frame with no history (first frame, or the first after a change of size): which static launch order of the 8×8 tiles
+is best?  Raster (what the launcher does today), centre-out (tiles sorted by distance from the image centre), and a few
+others, timed with rm_debug_set_tile_order on several scenes.  GPU box only."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    from raymarcher_amd import Renderer, Scene, abi, lib, scenes
+    S = os.path.join(ROOT, "tests", "golden", "scenes")
+    r = Renderer(0)
+    L = lib()
+    W, H = 3840, 2160
+    cases = [("bulb 4K", scenes.mandelbulb(W, H), abi.default_settings(fractalIters=12)),
+             ("directional_light_2 4K soft+AO", Scene(path=os.path.join(S, "lighting", "directional_light_2.json")).tables(W, H),
+              abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1)),
+             ("reflections_complex 4K", Scene(path=os.path.join(S, "lighting", "reflections_complex.json")).tables(W, H), abi.default_settings(enableReflection=1)),
+             ("unit_mengersponge 4K refl 2", Scene(path=os.path.join(S, "simple", "unit_mengersponge.json")).tables(W, H),
+              abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1))]
+    tx, ty = (W + 7) // 8, (H + 7) // 8
+    n = tx * ty
+    ix = torch.arange(n, device=r.device)
+    cx, cy = (ix % tx).float() - (tx - 1) / 2, (ix // tx).float() - (ty - 1) / 2
+    orders = {"raster (today)": None,
+              "centre-out": torch.argsort(cx * cx + cy * cy, stable=True),
+              "centre-out, aspect-normalised": torch.argsort((cx / tx) ** 2 + (cy / ty) ** 2, stable=True),
+              "outside-in": torch.argsort(-(cx * cx + cy * cy), stable=True),
+              "rows from the middle": torch.argsort(cy.abs(), stable=True)}
+    L.rm_set_tile_order(0)
+    for name, t, s in cases:
+        out = torch.empty((H, W, 4), dtype=torch.float32, device=r.device)
+        row = [name]
+        for oname, o in orders.items():
+            oo = None if o is None else o.to(torch.int32).contiguous()
+            L.rm_debug_set_tile_order(C.c_void_p(oo.data_ptr()) if oo is not None else None, None, n if oo is not None else 0)
+            for _ in range(2):
+                r.render(t, s, W, H, out=out)
+            torch.cuda.synchronize()
+            L.rm_set_timing(1)
+            for _ in range(8):
+                r.render(t, s, W, H, out=out)
+            torch.cuda.synchronize()
+            ms, k = C.c_double(), C.c_int()
+            L.rm_get_timing(C.byref(ms), C.byref(k))
+            L.rm_set_timing(0)
+            row.append(f"{oname} {ms.value:.3f}")
+        L.rm_debug_set_tile_order(None, None, 0)
+        # and with the feedback
+        L.rm_set_tile_order(1)
+        for _ in range(3):
+            r.render(t, s, W, H, out=out)
+        torch.cuda.synchronize()
+        L.rm_set_timing(1)
+        for _ in range(8):
+            r.render(t, s, W, H, out=out)
+        torch.cuda.synchronize()
+        st = (C.c_double * 4)()
+        ms, k = C.c_double(), C.c_int()
+        L.rm_get_stage_timing(C.byref(ms), st, C.byref(k))
+        L.rm_set_timing(0)
+        L.rm_set_tile_order(0)
+        row.append(f"feedback {st[1]:.3f} (+ sort {st[0]:.3f})")
+        print(" | ".join(row))
+    L.rm_set_tile_order(-1)
+
+
+if __name__ == "__main__":
+    main()
