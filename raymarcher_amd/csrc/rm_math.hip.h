@@ -2,9 +2,9 @@
 //
 // GLSL leaves the precision of sin/cos/acos/atan/pow/exp2/log implementation-defined
 // (the reference calls them all over resources/raymarch.frag, e.g. frag:787-793).  This project fixes
-// one legal implementation built only from correctly rounded binary32 operations
-// (v_add/v_mul/v_fma, IEEE division and sqrt expansions, v_floor, v_rndne, integer bit moves) so that
-// a frame is reproducible bit for bit; the CPU oracle implements the same contract separately and the
+// one legal implementation built only from operations that a CPU reproduces bit for bit — v_add/v_mul/v_fma, correctly
+// rounded reciprocal / division / sqrt, v_floor, v_fract, v_rndne, v_min/v_max with their documented NaN and zero rules,
+// integer bit moves — so that a frame is reproducible; the CPU oracle implements the same contract separately and the
 // GPU tests compare bits.  Compile with -ffp-contract=off and without fast-math: a fused multiply-add
 // exists only where fma() is written.  Branch-free select forms are used so a wave never diverges
 // inside a built-in.
@@ -20,7 +20,6 @@ RM_DEV float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RM_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 RM_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 RM_DEV float fabs_(float x) { return __builtin_fabsf(x); }
-// GLSL min/max as compare-select: "y if y < x else x" / "y if x < y else x".
 // contract (oracle rm_min / rm_max): the hardware's rule — a signalling NaN operand comes back quieted, a quiet NaN operand
 // is ignored, −0 < +0.  Inline asm: clang's fminf/fmaxf would put a canonicalising v_max in front (IEEE mode), and the
 // compare + select form of GLSL's text is two instructions.
@@ -76,8 +75,7 @@ RM_DEV float sqrt_fast_(float x) {
   return sqrt_noscale_(x);
 }
 
-// v_min_f32 (IEEE minNum: a quiet NaN operand is ignored).  Equal to min_() whenever neither operand is NaN and no
-// operand is −0; callers state why that holds, or why the NaN behaviour is the one they want.
+// min_() with a literal operand or a source modifier folded into the instruction (the same contract).
 #ifdef RM_X_BUILTIN_MIN
 RM_DEV float hwmin_(float a, float b) { return __builtin_fminf(a, b); }
 RM_DEV float hwmin1_(float a) { return __builtin_fminf(a, 1.0f); }
