@@ -5,15 +5,16 @@
  * of its built-ins (sin, cos, acos, atan, pow, exp2, log, …) implementation-defined, so two GPUs
  * running resources/raymarch.frag do not agree bit-for-bit, and the Mandelbulb/Menger silhouettes
  * amplify 1-ulp differences into different hit/miss decisions.  To make "identical results"
- * checkable, this project FIXES one legal implementation of every built-in, made only of IEEE-754
- * binary32 operations that are correctly rounded on both x86-64 and gfx950
- * (+, −, ×, ÷, sqrt, fma, floor, rint, compares, bit moves).  The HIP kernels implement the same
- * contract independently (raymarcher_amd/csrc/rm_math.hip.h); tests require bit equality.
+ * checkable, this project FIXES one legal implementation of every built-in, made only of binary32
+ * operations that x86-64 and gfx950 both compute to the same bits: +, −, ×, ÷, reciprocal, sqrt, fma (correctly rounded),
+ * floor, rint, fract, min / max (with the NaN and zero rules written out below), compares, bit moves.  The HIP kernels
+ * implement the same contract independently (raymarcher_amd/csrc/rm_math.hip.h); tests require bit equality.
  *
  * Rules of the contract
  *   - every operation is binary32, round-to-nearest-even, no flush of results;
  *   - a*b+c is fused ONLY where written as rm_fma(); build with -ffp-contract=off;
- *   - min/max are the compare-select forms below (no NaN/±0 ambiguity);
+ *   - min / max follow the rule of the hardware instruction (stated at rm_min), fract stays below 1, the quotients on
+ *     hot paths are x · RN(1/y) (rm_divr): each is one legal reading of GLSL's text and one GPU instruction (or three);
  *   - out-of-domain inputs give the documented finite/inf value, never "undefined".
  * Polynomial coefficients come from oracle/tools/fit_coeffs.py (max approximation error in the
  * comments); measured end-to-end accuracy is asserted in tests/test_oracle_math.py.
