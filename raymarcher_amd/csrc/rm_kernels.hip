@@ -55,7 +55,7 @@ constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 // the spills land outside the march / iteration loops (shading prologues and epilogues) and the extra resident waves hide the
 // serial latency of an evaluation (scalar loads per object, dependent transcendental chains): at 3840x2160 a 5-object Phong
 // scene gains 26 %, bump + reflection 28 %, textured / sky-box scenes 83-90 %, the 8K Menger frame 18 %, the terrain and
-// sea frames 5-7 %, the headline bulb frame 2.3 % (5 waves; its hot loops stay spill-free).  Frames too small to fill the
+// sea frames 5-7 %, the headline bulb frame 2.3 % (5 waves; its hot loops stay spill-free).  Re-tuned on the final code: 6 / 5 / 6 / 6.  Frames too small to fill the
 // chip (256x256, 1080p tails) lose 1-2 %.  -DRM_*_WAVES=n overrides, for the experiment script scripts/gpu_variants.sh.
 #ifndef RM_GENERIC_WAVES
 #define RM_GENERIC_WAVES 6
@@ -64,10 +64,10 @@ constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 #define RM_BULB_WAVES 5
 #endif
 #ifndef RM_ENV_WAVES
-#define RM_ENV_WAVES 5
+#define RM_ENV_WAVES 6
 #endif
 #ifndef RM_TEX_WAVES
-#define RM_TEX_WAVES 5
+#define RM_TEX_WAVES 6
 #endif
 template <bool BULB, int COUNT, bool ENV, bool TEX>
 __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? RM_BULB_WAVES : RM_GENERIC_WAVES)))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
