@@ -91,14 +91,19 @@ static inline float rm_sqrt(float x) { return sqrtf(x); }
 #define RM_PIO2_HI 1.57079637f          /* 0x3fc90fdb */
 #define RM_PIO2_MID (-4.37113883e-08f)  /* 0xb33bbd2e */
 
-/* r = x − k·pi/2 with k = rint(x·2/pi); valid contract range |x| < 2^22, outside it (and NaN)
- * the reduction returns r = 0, q = 0 (sin → 0, cos → 1). */
+/* r = x − k·pi/2 with k = the integer nearest to x·2/pi; valid contract range |x| < 2^22, outside it (and NaN) the
+ * reduction returns r = 0, q = 0 (sin → 0, cos → 1).  k by the shifter trick: t = fma(x, 2/pi, 1.5·2^23) lies in [2^23, 2^24),
+ * where the unit in the last place is 1, so the fma's single rounding IS round-to-nearest-even of x·2/pi; k = t − 1.5·2^23
+ * is exact and the two low bits of t's significand are k mod 4 (also for negative k).  One fma and one subtraction
+ * instead of multiply, rint and convert. */
+#define RM_SHIFTER 12582912.0f /* 1.5·2^23, 0x4b400000 */
 static inline float rm__reduce_pio2(float x, int *q) {
   if (!(fabsf(x) < 4194304.0f)) { *q = 0; return 0.0f; }
-  float k = rintf(x * RM_2OPI);
+  float t = rm_fma(x, RM_2OPI, RM_SHIFTER);
+  float k = t - RM_SHIFTER;
   float r = rm_fma(-k, RM_PIO2_HI, x);
   r = rm_fma(-k, RM_PIO2_MID, r);
-  *q = (int)k;
+  *q = (int)(rm_f2u(t) & 3u);
   return r;
 }
 /* sin(r), |r| <= pi/4 : r + r·z·S(z)   (max rel approx err 6.8e-9) */

@@ -96,15 +96,19 @@ RM_DEV float divc_(float x, float c, float rc) { float q = x * rc; float r = fma
 constexpr float kPi = 3.14159274f;          // 0x40490fdb
 constexpr float kPio2 = 1.57079637f;        // 0x3fc90fdb
 constexpr float k2oPi = 0.636619747f;       // 0x3f22f983
+constexpr float kShifter = 12582912.0f;     // 1.5·2^23, 0x4b400000
 constexpr float kPio2Mid = -4.37113883e-08f;  // 0xb33bbd2e
 
 // sin and cos of one argument sharing the Cody–Waite reduction (bits equal the separate calls).
 RM_DEV void sincos_(float x, float &sn, float &cs) {
   bool ok = fabs_(x) < 4194304.0f;
-  float k = __builtin_rintf(x * k2oPi);
+  // k = nearest integer to x·2/pi by the shifter 1.5·2^23 (oracle rm__reduce_pio2): one fma, one subtraction; the two low
+  // bits of t's significand are k mod 4
+  float t = fma(x, k2oPi, kShifter);
+  float k = t - kShifter;
   float r = fma(-k, kPio2, x);
   r = fma(-k, kPio2Mid, r);
-  int q = ok ? (int)k : 0;
+  uint32_t q = ok ? f2u(t) : 0u;
   r = ok ? r : 0.0f;
   float z = r * r;
   float s = fma(z, -1.950213627e-04f, 8.332063444e-03f);
@@ -122,10 +126,11 @@ RM_DEV void sincos_(float x, float &sn, float &cs) {
 // Same bits as sincos_ for finite |x| < 2^22 (the guard of the contract is dead there); used by the Mandelbulb
 // iteration, whose angles are power·acos(·) and power·atan(·,·): finite and bounded by power·pi.
 RM_DEV void sincos_inrange_(float x, float &sn, float &cs) {
-  float k = __builtin_rintf(x * k2oPi);
+  float t = fma(x, k2oPi, kShifter);
+  float k = t - kShifter;
   float r = fma(-k, kPio2, x);
   r = fma(-k, kPio2Mid, r);
-  int q = (int)k;
+  uint32_t q = f2u(t);
   float z = r * r;
   float s = fma(z, -1.950213627e-04f, 8.332063444e-03f);
   s = fma(z, s, -1.666665375e-01f);
