@@ -70,6 +70,8 @@ class FramePipeline:
         self.local = [torch.zeros((plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.gathered = [torch.empty((plan.world * plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device)
                          for _ in range(depth)] if rank == 0 else [None] * depth
+        # the per-rank views of every gather buffer, made once (submit() runs several thousand times a second at N = 8)
+        self.outs = [list(g.view(plan.world, plan.slot_rows, *tuple(slot_shape)).unbind(0)) if g is not None else None for g in self.gathered]
         self.work = [None] * depth
         self.streams = None
         if multi_stream and torch.device(device).type == "cuda":
@@ -101,8 +103,7 @@ class FramePipeline:
         with self._on(b):
             render_into(self.local[b])
             if self.rank == 0:
-                outs = list(self.gathered[b].view(self.plan.world, self.plan.slot_rows, *self.local[b].shape[1:]).unbind(0))
-                self.work[b] = dist.gather(self.local[b], outs, dst=0, async_op=True)
+                self.work[b] = dist.gather(self.local[b], self.outs[b], dst=0, async_op=True)
             else:
                 self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
         if self.i >= self.depth - 1:        # finish the oldest frame in flight while the newer ones render / travel
