@@ -60,7 +60,7 @@ class FramePipeline:
     multi_stream=True gives every slot its own CUDA stream, so consecutive frames' RENDER kernels overlap too.  That is what
     lets a sharded frame scale: a frame holds a few rays that march all 256 steps without converging — a serial chain of
     ≈0.7–0.9 ms — and on one stream a 1/8-frame shard (0.3 ms of work) cannot end before its longest chain does
-    (measured: 0.93 ms per shard-frame on one stream, 0.33 ms with three frames in flight on three streams;
+    (measured: 0.95 ms per shard-frame on one stream, 0.27–0.31 ms with three frames in flight on three streams;
     scripts/shard_probe.py).  The library keeps scratch and the tile-order feedback per stream, so the slots do not interfere."""
 
     def __init__(self, plan, rank, slot_shape, dtype, device, finish=None, depth=2, multi_stream=False):
