@@ -144,7 +144,7 @@ static inline float rm__asin_p(float z) {
  * by oracle/tools/fit_coeffs.py (max rel approx err 5.6e-8; measured < 2.9 ulp) — and pi − that for x <= 0.
  * |x| >= 1 or NaN clamps to acos(±1): x > 0 → 0, otherwise pi.  One polynomial, one square root, no branch on |x|. */
 static inline float rm_acos(float x) {
-  float ax = fabsf(x);
+  float ax = rm_min(1.0f, fabsf(x)); /* the clamp of the domain; a quiet NaN gives 1 (rm_min), i.e. acos(NaN) = pi */
   float p = rm_fma(ax, -1.253449009e-03f, 6.638590246e-03f);
   p = rm_fma(ax, p, -1.704506390e-02f);
   p = rm_fma(ax, p, 3.086272627e-02f);
@@ -152,7 +152,7 @@ static inline float rm_acos(float x) {
   p = rm_fma(ax, p, 8.897730708e-02f);
   p = rm_fma(ax, p, -2.145987004e-01f);
   p = rm_fma(ax, p, 1.570796251e+00f);
-  float v = (ax < 1.0f) ? (sqrtf(1.0f - ax) * p) : 0.0f;
+  float v = sqrtf(1.0f - ax) * p; /* |x| >= 1: sqrt(0)·P(1) = 0 */
   return (x > 0.0f) ? v : (RM_PI - v);
 }
 

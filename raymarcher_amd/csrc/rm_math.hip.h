@@ -157,10 +157,11 @@ RM_DEV float asin_p(float z) {
 // branch on |x|.  1 − |x| is 0, >= 2^-24, negative or NaN — never a tiny positive number — so the unscaled correctly
 // rounded square root applies; its NaN for |x| > 1 is discarded by the clamp.
 RM_DEV float acos_(float x) {
-  float ax = fabs_(x);
-  // keep |x| in a register of its own: folded into the fma operands as a source modifier it forces the VOP3 encoding, which
-  // takes no literal, and the seven coefficients would each occupy a scalar register across the march loops
-  asm("" : "+v"(ax));
+  // ax = min(1, |x|) in ONE instruction (the contract's min: a quiet NaN gives 1): the clamp of the domain and |x| in a
+  // register of its own — folded into the fma operands as a source modifier it would force the VOP3 encoding, which takes
+  // no literal, and the seven coefficients would each occupy a scalar register across the march loops
+  float ax;
+  asm("v_min_f32 %0, 1.0, |%1|" : "=v"(ax) : "v"(x));
   float p = fma(ax, -1.253449009e-03f, 6.638590246e-03f);
   p = fma(ax, p, -1.704506390e-02f);
   p = fma(ax, p, 3.086272627e-02f);
@@ -168,8 +169,7 @@ RM_DEV float acos_(float x) {
   p = fma(ax, p, 8.897730708e-02f);
   p = fma(ax, p, -2.145987004e-01f);
   p = fma(ax, p, 1.570796251e+00f);
-  float v = sqrt_noscale_(1.0f - ax) * p;
-  v = (ax < 1.0f) ? v : 0.0f;
+  float v = sqrt_noscale_(1.0f - ax) * p;  // 1 − ax is 0 or >= 2^-24; |x| >= 1 or NaN: sqrt(0)·P(1) = 0
   return (x > 0.0f) ? v : (kPi - v);
 }
 
