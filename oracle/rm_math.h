@@ -189,8 +189,8 @@ static inline float rm__atan_p(float s) {
  * x < 0 (so −0 counts as +0); the result carries the sign bit of y. */
 static inline float rm_atan2(float y, float x) {
   float ax = fabsf(x), ay = fabsf(y);
-  float mx = (ax < ay) ? ay : ax;
-  float mn = (ax < ay) ? ax : ay;
+  float mx = rm_max(ax, ay);
+  float mn = rm_min(ax, ay);
   float t = rm_divr(mn, mx);
   if (!(t <= 1.0f)) t = 1.0f; /* NaN, +inf */
   if (mx == 0.0f) t = 0.0f;

@@ -201,9 +201,9 @@ RM_DEV float atan_p(float s) {
 template <bool RAW = false>
 RM_DEV float atan2_(float y, float x) {
   float ax = fabs_(x), ay = fabs_(y);
-  bool sw = ax < ay;
-  float mx = sw ? ay : ax;
-  float mn = sw ? ax : ay;
+  float mx, mn;  // the contract's max / min of the magnitudes, |·| folded into the instructions
+  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+  asm("v_min_f32 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
   float t = RAW ? mn * rcp_raw_(mx) : divr_(mn, mx);
   // contract: a NaN quotient (0·inf, inf·0, NaN operand) or one that overflows (denormal operands) is 1, and 0 if mx == 0.
   // mn <= mx, so any other quotient is <= 1 and v_min_f32(t, 1) — which ignores a NaN operand — is t itself.
