@@ -63,6 +63,10 @@ static inline float rm_floor(float x) { return floorf(x); }
 static inline float rm_fract(float x) { float f = x - floorf(x); return (f >= 1.0f) ? 0.99999994f : f; }
 /* GLSL mod(x,y) = x − y·floor(x/y). */
 static inline float rm_mod(float x, float y) { return rm_fma(-y, floorf(x / y), x); }
+/* mod(x, 2^k) through fract: y·fract(x/y).  x/y and the multiplication by y are exact, so this IS x − y·floor(x/y) — except
+ * for a tiny negative x, where that expression rounds to y itself and this one stays below it (fract's rule).  The Menger
+ * sponge's mod(p·s, 2): multiply, v_fract_f32, and the ·2 − 1 that follows in one fma. */
+static inline float rm_mod_pow2(float x, float y) { return y * rm_fract(x * (1.0f / y)); }
 static inline float rm_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 /* GLSL step(edge,x) = x < edge ? 0 : 1. */
 static inline float rm_step(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }

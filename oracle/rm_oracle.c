@@ -326,7 +326,7 @@ static float sdMengerSponge(const Ctx *c, v3 p, v4 *res) {
     /* frag:1057 */
     p = mix3(p, mul_ma(V3(p.x + off, p.y + off, p.z + off)), ani);
     /* frag:1058-1060 */
-    v3 a = V3(rm_mod(p.x * s, 2.0f) - 1.0f, rm_mod(p.y * s, 2.0f) - 1.0f, rm_mod(p.z * s, 2.0f) - 1.0f);
+    v3 a = V3(rm_mod_pow2(p.x * s, 2.0f) - 1.0f, rm_mod_pow2(p.y * s, 2.0f) - 1.0f, rm_mod_pow2(p.z * s, 2.0f) - 1.0f);
     s = s * 3.0f;
     v3 r = V3(rm_abs(rm_fma(-3.0f, rm_abs(a.x), 1.0f)), rm_abs(rm_fma(-3.0f, rm_abs(a.y), 1.0f)),
               rm_abs(rm_fma(-3.0f, rm_abs(a.z), 1.0f)));

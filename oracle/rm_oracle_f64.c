@@ -39,6 +39,7 @@ static inline double rm_abs(double x) { return fabs(x); }
 static inline double rm_floor(double x) { return floor(x); }
 static inline double rm_fract(double x) { double f = x - floor(x); return (f >= 1.0) ? 0.99999999999999989 : f; }
 static inline double rm_mod(double x, double y) { return x - y * floor(x / y); }
+static inline double rm_mod_pow2(double x, double y) { return y * rm_fract(x / y); }
 static inline double rm_sign(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }
 static inline double rm_step(double edge, double x) { return (x < edge) ? 0.0 : 1.0; }
 static inline double rm_mix(double x, double y, double a) { return x * (1.0 - a) + y * a; }

@@ -300,7 +300,9 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
                  fma(0.60f, v.z, fma(0.00f, v.y, 0.80f * v.x)));
       p = mix(p, mv, ani);
     }
-    V3 a = v3(mod_(p.x * s, 2.0f) - 1.0f, mod_(p.y * s, 2.0f) - 1.0f, mod_(p.z * s, 2.0f) - 1.0f);
+    // mod(·, 2) − 1 as 2·fract(·/2) − 1 (contract: rm_mod_pow2): 2·f is exact, so the fma rounds exactly like the subtraction
+    const float hs = 0.5f * s;
+    V3 a = v3(fma(2.0f, fract_(p.x * hs), -1.0f), fma(2.0f, fract_(p.y * hs), -1.0f), fma(2.0f, fract_(p.z * hs), -1.0f));
     s = s * 3.0f;
     float rx = fabs_(fma(-3.0f, fabs_(a.x), 1.0f)), ry = fabs_(fma(-3.0f, fabs_(a.y), 1.0f)),
           rz = fabs_(fma(-3.0f, fabs_(a.z), 1.0f));
