@@ -43,8 +43,10 @@ RM_DEV float quintic(float w) { return ((w * w) * w) * fma(w, fma(w, 6.0f, -15.0
 RM_DEV float noiseT(float x, float y) {  // frag:493-502
   float px = floor_(x), py = floor_(y);
   float ux = quintic(fract_(x)), uy = quintic(fract_(y));
-  float a = hash1v2(px + 0.0f, py + 0.0f), b = hash1v2(px + 1.0f, py + 0.0f);
-  float c = hash1v2(px + 0.0f, py + 1.0f), d = hash1v2(px + 1.0f, py + 1.0f);
+  // the shader's "+ 0.0" only turns a −0 lattice coordinate into +0, and the hash starts with fract(·) of a multiple of it,
+  // which is +0 for either zero (v_fract_f32(−0) = +0, rm_debug_check_math): dropped
+  float a = hash1v2(px, py), b = hash1v2(px + 1.0f, py);
+  float c = hash1v2(px, py + 1.0f), d = hash1v2(px + 1.0f, py + 1.0f);
   float t = fma(b - a, ux, a);
   t = fma(c - a, uy, t);
   t = fma((((a - b) - c) + d) * ux, uy, t);
@@ -57,7 +59,7 @@ RM_DEV V4 noised3(V3 x) {  // frag:536-567
   V3 du = v3(((30.0f * w.x) * w.x) * fma(w.x, w.x - 2.0f, 1.0f), ((30.0f * w.y) * w.y) * fma(w.y, w.y - 2.0f, 1.0f),
              ((30.0f * w.z) * w.z) * fma(w.z, w.z - 2.0f, 1.0f));
   float n = fma(157.0f, p.z, fma(317.0f, p.y, p.x));
-  float a = hash1f(n + 0.0f), b = hash1f(n + 1.0f), c = hash1f(n + 317.0f), d = hash1f(n + 318.0f);
+  float a = hash1f(n), b = hash1f(n + 1.0f), c = hash1f(n + 317.0f), d = hash1f(n + 318.0f);  // "+ 0.0" dropped: hash1f(−0) = hash1f(+0)
   float e = hash1f(n + 157.0f), f = hash1f(n + 158.0f), g = hash1f(n + 474.0f), h = hash1f(n + 475.0f);
   float k0 = a, k1 = b - a, k2 = c - a, k3 = e - a;
   float k4 = ((a - b) - c) + d, k5 = ((a - c) - e) + g, k6 = ((a - b) - e) + f;
