@@ -302,12 +302,18 @@ int rm_get_timing(double *avgKernelMs, int *launches);
 /* Same, split by pipeline stage.  The single-Mandelbulb scene class renders as four kernels (primary march,
  * surface/normals, shadow marches, shading: stage 0..3); every other scene is one kernel (stage 0). */
 int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches);
-/* Which schedule renders the single-Mandelbulb scene class: 0 = the measured-fastest one (default),
- * 1 = one lane per pixel (rm::render_kernel, the only path for every other scene), 2 = four-kernel pipeline with
- * per-lane state machines and ballot-based lane refill, 3 = four-kernel pipeline with plain loops on compacted
- * hit / shadow-ray lists, 4 = as 3 with the march stages cut into step-budgeted passes (survivors re-compacted
- * between launches).  All paths produce identical bits; the switch exists for A/B measurement and tests. */
+/* Which schedule renders a frame: 0 = the measured-fastest one of the scene's class (default), 1 = one lane per pixel
+ * (rm::render_kernel).  Single-Mandelbulb class only: 2 = four-kernel pipeline with per-lane state machines and
+ * ballot-based lane refill, 3 = four-kernel pipeline with plain loops on compacted hit / shadow-ray lists, 4 = as 3 with
+ * the march stages cut into step-budgeted passes (survivors re-compacted between launches).  Table-walk classes
+ * (primitives, Menger sponge, Sierpinski; no samplers, procedural layers, refraction, Mandelbulb or 2-D Mandelbrot in the
+ * scene): 5 = the wavefront pipeline of rm_wavefront.hip.h — per generation of rays (primary, then each reflection
+ * bounce of frag:2491-2524) a persistent march kernel whose lanes are rays refilled from a queue as they end, a dense
+ * surface kernel, the same march kernel over the shadow rays, a dense light / bounce kernel.  A request that does not
+ * apply to the scene falls back to 1.  All paths produce identical bits; the switch exists for A/B measurement and tests. */
 int rm_set_kernel_path(int path);
+/* Tests: the schedule (numbering above; never 0) the most recent render launch on the current device ran, -1 on error. */
+int rm_debug_last_path(void);
 /* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never
  * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely
  * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): feedback — every

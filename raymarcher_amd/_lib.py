@@ -54,6 +54,7 @@ SIGNATURES = {
     "rm_get_timing": (C.c_int, [_P(C.c_double), _P(C.c_int)]),
     "rm_get_stage_timing": (C.c_int, [_P(C.c_double), _P(C.c_double), _P(C.c_int)]),
     "rm_set_kernel_path": (C.c_int, [C.c_int]),
+    "rm_debug_last_path": (C.c_int, []),
     "rm_set_tile_order": (C.c_int, [C.c_int]),
     "rm_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rm_debug_ray_planes": (C.c_int, [_P(abi.RmCamera), _P(C.c_float)]),

@@ -18,6 +18,7 @@
 
 #include "rm_bulb_pipeline.hip.h"
 #include "rm_device.hip.h"
+#include "rm_wavefront.hip.h"
 #include "rm_internal.h"
 
 namespace rm {
@@ -287,6 +288,7 @@ struct DeviceState {
   const int32_t *dbgTileOrder = nullptr;  // rm_debug_set_tile_order (experiments): overrides the modes below
   uint32_t *dbgTileCost = nullptr;
   int dbgTileCount = 0;
+  int lastPath = 0;  // rm_debug_last_path: the schedule of the most recent render launch on this device
 };
 std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_ORDER or the default
 constexpr int kDefaultTileOrder = 1;
@@ -404,6 +406,35 @@ int bulb_workspace(size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWs
       wsC->sSteps[k] = reinterpret_cast<int *>(take(pixels * nlq * 4));
     }
   }
+  return RM_OK;
+}
+
+// Carve the wavefront pipeline's records for `cap` hit slots and `nl` lights out of the stream's workspace.
+int wavefront_workspace(size_t cap, int nl, hipStream_t stream, WfWs *ws) {
+  auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t nlq = (size_t)(nl > 0 ? nl : 1);
+  const size_t sizes[] = {align(WF_STRIDE * (kWfMaxBounces + 2) * 4), align(cap * 16), align(cap * 16), align(cap * 16), align(cap * 16),
+                          align(cap * 16), align(cap * 16), align(cap * 16), align(cap * nlq * 4), align(cap * 8), align(cap * 16),
+                          align(cap * 16), align(cap * 8)};
+  size_t total = 0;
+  for (size_t b : sizes) total += b;
+  void *mem = nullptr;
+  if (int st = stream_workspace(kWsWavefront, stream, total, &mem)) return st;
+  char *q = static_cast<char *>(mem);
+  int k = 0;
+  auto take = [&]() { char *r = q; q += sizes[k++]; return r; };
+  ws->counters = reinterpret_cast<uint32_t *>(take());
+  ws->rayO[0] = reinterpret_cast<float4 *>(take()); ws->rayO[1] = reinterpret_cast<float4 *>(take());
+  ws->rayD[0] = reinterpret_cast<float4 *>(take()); ws->rayD[1] = reinterpret_cast<float4 *>(take());
+  ws->hit = reinterpret_cast<int4 *>(take());
+  ws->surfP = reinterpret_cast<float4 *>(take());
+  ws->surfN = reinterpret_cast<float4 *>(take());
+  ws->shadow = reinterpret_cast<float *>(take());
+  ws->pathPix = reinterpret_cast<int2 *>(take());
+  ws->pathA = reinterpret_cast<float4 *>(take());
+  ws->pathB = reinterpret_cast<float4 *>(take());
+  ws->pathC = reinterpret_cast<float2 *>(take());
+  ws->cap = (uint32_t)cap;
   return RM_OK;
 }
 
@@ -622,6 +653,12 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   return RM_OK;
 }
 
+// Whether the wavefront pipeline is expected to beat the one-lane-per-pixel kernel on this scene (measured).
+bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels) {
+  (void)objs; (void)numObjects; (void)bounces; (void)pixels;
+  return false;
+}
+
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                   const RmGlobals *g, const RmSettings *s, int W, int H, RowMap map, int nRows, float *d_rgba,
                   float *d_bright, hipStream_t stream, int count, RmCounters *countersOut,
@@ -644,8 +681,9 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   // The wavefront pipeline covers the single-Mandelbulb class without secondary rays; everything else (and the
   // counted variant) runs the one-lane-per-pixel kernel.  Both produce the same bits.
   static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
-  int path = g_kernelPath.load() ? g_kernelPath.load() : envPath;
-  if (path == 0) path = kAutoBulbPath;
+  const int pathReq = g_kernelPath.load() ? g_kernelPath.load() : envPath;  // 0 = the measured-fastest schedule of the scene's class
+  int path = pathReq;
+  if (path == 0 || path == 5) path = kAutoBulbPath;
   const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND | RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) != 0;
   // anything that reads a sampler or takes the area-light branches: object textures, sky box, emissive rectangles, area lights
   bool textured = s->enableSkyBox != 0;
@@ -654,6 +692,17 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   const bool pipeline = bulb && !count && path != 1 && !envFeatures && !textured && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
                         !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
                         !(s->enableRefraction && nonzero3(objs[0].cTransparent));
+  // The wavefront pipeline (rm_wavefront.hip.h) covers the table-walk classes whose evaluations cost the same on every
+  // lane: no Mandelbulb / 2-D Mandelbrot in the table, no samplers or procedural layers, no refraction.
+  bool wfOk = !bulb && !count && !envFeatures && !textured && !g->isTwoD && s->maxSteps >= 1 && s->numReflection <= kWfMaxBounces;
+  bool anyReflective = false;
+  for (int i = 0; i < numObjects; i++) {
+    if (objs[i].type == RM_MANDELBULB || objs[i].type == RM_MANDELBROT) wfOk = false;
+    if (s->enableRefraction && nonzero3(objs[i].cTransparent)) wfOk = false;
+    anyReflective = anyReflective || nonzero3(objs[i].cReflective);
+  }
+  const int wfBounces = (s->enableReflection && anyReflective) ? s->numReflection : 0;
+  const bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W)));
   // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
   // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident: one wave
   // per workgroup for every class (measured at the register budgets above: the 4K bulb frame 2.31 / 2.34 / 2.58 ms at
@@ -667,7 +716,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   static const int envOrder = std::getenv("RM_TILE_ORDER") ? std::atoi(std::getenv("RM_TILE_ORDER")) : kDefaultTileOrder;
   const int orderMode = g_tileOrderMode.load() >= 0 ? g_tileOrderMode.load() : envOrder;
   const int tileCount = (int)(rgrid.x * rgrid.y);
-  const bool ordered = orderMode > 0 && !pipeline && !envFeatures && !textured && !g->isTwoD && count == 0 &&
+  const bool ordered = orderMode > 0 && !pipeline && !wavefront && !envFeatures && !textured && !g->isTwoD && count == 0 &&
                        tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
   uint32_t *oCost = nullptr, *oHist = nullptr;
   int32_t *oOrder = nullptr;
@@ -756,6 +805,32 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       hipLaunchKernelGGL(bulbB_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, wsB);
     }
     if ((st = stamp(4)) != RM_OK) return st;
+  } else if (wavefront) {
+    if (ds.numCUs == 0) {
+      hipDeviceProp_t prop;
+      HIP_OK(hipGetDeviceProperties(&prop, dev));
+      ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // tuning knobs for A/B runs (defaults are the measured best)
+    static const int wavesPerCU = std::getenv("RM_WF_WAVES_PER_CU") ? std::atoi(std::getenv("RM_WF_WAVES_PER_CU")) : 4 * RM_WF_MARCH_WAVES;
+    static const int flushThr = std::getenv("RM_WF_FLUSH") ? std::atoi(std::getenv("RM_WF_FLUSH")) : 16;
+    const int marchWaves = ds.numCUs * (wavesPerCU > 0 ? wavesPerCU : 4 * RM_WF_MARCH_WAVES);
+    // hit-slot capacity: every ray may hit, plus one partly used 64-slot chunk per persistent wave
+    const size_t cap = (size_t)nRows * W + (size_t)kSlotChunk * marchWaves;
+    WfWs ws;
+    if ((st = wavefront_workspace(cap, numLights, stream, &ws)) != RM_OK) return st;
+    HIP_OK(hipMemsetAsync(ws.counters, 0, WF_STRIDE * (kWfMaxBounces + 2) * sizeof(uint32_t), stream));
+    const dim3 mgrid(marchWaves), mblock(64), dense(ds.numCUs * 16);
+    const int thr = flushThr > 0 && flushThr <= 64 ? flushThr : 16;
+    if ((st = stamp(0)) != RM_OK) return st;
+    for (int gen = 0; gen <= wfBounces; gen++) {
+      if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      else hipLaunchKernelGGL((wf_march_kernel<1>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      hipLaunchKernelGGL(wf_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws, gen);
+      if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      hipLaunchKernelGGL(wf_light_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws, gen, wfBounces);
+    }
+    if ((st = stamp(1)) != RM_OK) return st;
   } else {
     if ((st = stamp(0)) != RM_OK) return st;
     // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
@@ -787,6 +862,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if ((st = stamp((ordered && haveCost) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
+  ds.lastPath = pipeline ? path : (wavefront ? 5 : 1);
   if (timing) ds.timed.push_back(tl);
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
@@ -1044,8 +1120,14 @@ int rm_set_tile_order(int mode) {
   g_tileOrderMode.store(mode);
   return RM_OK;
 }
+int rm_debug_last_path(void) {
+  DeviceState *ds;
+  if (current_device_state(&ds)) return -1;
+  std::lock_guard<std::mutex> lock(ds->mu);
+  return ds->lastPath;
+}
 int rm_set_kernel_path(int path) {
-  if (path < 0 || path > 4) { set_error("kernel path must be 0..4"); return RM_ERR_INVALID_ARGUMENT; }
+  if (path < 0 || path > 5) { set_error("kernel path must be 0..5"); return RM_ERR_INVALID_ARGUMENT; }
   g_kernelPath.store(path);
   return RM_OK;
 }

@@ -57,7 +57,7 @@ def main():
     cases.append(("area light (LTC) + point light, reflection 1920x1080", ta, al[1], 1920, 1080))
     only = os.environ.get("RM_ONLY")  # e.g. RM_ONLY=C5: a single configuration (PMC passes profile one kernel at a time)
     if only:
-        cases = [c for c in cases if c[0].startswith(only + " ")]
+        cases = [c for c in cases if any(c[0].startswith(o + " ") for o in only.split(","))]
     rows = ["| configuration | kernel ms | Mpixels/s | sceneEvals (reference / executed) |", "|---|---|---|---|"]
     for name, t, s, W, H in cases:
         out = torch.empty((H, W, 4), dtype=torch.float32, device=r.device)
