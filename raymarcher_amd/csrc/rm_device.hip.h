@@ -284,16 +284,20 @@ RM_DEV float sdSierpinski(V3 p) {
 //    instructions per level);
 //  * the division by s = 3^(m+1) uses the exact constant-divisor sequence (RM_DIVC) for the first eight levels: its
 //    numerator is min(…) − 1 with min(…) a number near 1, i.e. 0 or at least 2^-24 in magnitude.
+// Inside a level every operand of the three maxima and of the minimum is a freshly computed |·| (canonical, >= +0), so the
+// compiler's own v_max_f32 with |·| source modifiers / v_min3_f32 give the contract's bits (same comparator as the v_min_f32 /
+// v_max_f32 pair of rm_math, no NaN-quieting prologue needed) — and, unlike the inline-asm spellings, carry no hazard s_nops.
+// TRAP = false (shadow marches, normal and AO taps) drops the orbit-trap bookkeeping (res is then unspecified).
+template <bool TRAP>
 RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
   float d = sdBox(p, 1.0f, 1.0f, 1.0f);
-  res = v4(d, 1.0f, 0.0f, 0.0f);
+  float ty = 1.0f, tz = 0.0f;
   const float ani = smoothstep_(-0.2f, 0.2f, -cos_(0.5f * sb->g.iTime));
   const float off = 1.5f * sin_(0.01f * sb->g.iTime);
   const int levels = sb->s.mengerLevels;
   const bool still = __builtin_amdgcn_readfirstlane((int)(ani == 0.0f)) != 0;  // iTime is a uniform
-  float s = 1.0f;
-  // one level (frag:1057-1069); DIVC > 0: the divisor 3^(m+1) as a compile-time constant
-  auto level = [&](int m, float divc) __attribute__((always_inline)) {
+  // one level (frag:1057-1069); hs = 0.5·s = 0.5·3^m and the divisor 3^(m+1) as compile-time constants (DIVC > 0)
+  auto level = [&](int m, float divc, float hs, float sNext) __attribute__((always_inline)) {
     if (!still) {
       V3 v = v3(p.x + off, p.y + off, p.z + off);
       V3 mv = v3(fma(-0.80f, v.z, fma(0.00f, v.y, 0.60f * v.x)), fma(0.00f, v.z, fma(1.00f, v.y, 0.00f * v.x)),
@@ -301,30 +305,37 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
       p = mix(p, mv, ani);
     }
     // mod(·, 2) − 1 as 2·fract(·/2) − 1 (contract: rm_mod_pow2): 2·f is exact, so the fma rounds exactly like the subtraction
-    const float hs = 0.5f * s;
     V3 a = v3(fma(2.0f, fract_(p.x * hs), -1.0f), fma(2.0f, fract_(p.y * hs), -1.0f), fma(2.0f, fract_(p.z * hs), -1.0f));
-    s = s * 3.0f;
     float rx = fabs_(fma(-3.0f, fabs_(a.x), 1.0f)), ry = fabs_(fma(-3.0f, fabs_(a.y), 1.0f)),
           rz = fabs_(fma(-3.0f, fabs_(a.z), 1.0f));
-    float da = max_(rx, ry), db = max_(ry, rz), dc = max_(rz, rx);
-    const float num = min_(da, min_(db, dc)) - 1.0f;
-    const float c = (divc > 0.0f) ? divc_(num, divc, 1.0f / divc) : (num / s);
-    if (c > d) {
-      d = c;
-      res = v4(d, min_(res.y, ((0.2f * da) * db) * dc), (1.0f + (float)m) / 4.0f, 0.0f);
+    float da = __builtin_fmaxf(rx, ry), db = __builtin_fmaxf(ry, rz), dc = __builtin_fmaxf(rz, rx);
+    const float num = __builtin_fminf(da, __builtin_fminf(db, dc)) - 1.0f;
+    const float c = (divc > 0.0f) ? divc_(num, divc, 1.0f / divc) : (num / sNext);
+    const bool up = c > d;
+    d = up ? c : d;
+    if (TRAP) {
+      const float t = __builtin_fminf(ty, ((0.2f * da) * db) * dc);
+      ty = up ? t : ty;
+      tz = up ? ((1.0f + (float)m) / 4.0f) : tz;
     }
   };
   // the first eight levels written out (straight-line code, constants as immediates, one scalar test per level); deeper
   // ones — far below pixel size — in a loop with the IEEE division
-  if (levels > 0) level(0, 3.0f);
-  if (levels > 1) level(1, 9.0f);
-  if (levels > 2) level(2, 27.0f);
-  if (levels > 3) level(3, 81.0f);
-  if (levels > 4) level(4, 243.0f);
-  if (levels > 5) level(5, 729.0f);
-  if (levels > 6) level(6, 2187.0f);
-  if (levels > 7) level(7, 6561.0f);
-  for (int m = 8; m < levels; m++) level(m, 0.0f);
+  if (levels > 0) level(0, 3.0f, 0.5f, 0.0f);
+  if (levels > 1) level(1, 9.0f, 1.5f, 0.0f);
+  if (levels > 2) level(2, 27.0f, 4.5f, 0.0f);
+  if (levels > 3) level(3, 81.0f, 13.5f, 0.0f);
+  if (levels > 4) level(4, 243.0f, 40.5f, 0.0f);
+  if (levels > 5) level(5, 729.0f, 121.5f, 0.0f);
+  if (levels > 6) level(6, 2187.0f, 364.5f, 0.0f);
+  if (levels > 7) level(7, 6561.0f, 1093.5f, 0.0f);
+  float s = 6561.0f;
+  for (int m = 8; m < levels; m++) {
+    const float hs = 0.5f * s;
+    s = s * 3.0f;
+    level(m, 0.0f, hs, s);
+  }
+  res = v4(d, ty, tz, 0.0f);
   return d;
 }
 
@@ -365,7 +376,7 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
       case RM_RECTANGLE: d = sdBox(po, 0.5f, 0.5f, 0.0f); break;
       case RM_MANDELBROT: d = sdMandelBrot(sb, po.x, po.y); break;
       case RM_MANDELBULB: d = sdMandelBulb<COUNT, BULB && COUNT == 0, TRAP>(sb, po, res.trap, cnt); break;
-      case RM_MENGERSPONGE: d = sdMengerSponge(sb, po, res.trap); break;
+      case RM_MENGERSPONGE: d = sdMengerSponge<TRAP>(sb, po, res.trap); break;
       case RM_SIERPINSKI: d = sdSierpinski(po); break;
       default: continue;
     }
@@ -920,8 +931,13 @@ RM_DEV void primaryRay(const SceneBlock *sb, int px, int py, int W, int H, V3 &r
 #pragma unroll
   for (int k = 0; k < 4; k++) {  // both triangles from scalar registers, then a per-lane select (wave-uniform almost everywhere)
     const float (*A)[3][4] = sb->rayPlane[0], (*B)[3][4] = sb->rayPlane[1];
-    const float p0n = q.upper ? B[0][0][k] : A[0][0][k], p1n = q.upper ? B[0][1][k] : A[0][1][k], p2n = q.upper ? B[0][2][k] : A[0][2][k];
-    const float p0f = q.upper ? B[1][0][k] : A[1][0][k], p1f = q.upper ? B[1][1][k] : A[1][1][k], p2f = q.upper ? B[1][2][k] : A[1][2][k];
+    // readfirstlane pins each coefficient to a scalar register: otherwise the compiler may turn the select of two loads into
+    // one per-lane load through a selected pointer (six global_load_dwordx4 in the wavefront pipeline's refill path)
+    auto sc = [](float v) { return u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(v))); };
+    const float p0n = q.upper ? sc(B[0][0][k]) : sc(A[0][0][k]), p1n = q.upper ? sc(B[0][1][k]) : sc(A[0][1][k]),
+                p2n = q.upper ? sc(B[0][2][k]) : sc(A[0][2][k]);
+    const float p0f = q.upper ? sc(B[1][0][k]) : sc(A[1][0][k]), p1f = q.upper ? sc(B[1][1][k]) : sc(A[1][1][k]),
+                p2f = q.upper ? sc(B[1][2][k]) : sc(A[1][2][k]);
     nc[k] = fma(q.J, p2n, fma(q.I, p1n, p0n));
     fc4[k] = fma(q.J, p2f, fma(q.I, p1f, p0f));
   }

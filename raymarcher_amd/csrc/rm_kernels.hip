@@ -812,20 +812,22 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     // tuning knobs for A/B runs (defaults are the measured best)
-    static const int wavesPerCU = std::getenv("RM_WF_WAVES_PER_CU") ? std::atoi(std::getenv("RM_WF_WAVES_PER_CU")) : 4 * RM_WF_MARCH_WAVES;
+    static const int wavesPerSimd = std::getenv("RM_WF_WAVES_PER_SIMD") ? std::atoi(std::getenv("RM_WF_WAVES_PER_SIMD")) : 0;
     static const int flushThr = std::getenv("RM_WF_FLUSH") ? std::atoi(std::getenv("RM_WF_FLUSH")) : 16;
-    const int marchWaves = ds.numCUs * (wavesPerCU > 0 ? wavesPerCU : 4 * RM_WF_MARCH_WAVES);
+    // persistent waves: as many as are resident at once (4 SIMDs per CU x the kernel's register budget)
+    auto waves = [&](int kind) { return ds.numCUs * 4 * (wavesPerSimd > 0 && wavesPerSimd < wfMarchWaves(kind) ? wavesPerSimd : wfMarchWaves(kind)); };
+    const int marchWaves = waves(2) > waves(0) ? waves(2) : waves(0);
     // hit-slot capacity: every ray may hit, plus one partly used 64-slot chunk per persistent wave
     const size_t cap = (size_t)nRows * W + (size_t)kSlotChunk * marchWaves;
     WfWs ws;
     if ((st = wavefront_workspace(cap, numLights, stream, &ws)) != RM_OK) return st;
     HIP_OK(hipMemsetAsync(ws.counters, 0, WF_STRIDE * (kWfMaxBounces + 2) * sizeof(uint32_t), stream));
-    const dim3 mgrid(marchWaves), mblock(64), dense(ds.numCUs * 16);
+    const dim3 pgrid(waves(0)), mgrid(waves(2)), mblock(64), dense(ds.numCUs * 16);
     const int thr = flushThr > 0 && flushThr <= 64 ? flushThr : 16;
     if ((st = stamp(0)) != RM_OK) return st;
     for (int gen = 0; gen <= wfBounces; gen++) {
-      if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
-      else hipLaunchKernelGGL((wf_march_kernel<1>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      else hipLaunchKernelGGL((wf_march_kernel<1>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
       hipLaunchKernelGGL(wf_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws, gen);
       if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
       hipLaunchKernelGGL(wf_light_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws, gen, wfBounces);

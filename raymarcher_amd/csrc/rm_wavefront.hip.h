@@ -82,15 +82,21 @@ RM_DEV void wfLightRay(const RmLight &li, V3 p, float far, V3 &L, float &maxT) {
   }
 }
 
+// Register budgets (waves per SIMD) of the march kernels: the shadow kernel fits 64 VGPRs; the primary / bounce kernels carry
+// the ray set-up of their refill path (primaryRay's IEEE divisions) and spill 15 / 5 registers at that budget.
 #ifndef RM_WF_MARCH_WAVES
 #define RM_WF_MARCH_WAVES 8
 #endif
+#ifndef RM_WF_PRIMARY_WAVES
+#define RM_WF_PRIMARY_WAVES 6
+#endif
+constexpr int wfMarchWaves(int kind) { return kind == 2 ? RM_WF_MARCH_WAVES : RM_WF_PRIMARY_WAVES; }
 constexpr uint32_t kWfRayChunk = 512;
 
 // KIND 0: primary rays from the tile-major pixel cursor; 1: bounce rays of generation `gen` from the ray queue;
 // 2: shadow rays of generation `gen`, ray id = light·(hit slots) + hit slot.
 template <int KIND>
-__global__ __launch_bounds__(64, RM_WF_MARCH_WAVES) void wf_march_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+__global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                                           int nRows, float4 *__restrict__ out,
                                                                           float4 *__restrict__ bright, WfWs ws, int gen,
                                                                           int flushThreshold) {
@@ -138,8 +144,15 @@ __global__ __launch_bounds__(64, RM_WF_MARCH_WAVES) void wf_march_kernel(const S
               src = (uint32_t)(r * W + x);
               primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
               end = sceneCullEnd(sb, ro, rd, far, cullR2);
-              depth = 0.0f; steps = 0;
-              st = ST_MARCH;
+              if (far >= 0.0f && end < 0.0f) {
+                // the ray starts outside the scene's bounding ball and never enters it: its one evaluation cannot hit (the
+                // ball's margin keeps every distance value above the hit threshold) and then depth 0 > end — the background
+                out[src] = make_float4(bg.x, bg.y, bg.z, 1.0f);
+                if (bright) bright[src] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+              } else {
+                depth = 0.0f; steps = 0;
+                st = ST_MARCH;
+              }
             }
           } else if (KIND == 1) {
             const float4 O = ws.rayO[cur][id], D = ws.rayD[cur][id];
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(64, RM_WF_MARCH_WAVES) void wf_march_kernel(const S
     float hitD = 0.0f, hitTz = 0.0f;
     int hitObj = -1;
     if (st == ST_MARCH) {
-      const SceneMin c = sdScene<false, 0, false>(sb, madd(rd, depth, ro), none);
+      const SceneMin c = sdScene<false, 0, KIND != 2>(sb, madd(rd, depth, ro), none);
       const bool hit = fabs_(c.d) < kSurfaceDist;
       bool fin = hit || depth > end;
       if (!fin) {
