@@ -654,9 +654,14 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 }
 
 // Whether the wavefront pipeline is expected to beat the one-lane-per-pixel kernel on this scene (measured).
+// Measured (profiles/r03_b_wavefront.md): with reflection bounces the regrouping wins from 4K frames up (8K Menger frame
+// with two bounces 39.0 -> 24.4 ms, the same scene at 4K 12.0 -> 9.2 ms, reflections_complex.json at 4K with two bounces
+// 25.4 -> 20.2 ms, with one 16.8 -> 16.4 ms); at 1080p its dozen launches of persistent waves cost more than the idle lanes
+// they remove (4.5 -> 5.2 ms, 5.4 -> 7.2 ms), and without secondary rays the one-lane-per-pixel kernel keeps 89-95 % of its
+// lanes busy by itself (directional_light_2.json: 1.3 ms against 3.5 ms).
 bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels) {
-  (void)objs; (void)numObjects; (void)bounces; (void)pixels;
-  return false;
+  (void)objs; (void)numObjects;
+  return bounces >= 1 && pixels >= (size_t(1) << 22);
 }
 
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -817,8 +822,15 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // persistent waves: as many as are resident at once (4 SIMDs per CU x the kernel's register budget)
     auto waves = [&](int kind) { return ds.numCUs * 4 * (wavesPerSimd > 0 && wavesPerSimd < wfMarchWaves(kind) ? wavesPerSimd : wfMarchWaves(kind)); };
     const int marchWaves = waves(2) > waves(0) ? waves(2) : waves(0);
-    // hit-slot capacity: every ray may hit, plus one partly used 64-slot chunk per persistent wave
-    const size_t cap = (size_t)nRows * W + (size_t)kSlotChunk * marchWaves;
+    static const int envSlotChunk = std::getenv("RM_WF_SLOT_CHUNK") ? std::atoi(std::getenv("RM_WF_SLOT_CHUNK")) : 0;
+    static const int envRayChunk = std::getenv("RM_WF_RAY_CHUNK") ? std::atoi(std::getenv("RM_WF_RAY_CHUNK")) : 0;
+    static const int envPixelChunk = std::getenv("RM_WF_PIXEL_CHUNK") ? std::atoi(std::getenv("RM_WF_PIXEL_CHUNK")) : 0;
+    const uint32_t slotChunk = envSlotChunk >= 64 ? (uint32_t)envSlotChunk : kWfSlotChunk;  // >= 64: one trip's hits fit one fresh chunk
+    static const int envMaxChunk = std::getenv("RM_WF_MAX_CHUNK") ? std::atoi(std::getenv("RM_WF_MAX_CHUNK")) : 0;
+    const uint32_t maxChunk = envMaxChunk > 0 ? (uint32_t)envMaxChunk : 0u;  // 0: fixed chunks (guided chunks measured slower)
+    const uint32_t rayChunk = envRayChunk > 0 ? (uint32_t)envRayChunk : wfRayChunk(1), pixelChunk = envPixelChunk > 0 ? (uint32_t)envPixelChunk : wfRayChunk(0);
+    // hit-slot capacity: every ray may hit, plus one partly used chunk of slots per persistent wave
+    const size_t cap = (size_t)nRows * W + (size_t)slotChunk * marchWaves;
     WfWs ws;
     if ((st = wavefront_workspace(cap, numLights, stream, &ws)) != RM_OK) return st;
     HIP_OK(hipMemsetAsync(ws.counters, 0, WF_STRIDE * (kWfMaxBounces + 2) * sizeof(uint32_t), stream));
@@ -826,10 +838,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     const int thr = flushThr > 0 && flushThr <= 64 ? flushThr : 16;
     if ((st = stamp(0)) != RM_OK) return st;
     for (int gen = 0; gen <= wfBounces; gen++) {
-      if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
-      else hipLaunchKernelGGL((wf_march_kernel<1>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, pixelChunk, maxChunk, slotChunk);
+      else hipLaunchKernelGGL((wf_march_kernel<1>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
       hipLaunchKernelGGL(wf_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws, gen);
-      if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr);
+      if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
       hipLaunchKernelGGL(wf_light_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws, gen, wfBounces);
     }
     if ((st = stamp(1)) != RM_OK) return st;

@@ -91,7 +91,21 @@ RM_DEV void wfLightRay(const RmLight &li, V3 p, float far, V3 &L, float &maxT) {
 #define RM_WF_PRIMARY_WAVES 6
 #endif
 constexpr int wfMarchWaves(int kind) { return kind == 2 ? RM_WF_MARCH_WAVES : RM_WF_PRIMARY_WAVES; }
-constexpr uint32_t kWfRayChunk = 512;
+// Cursor granularity.  One device counter sustains ≈88 atomics per µs (measured, rm_bulb_pipeline.hip.h): with 64-slot hit
+// chunks the 20 M primary hits of the 8K Menger frame were 311 k atomics ≈ 3.5 ms of a 5.0 ms kernel (the bounce kernels
+// likewise), so hit slots are reserved 1024 at a time (a wave's unused remainder becomes holes) and rays 512 / 1024.
+#ifndef RM_WF_SLOT_CHUNK
+#define RM_WF_SLOT_CHUNK 256
+#endif
+#ifndef RM_WF_RAY_CHUNK
+#define RM_WF_RAY_CHUNK 256
+#endif
+#ifndef RM_WF_PIXEL_CHUNK
+#define RM_WF_PIXEL_CHUNK 256
+#endif
+constexpr uint32_t kWfSlotChunk = RM_WF_SLOT_CHUNK;
+constexpr uint32_t kWfStripes = 64;  // power of two
+constexpr uint32_t wfRayChunk(int kind) { return kind == 0 ? RM_WF_PIXEL_CHUNK : RM_WF_RAY_CHUNK; }
 
 // KIND 0: primary rays from the tile-major pixel cursor; 1: bounce rays of generation `gen` from the ray queue;
 // 2: shadow rays of generation `gen`, ray id = light·(hit slots) + hit slot.
@@ -99,12 +113,17 @@ template <int KIND>
 __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                                           int nRows, float4 *__restrict__ out,
                                                                           float4 *__restrict__ bright, WfWs ws, int gen,
-                                                                          int flushThreshold) {
+                                                                          int flushThreshold, uint32_t rayChunk, uint32_t maxChunk, uint32_t slotChunk) {
   uint32_t *cnt = ws.counters + WF_STRIDE * gen;
   const int tilesX = (W + 7) >> 3, tilesY = (nRows + 7) >> 3;
   const uint32_t nSlots = (KIND == 2) ? cnt[WF_HITS] : 0u;
   const uint32_t total = (KIND == 0) ? (uint32_t)tilesX * (uint32_t)tilesY * 64u
                          : (KIND == 1) ? ws.counters[WF_STRIDE * (gen - 1) + WF_NEXT] : nSlots * (uint32_t)sb->numLights;
+  // Expensive rays cluster in the source order (a region of grazing shadow rays that all run 256 steps is contiguous in the
+  // hit list): a wave's chunk of consecutive ids would be all cheap or all expensive, and the waves that drew the expensive
+  // chunks end the kernel alone.  So consecutive 64-id blocks of the cursor map to kWfStripes stripes of the source, and every
+  // chunk samples the whole source.
+  const uint32_t stripeBlocks = (((total + 63u) >> 6) + kWfStripes - 1u) / kWfStripes, totalPad = stripeBlocks * kWfStripes * 64u;
   const int maxSteps = sb->s.maxSteps;
   const float far = sb->cam.initialFar;
   const bool soft = sb->s.enableSoftShadow != 0;
@@ -128,17 +147,26 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
     if (mMarch == 0 ? (mWait != 0) : ((int)__popcll(mWait) >= flushThreshold)) {
       // ---- refill the waiting lanes from the wave's chunk of the source ----
       if (srcCur == srcEnd && !exhausted) {
-        srcCur = waveReserve(&cnt[KIND == 2 ? WF_SHADOW : WF_SRC], kWfRayChunk);
-        srcEnd = srcCur + kWfRayChunk;
-        if (srcCur >= total) { exhausted = true; srcEnd = srcCur; }
-        else if (srcEnd > total) srcEnd = total;
+        // guided self-scheduling: a chunk is the work still unclaimed (as of this wave's previous reservation) split over
+        // four rounds of all waves, between `rayChunk` (the floor, at the end of the kernel) and `maxChunk`
+        uint32_t want = (totalPad - srcEnd) / (4u * gridDim.x);
+        const uint32_t hi = maxChunk > rayChunk ? maxChunk : rayChunk;  // maxChunk <= rayChunk: fixed chunks
+        want = want < rayChunk ? rayChunk : (want > hi ? hi : want);
+        srcCur = waveReserve(&cnt[KIND == 2 ? WF_SHADOW : WF_SRC], want);
+        srcEnd = srcCur + want;
+        if (srcCur >= totalPad) { exhausted = true; srcEnd = srcCur; }
+        else if (srcEnd > totalPad) srcEnd = totalPad;
       }
       const uint32_t avail = srcEnd - srcCur, n = (uint32_t)__popcll(mWait);
       if (st == ST_NEED) {
         const uint32_t rank = (uint32_t)__popcll(mWait & lt);
         if (rank < avail) {
-          const uint32_t id = srcCur + rank;
-          if (KIND == 0) {
+          // cursor position → ray id: 64-id blocks dealt round-robin into kWfStripes far-apart stripes of the source
+          const uint32_t cid = srcCur + rank, blk = cid >> 6;
+          const uint32_t id = (((blk & (kWfStripes - 1u)) * stripeBlocks + blk / kWfStripes) << 6) | (cid & 63u);
+          if (id >= total) {
+            // padding of the striped id space: nothing to do, stays NEED
+          } else if (KIND == 0) {
             int x, r;
             if (decodePixel(id, tilesX, W, nRows, x, r)) {  // else: padding lane of an edge tile, stays NEED
               src = (uint32_t)(r * W + x);
@@ -238,13 +266,13 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
       if (mHit) {
         const uint32_t n = (uint32_t)__popcll(mHit), avail = slotEnd - slotCur;
         uint32_t fresh = 0;
-        if (n > avail) fresh = waveReserve(&cnt[WF_HITS], kSlotChunk);  // the old chunk gets exactly filled
+        if (n > avail) fresh = waveReserve(&cnt[WF_HITS], slotChunk);  // the old chunk gets exactly filled
         if (hitNow) {
           const uint32_t rank = (uint32_t)__popcll(mHit & lt);
           const uint32_t slot = (rank < avail) ? (slotCur + rank) : (fresh + (rank - avail));
           ws.hit[slot] = make_int4((int)src, (int)f2u(hitD), hitObj, (int)f2u(hitTz));
         }
-        if (n > avail) { slotCur = fresh + (n - avail); slotEnd = fresh + kSlotChunk; }
+        if (n > avail) { slotCur = fresh + (n - avail); slotEnd = fresh + slotChunk; }
         else slotCur += n;
       }
     }

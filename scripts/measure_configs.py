@@ -33,7 +33,7 @@ def main():
     t = Scene(path=os.path.join(S, "lighting", "directional_light_2.json")).tables(3840, 2160)
     cases.append(("C2@4K the same scene and options at 3840x2160", t, abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1), 3840, 2160))
     t = Scene(path=os.path.join(S, "lighting", "reflections_complex.json")).tables(3840, 2160)
-    cases.append(("RC reflections_complex.json 3840x2160, reflection 2 bounces + Perlin bump", t, abi.default_settings(enableReflection=1), 3840, 2160))
+    cases.append(("RC reflections_complex.json 3840x2160, reflection (1 bounce) + Perlin bump", t, abi.default_settings(enableReflection=1), 3840, 2160))
     cases.append(("C3 Mandelbulb p8 12 iters 3840x2160 (headline)", scenes.mandelbulb(3840, 2160), abi.default_settings(fractalIters=12), 3840, 2160))
     cases.append(("C3' same, RM_FEAT_BULB_POWER8_ALGEBRAIC", scenes.mandelbulb(3840, 2160),
                   abi.default_settings(fractalIters=12, features=abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC), 3840, 2160))
@@ -47,6 +47,16 @@ def main():
     cases.append(("C5 unit_mengersponge.json, 5 levels, reflection 2 bounces 7680x4320 (1 GPU)",
                   Scene(path=os.path.join(S, "simple", "unit_mengersponge.json")).tables(7680, 4320),
                   abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1), 7680, 4320))
+    for tag, (w, hh) in (("C5@4K", (3840, 2160)), ("C5@1080p", (1920, 1080))):
+        cases.append((f"{tag} unit_mengersponge.json, 5 levels, reflection 2 bounces {w}x{hh}",
+                      Scene(path=os.path.join(S, "simple", "unit_mengersponge.json")).tables(w, hh),
+                      abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1), w, hh))
+    cases.append(("RC@1080p reflections_complex.json 1920x1080, reflection + Perlin bump",
+                  Scene(path=os.path.join(S, "lighting", "reflections_complex.json")).tables(1920, 1080),
+                  abi.default_settings(enableReflection=1), 1920, 1080))
+    cases.append(("RC2 reflections_complex.json 3840x2160, reflection 2 bounces + Perlin bump",
+                  Scene(path=os.path.join(S, "lighting", "reflections_complex.json")).tables(3840, 2160),
+                  abi.default_settings(enableReflection=1, numReflection=2), 3840, 2160))
     sea = tg.resource_case("sea_sky", 3840, 2160)
     ts = tg.tables_of(sea[0])
     ts.noise = sea[2]["noise"]
