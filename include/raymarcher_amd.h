@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 3
+#define RM_ABI_VERSION 4
 
 /* Capacity limits — src/realtime.h:17-27 (MAX_NUM_LIGHTS 10, MAX_NUM_SHAPES 30). */
 #define RM_MAX_LIGHTS 10
@@ -269,9 +269,12 @@ int rm_gather_tiles(RmGather *g, const float *const *d_tiles, float *d_gathered,
 
 /* Fractal / shading work counters of the last counted render (debug/roofline accounting). */
 typedef struct RmCounters {
-  uint64_t sceneEvals;   /* sdScene evaluations (frag:1406) */
-  uint64_t bulbIters;    /* Mandelbulb inner iterations (frag:785-799) */
-  uint64_t hitPixels;    /* pixels whose primary ray hit */
+  uint64_t sceneEvals;    /* sdScene evaluations (frag:1406) */
+  uint64_t bulbIters;     /* Mandelbulb inner iterations (frag:785-799) */
+  uint64_t hitPixels;     /* pixels whose primary ray hit */
+  uint64_t shadedPoints;  /* surface points shaded by render() (frag:2333-2373): primary hits and reflection / refraction hits */
+  uint64_t terrainEvals;  /* fbm_9 evaluations (frag:630-644): terrain height samples of the TERRAIN layer */
+  uint64_t cloudEvals;    /* fbmd_8 evaluations (frag:647-667): cloud density samples (CLOUD) and the terrain's bump / cloud shadow */
 } RmCounters;
 /* Same as rm_render but also accumulates counters with device atomics (slower; synchronises).  Counts the REFERENCE's
  * work: every evaluation the shader as written performs, i.e. without the bit-identical shortcuts of the production
@@ -280,9 +283,13 @@ int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects,
                       int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
                       int rowEnd, float *d_rgba, float *d_bright, RmCounters *out);
 /* mode RM_COUNT_REFERENCE = rm_render_counted; RM_COUNT_EXECUTED counts the work the production kernel really executes
- * (shortcuts honoured) — the pair gives the algorithmic and the executed figure of the roofline.  Scenes that need the
- * procedural layers or samplers are rendered but not counted (counters stay 0). */
+ * (shortcuts honoured) — the pair gives the algorithmic and the executed figure of the roofline. */
 enum { RM_COUNT_REFERENCE = 1, RM_COUNT_EXECUTED = 2 };
+/* rm_render_counted_ex with samplers (res may be NULL): scenes with procedural layers or samplers are counted in mode
+ * RM_COUNT_REFERENCE only (their kernels have no bit-identical shortcuts to tell apart). */
+int rm_render_counted_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
+                          int numLights, const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H,
+                          int rowBegin, int rowEnd, float *d_rgba, float *d_bright, int mode, RmCounters *out);
 int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
                          int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
                          int rowEnd, float *d_rgba, float *d_bright, int mode, RmCounters *out);

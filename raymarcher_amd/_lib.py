@@ -49,6 +49,8 @@ SIGNATURES = {
                                                   _P(abi.RmCounters)]),
     "rm_render_counted_ex": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                      _P(abi.RmCounters)]),
+    "rm_render_counted_res": (C.c_int, _SCENE_ARGS + [_P(abi.RmResources), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                      C.c_int, _P(abi.RmCounters)]),
     "rm_render_clocked": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_void_p, _P(C.c_double), C.c_void_p]),
     "rm_set_timing": (C.c_int, [C.c_int]),
     "rm_get_timing": (C.c_int, [_P(C.c_double), _P(C.c_int)]),

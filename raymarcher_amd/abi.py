@@ -5,7 +5,7 @@ struct against the library's own `rm_abi_sizeof`.
 """
 import ctypes as C
 
-RM_ABI_VERSION = 3
+RM_ABI_VERSION = 4
 RM_COUNT_REFERENCE, RM_COUNT_EXECUTED = 1, 2
 RM_MAX_LIGHTS = 10
 RM_MAX_OBJECTS = 30
@@ -88,7 +88,8 @@ class RmSettings(C.Structure):
 
 
 class RmCounters(C.Structure):
-    _fields_ = [("sceneEvals", C.c_uint64), ("bulbIters", C.c_uint64), ("hitPixels", C.c_uint64)]
+    _fields_ = [("sceneEvals", C.c_uint64), ("bulbIters", C.c_uint64), ("hitPixels", C.c_uint64),
+                ("shadedPoints", C.c_uint64), ("terrainEvals", C.c_uint64), ("cloudEvals", C.c_uint64)]
 
 
 class RmPostSettings(C.Structure):

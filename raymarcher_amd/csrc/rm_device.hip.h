@@ -47,6 +47,14 @@ RM_DEV V3 mix(V3 a, V3 b, float t) { return v3(mix_(a.x, b.x, t), mix_(a.y, b.y,
 
 constexpr float kSurfaceDist = 0.001f;  // frag:32
 
+// Per-lane work counters (only live in the counting instantiations; where nothing reads them the increments are dead code).
+// COUNT is a mode: 0 = no counters (production), 1 = count the REFERENCE's work (no bounding-ball culls, shadow rays of
+// dropped lights still marched — the algorithmic figure of the roofline), 2 = count the work the production kernel really
+// executes (culls and skips honoured).  evals = sdScene evaluations, iters = Mandelbulb iterations, shades = surface points
+// shaded by render() (normal + bump + Phong; primary hits and bounce hits), fbm9 / fbmd8 = terrain-height and cloud-noise
+// evaluations of the procedural layers (frag:630-667).
+struct Counters { unsigned long long evals, iters, shades, fbm9, fbmd8; };
+
 }  // namespace rm
 #include "rm_sampler.hip.h"
 #include "rm_env.hip.h"
@@ -98,10 +106,6 @@ struct MarchRes { int obj; float d; V4 trap; };
 struct Hit { V3 rd, p, n; int obj; };
 struct RenderOut { V3 col; int isEnv; float d; };
 
-// Per-lane work counters (only live in the counting instantiations).  COUNT is a mode: 0 = no counters (production),
-// 1 = count the REFERENCE's work (no bounding-ball culls, shadow rays of dropped lights still marched — the algorithmic
-// figure of the roofline), 2 = count the work the production kernel really executes (culls and skips honoured).
-struct Counters { unsigned long long evals, iters; };
 
 // ---- primitives (frag:832-894, 991-1019), unit sizes of sdMatch (frag:1262-1293) -------------------
 RM_DEV float sdBox(V3 p, float bx, float by, float bz) {
@@ -875,6 +879,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   }
   out.isEnv = 0;
   out.d = res.d;  // frag:2332
+  if (COUNT) cnt.shades++;
   V3 p = madd(rd, res.d, ro);
   V3 pn = getNormal<BULB, COUNT>(sb, p, cnt);
   if (sb->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p);
@@ -987,7 +992,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   RenderOut ri = render<BULB, COUNT, TEX, !ENV>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
   EnvOut e;
   e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
-  if (env) e = envLayers(feat, sb->noise, iTime, W, ro, rd, ri.d, bg);  // frag:2444-2456
+  if (env) e = envLayers(feat, sb->noise, iTime, W, ro, rd, ri.d, bg, cnt);  // frag:2444-2456
   if (ri.isEnv && !e.cloudHit && !e.terrainHit && !e.seaHit) {  // frag:2459-2465
     fragColor = v4(ri.col.x, ri.col.y, ri.col.z, 1.0f);
     return;
@@ -1019,7 +1024,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
       fil = mul(fil, cRefl);
       RenderOut res = render<BULB, COUNT, TEX, !ENV>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2506-2518 (a sea hit sets sr.isEnv, not res.isEnv: the bounce loop goes on)
-        EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, r, res.d, bg);
+        EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, r, res.d, bg, cnt);
         if (b.seaHit) res.col = b.scol;
         if (b.terrainHit) { res.col = b.tcol; res.isEnv = 1; }
         if (b.cloudHit) { res.col = b.ccol; res.isEnv = 1; }
@@ -1044,7 +1049,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
                   fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
       RenderOut res = render<BULB, COUNT, TEX, !ENV>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2555-2567
-        EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, rdOut, res.d, bg);
+        EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, rdOut, res.d, bg, cnt);
         if (b.seaHit) res.col = b.scol;
         if (b.terrainHit) res.col = b.tcol;
         if (b.cloudHit) res.col = b.ccol;

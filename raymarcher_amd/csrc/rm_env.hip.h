@@ -76,7 +76,8 @@ RM_DEV V4 noised3(V3 x) {  // frag:536-567
   float dz = fma(k7 * u.x, u.y, fma(k5, u.y, fma(k6, u.x, k3)));
   return v4(fma(2.0f, v, -1.0f), (2.0f * du.x) * dx, (2.0f * du.y) * dy, (2.0f * du.z) * dz);
 }
-RM_DEV float fbm_9(float x, float y) {  // frag:630-644
+RM_DEV float fbm_9(float x, float y, Counters &cnt) {  // frag:630-644
+  cnt.fbm9++;
   const float m00 = 1.9f * 0.80f, m01 = 1.9f * 0.60f, m10 = 1.9f * -0.60f, m11 = 1.9f * 0.80f;
   float a = 0.0f, b = 0.5f;
 #pragma unroll 1
@@ -89,7 +90,8 @@ RM_DEV float fbm_9(float x, float y) {  // frag:630-644
   }
   return a;
 }
-RM_DEV V4 fbmd_8(V3 x) {  // frag:647-667
+RM_DEV V4 fbmd_8(V3 x, Counters &cnt) {  // frag:647-667
+  cnt.fbmd8++;
   const M3 m3c = {{{0.00f, 0.80f, 0.60f}, {-0.80f, 0.36f, -0.48f}, {-0.60f, -0.48f, 0.64f}}};   // frag:118-120
   const M3 m3ic = {{{0.00f, -0.80f, -0.60f}, {0.80f, 0.36f, -0.48f}, {0.60f, -0.48f, 0.64f}}};  // frag:121-123
   const M3 fm3 = scaleM(m3c, 2.0f), fm3i = scaleM(m3ic, 2.0f);
@@ -107,8 +109,8 @@ RM_DEV V4 fbmd_8(V3 x) {  // frag:647-667
   }
   return v4(a, d.x, d.y, d.z);
 }
-RM_DEV void sdTerrain(float px, float pz, float &hgt, float &slope) {  // frag:737-746
-  float e = fbm_9(RM_DIVR_CONST(px, 2000.0f) + 1.0f, RM_DIVR_CONST(pz, 2000.0f) + -2.0f);
+RM_DEV void sdTerrain(float px, float pz, float &hgt, float &slope, Counters &cnt) {  // frag:737-746
+  float e = fbm_9(RM_DIVR_CONST(px, 2000.0f) + 1.0f, RM_DIVR_CONST(pz, 2000.0f) + -2.0f, cnt);
   slope = 1.0f - smoothstep_(0.12f, 0.13f, fabs_(e + 0.12f));
   e = fma(600.0f, e, 600.0f);
   hgt = fma(90.0f, smoothstep_(552.0f, 594.0f, e), e);
@@ -136,27 +138,27 @@ RM_DEV V3 fog(V3 col, float t) {  // frag:1519-1523
   V3 ext = v3(exp2_(k * 1.0f), exp2_(k * 1.5f), exp2_(k * 4.0f));
   return v3(fma(1.0f - ext.x, 0.55f, col.x * ext.x), fma(1.0f - ext.y, 0.55f, col.y * ext.y), fma(1.0f - ext.z, 0.58f, col.z * ext.z));
 }
-RM_DEV V4 cloudsFbm(float iTime, V3 pos) {  // frag:1950-1952
+RM_DEV V4 cloudsFbm(float iTime, V3 pos, Counters &cnt) {  // frag:1950-1952
   V3 q = v3(fma(0.07f, iTime, fma(pos.x, 0.0015f, 2.0f)), fma(0.07f, 0.5f * iTime, fma(pos.y, 0.0015f, 1.1f)),
             fma(0.07f, -0.15f * iTime, fma(pos.z, 0.0015f, 1.0f)));
-  return fbmd_8(q);
+  return fbmd_8(q, cnt);
 }
-RM_DEV float cloudsShadowFlat(float iTime, V3 ro, V3 rd) {  // frag:1954-1959
+RM_DEV float cloudsShadowFlat(float iTime, V3 ro, V3 rd, Counters &cnt) {  // frag:1954-1959
   float t = (900.0f - ro.y) / rd.y;
   if (t < 0.0f) return 1.0f;
-  return cloudsFbm(iTime, madd(rd, t, ro)).x;
+  return cloudsFbm(iTime, madd(rd, t, ro), cnt).x;
 }
 // frag:1961-1974; nnd = −d always (contract decision UB10, iq's original order).  Returns (density, gra.y).
-RM_DEV void cloudsMap(float iTime, V3 pos, float &den, float &gy, float &nnd) {
+RM_DEV void cloudsMap(float iTime, V3 pos, float &den, float &gy, float &nnd, Counters &cnt) {
   float d = fabs_(pos.y - 900.0f) - 4.0f;
   gy = (pos.y - 900.0f > 0.0f) ? 1.0f : ((pos.y - 900.0f < 0.0f) ? -1.0f : 0.0f);
-  V4 n = cloudsFbm(iTime, pos);
+  V4 n = cloudsFbm(iTime, pos, cnt);
   d = fma(400.0f * n.x, fma(0.3f, gy, 0.7f), d);
   nnd = -d;
   den = (d > 0.0f) ? -d : min_(RM_DIVR_CONST(-d, 100.0f), 0.25f);
   gy = (d > 0.0f) ? 0.0f : gy;
 }
-RM_DEV bool cloudMarch(float iTime, int steps, V3 ro, V3 rd, float minT, float maxT, V4 &sum) {  // frag:1976-2026
+RM_DEV bool cloudMarch(float iTime, int steps, V3 ro, V3 rd, float minT, float maxT, V4 &sum, Counters &cnt) {  // frag:1976-2026
   bool hasHit = false;
   float t = minT, thickness = 0.0f;
   const V3 sunColor = getSunColor(), sunDir = getSunDir();
@@ -164,12 +166,12 @@ RM_DEV bool cloudMarch(float iTime, int steps, V3 ro, V3 rd, float minT, float m
   for (int i = 0; i < steps; i++) {
     V3 pos = madd(rd, t, ro);
     float den, gy, nnd;
-    cloudsMap(iTime, pos, den, gy, nnd);
+    cloudsMap(iTime, pos, den, gy, nnd, cnt);
     float dt = max_(0.3f, 0.011f * t);
     if (den > 0.001f) {
       hasHit = true;
       float den2, gy2, kk;
-      cloudsMap(iTime, madd(sunDir, 70.0f, pos), den2, gy2, kk);
+      cloudsMap(iTime, madd(sunDir, 70.0f, pos), den2, gy2, kk, cnt);
       float sha = 1.0f - smoothstep_(-200.0f, 200.0f, kk);
       sha = sha * 1.5f;
       V3 nor = normalize(v3(0.0f, gy, 0.0f));
@@ -203,7 +205,7 @@ RM_DEV bool cloudMarch(float iTime, int steps, V3 ro, V3 rd, float minT, float m
   return hasHit;
 }
 // frag:2031-2057; blue-noise sample = 0 (texture blob missing from the reference checkout), FRAME = 1.
-RM_DEV V3 cloudRender(float iTime, V3 ro, V3 rd, V3 bg, bool &hit, float maxT) {
+RM_DEV V3 cloudRender(float iTime, V3 ro, V3 rd, V3 bg, bool &hit, float maxT, Counters &cnt) {
   float minT = 0.0f;
   float tl = (600.0f - ro.y) / rd.y, th = (1200.0f - ro.y) / rd.y;
   hit = false;
@@ -213,12 +215,12 @@ RM_DEV V3 cloudRender(float iTime, V3 ro, V3 rd, V3 bg, bool &hit, float maxT) {
   V4 sum = v4(0.0f, 0.0f, 0.0f, 0.0f);
   float off = (float)(1 % 64) + 0.61803398875f;
   minT = fma(0.3f, fract_(off + 0.0f), minT);
-  hit = cloudMarch(iTime, 128, ro, rd, minT, maxT, sum);
+  hit = cloudMarch(iTime, 128, ro, rd, minT, maxT, sum, cnt);
   sum = v4(clamp_(sum.x, 0.0f, 1.0f), clamp_(sum.y, 0.0f, 1.0f), clamp_(sum.z, 0.0f, 1.0f), clamp_(sum.w, 0.0f, 1.0f));
   float om = 1.0f - sum.w;
   return v3(fma(bg.x, om, sum.x), fma(bg.y, om, sum.y), fma(bg.z, om, sum.z));
 }
-RM_DEV float raymarchTerrain(V3 ro, V3 rd, float tmin, float tmax) {  // frag:2060-2090
+RM_DEV float raymarchTerrain(V3 ro, V3 rd, float tmin, float tmax, Counters &cnt) {  // frag:2060-2090
   float tp = (700.0f - ro.y) / rd.y;
   if (tp > 0.0f) tmax = min_(tmax, tp);
   float dis = 0.0f, th = 0.0f, t = tmin, ot = t, odis = 0.0f;
@@ -227,7 +229,7 @@ RM_DEV float raymarchTerrain(V3 ro, V3 rd, float tmin, float tmax) {  // frag:20
     th = 0.001f * t;
     V3 pos = madd(rd, t, ro);
     float hgt, slope;
-    sdTerrain(pos.x, pos.z, hgt, slope);
+    sdTerrain(pos.x, pos.z, hgt, slope, cnt);
     dis = pos.y - hgt;
     if (dis < th) break;
     ot = t;
@@ -238,36 +240,36 @@ RM_DEV float raymarchTerrain(V3 ro, V3 rd, float tmin, float tmax) {  // frag:20
   if (t > tmax) return -1.0f;
   return ot + ((th - odis) * (t - ot)) / (dis - odis);
 }
-RM_DEV float terrainHeight(float x, float z) { float h, s; sdTerrain(x, z, h, s); return h; }
-RM_DEV V3 terrainNormal(float px, float pz) {  // frag:2106-2111
+RM_DEV float terrainHeight(float x, float z, Counters &cnt) { float h, s; sdTerrain(x, z, h, s, cnt); return h; }
+RM_DEV V3 terrainNormal(float px, float pz, Counters &cnt) {  // frag:2106-2111
   const float e = 0.03f;
-  return normalize(v3(terrainHeight(px - e, pz - 0.0f) - terrainHeight(px + e, pz + 0.0f), 2.0f * e,
-                      terrainHeight(px - 0.0f, pz - e) - terrainHeight(px + 0.0f, pz + e)));
+  return normalize(v3(terrainHeight(px - e, pz - 0.0f, cnt) - terrainHeight(px + e, pz + 0.0f, cnt), 2.0f * e,
+                      terrainHeight(px - 0.0f, pz - e, cnt) - terrainHeight(px + 0.0f, pz + e, cnt)));
 }
-RM_DEV float terrainShadow(V3 ro, V3 rd, float mint) {  // frag:2113-2125
+RM_DEV float terrainShadow(V3 ro, V3 rd, float mint, Counters &cnt) {  // frag:2113-2125
   float res = 1.0f, t = mint;
 #pragma unroll 1
   for (int i = 0; i < 32; i++) {
     V3 pos = madd(rd, t, ro);
-    float hei = pos.y - terrainHeight(pos.x, pos.z);
+    float hei = pos.y - terrainHeight(pos.x, pos.z, cnt);
     res = min_(res, divr_(32.0f * hei, t));
     if (res < 0.0001f || pos.y > 700.0f) break;
     t = t + clamp_(hei, fma(t, 0.1f, 2.0f), 100.0f);
   }
   return clamp_(res, 0.0f, 1.0f);
 }
-RM_DEV bool terrainRender(float iTime, V3 ro, V3 rd, float maxT, V3 bg, V3 &colOut, float &dOut) {  // frag:2128-2158
+RM_DEV bool terrainRender(float iTime, V3 ro, V3 rd, float maxT, V3 bg, V3 &colOut, float &dOut, Counters &cnt) {  // frag:2128-2158
   colOut = bg; dOut = maxT;
-  float res = raymarchTerrain(ro, rd, 15.0f, maxT);
+  float res = raymarchTerrain(ro, rd, 15.0f, maxT, cnt);
   if (!(res > 0.0f)) return false;
   dOut = res;
   V3 p = madd(rd, res, ro);
-  V3 pn = terrainNormal(p.x, p.z);
+  V3 pn = terrainNormal(p.x, p.z, cnt);
   V3 epos = v3(p.x + 0.0f, p.y + 4.8f, p.z + 0.0f);
   const V3 sunColor = getSunColor(), sunDir = getSunDir();
-  float sha1 = terrainShadow(v3(p.x + 0.0f, p.y + 0.02f, p.z + 0.0f), sunDir, 0.02f);
-  sha1 = sha1 * smoothstep_(-0.325f, -0.075f, cloudsShadowFlat(iTime, epos, sunDir));
-  V4 fb = fbmd_8(v3(((p.x - 0.0f) * 0.15f) * 1.0f, ((p.y - 600.0f) * 0.15f) * 0.2f, ((p.z - 0.0f) * 0.15f) * 1.0f));
+  float sha1 = terrainShadow(v3(p.x + 0.0f, p.y + 0.02f, p.z + 0.0f), sunDir, 0.02f, cnt);
+  sha1 = sha1 * smoothstep_(-0.325f, -0.075f, cloudsShadowFlat(iTime, epos, sunDir, cnt));
+  V4 fb = fbmd_8(v3(((p.x - 0.0f) * 0.15f) * 1.0f, ((p.y - 600.0f) * 0.15f) * 0.2f, ((p.z - 0.0f) * 0.15f) * 1.0f), cnt);
   float k = (0.8f * (1.0f - fabs_(pn.y))) * 0.8f;
   V3 nor = normalize(v3(fma(k, fb.y, pn.x), fma(k, fb.z, pn.y), fma(k, fb.w, pn.z)));
   V3 col = v3(0.18f * 0.85f, 0.12f * 0.85f, 0.10f * 0.85f);
@@ -401,14 +403,14 @@ RM_DEV bool seaRender(const RmTexture &noise, float iTime, int W, V3 ro, V3 rd, 
 // Sea, terrain, then cloud after a render() (frag:2444-2456, 2506-2518, 2555-2567).  The cloud layer is bounded by
 // tr.d, which starts at the render's d — not at the sea's — when TERRAIN is off.
 struct EnvOut { bool terrainHit, cloudHit, seaHit; V3 tcol, ccol, scol; };
-RM_DEV EnvOut envLayers(uint32_t features, const RmTexture &noise, float iTime, int W, V3 ro, V3 rd, float d, V3 bg) {
+RM_DEV EnvOut envLayers(uint32_t features, const RmTexture &noise, float iTime, int W, V3 ro, V3 rd, float d, V3 bg, Counters &cnt) {
   EnvOut e;
   float sd = d, td = d;
   e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
   e.tcol = bg; e.ccol = bg; e.scol = bg;
   if (features & RM_FEAT_SEA) e.seaHit = seaRender(noise, iTime, W, ro, rd, d, bg, e.scol, sd);
-  if (features & RM_FEAT_TERRAIN) e.terrainHit = terrainRender(iTime, ro, rd, sd, bg, e.tcol, td);
-  if (features & RM_FEAT_CLOUD) e.ccol = cloudRender(iTime, ro, rd, bg, e.cloudHit, td);
+  if (features & RM_FEAT_TERRAIN) e.terrainHit = terrainRender(iTime, ro, rd, sd, bg, e.tcol, td, cnt);
+  if (features & RM_FEAT_CLOUD) e.ccol = cloudRender(iTime, ro, rd, bg, e.cloudHit, td, cnt);
   return e;
 }
 

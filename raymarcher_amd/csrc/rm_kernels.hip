@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   if (x >= W || r >= nRows) return;
   const int y = map.frameRow(r);
   V4 col, br;
-  Counters cnt{0, 0};
+  Counters cnt{0, 0, 0, 0, 0};
   bool hit;
   shadePixel<BULB, CM, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
     atomicAdd(&counters[0], cnt.evals);
     atomicAdd(&counters[1], cnt.iters);
     if (hit) atomicAdd(&counters[2], 1ull);
+    if (cnt.shades) atomicAdd(&counters[6], cnt.shades);
+    if (cnt.fbm9) atomicAdd(&counters[7], cnt.fbm9);
+    if (cnt.fbmd8) atomicAdd(&counters[8], cnt.fbmd8);
   }
   if (sb->tileCost && sb->tileCount == (int)(gridDim.x * gridDim.y)) {  // wave-uniform
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
@@ -231,7 +234,7 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
 __global__ void probe_sdscene_kernel(const SceneBlock *__restrict__ sb, const float *pts, float *out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Counters cnt{0, 0};
+  Counters cnt{0, 0, 0, 0, 0};
   SceneMin m = sdScene<false, 0>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
   out[4 * i] = m.d;
   out[4 * i + 1] = (float)m.idx;
@@ -281,7 +284,7 @@ struct DeviceState {
   std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
   std::vector<Slot> slots;       // ring of scene-table slots; grows (to kSlotsMax) instead of waiting for a busy slot
   size_t next = 0;
-  unsigned long long *dCounters = nullptr;  // 5 words: evals, iterations, hits, clock stamps (counted renders synchronise)
+  unsigned long long *dCounters = nullptr;  // 9 words: evals, iterations, hits, clock stamps (2), span pointer, shades, fbm9, fbmd8
   std::vector<TimedLaunch> timed;           // rm_set_timing / rm_get_timing, per device
   int numCUs = 0;
   std::map<hipStream_t, TileOrderState> tileOrder;  // what the feedback costs of each stream belong to
@@ -318,7 +321,7 @@ int acquire_slot(DeviceState &ds, Slot **out) {
   if (ds.slots.empty()) {
     ds.slots.resize(kSlotsInit);
     for (auto &s : ds.slots) { int st = new_slot(&s); if (st != RM_OK) return st; }
-    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 6 * sizeof(unsigned long long)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 9 * sizeof(unsigned long long)));
   }
   Slot *s = &ds.slots[ds.next];
   if (s->used) {
@@ -745,7 +748,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (st != RM_OK) return st;
   unsigned long long *dc = ds.dCounters;
   if (count) {
-    HIP_OK(hipMemsetAsync(dc, 0, 6 * sizeof(unsigned long long), stream));
+    HIP_OK(hipMemsetAsync(dc, 0, 9 * sizeof(unsigned long long), stream));
     if (d_waveSpans) HIP_OK(hipMemcpyAsync(dc + 5, &d_waveSpans, sizeof(d_waveSpans), hipMemcpyHostToDevice, stream));
   }
   TimedLaunch tl{};
@@ -859,9 +862,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     }
 #define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
-      if (envFeatures && textured) RM_LAUNCH(false, 0, true, true);
-      else if (envFeatures) RM_LAUNCH(false, 0, true, false);
-      else RM_LAUNCH(false, 0, false, true);
+      // counting instantiations of the layer / sampler kernels: the reference's work only (they have no shortcuts to count apart)
+      if (envFeatures && textured) { if (count) RM_LAUNCH(false, 1, true, true); else RM_LAUNCH(false, 0, true, true); }
+      else if (envFeatures) { if (count) RM_LAUNCH(false, 1, true, false); else RM_LAUNCH(false, 0, true, false); }
+      else { if (count) RM_LAUNCH(false, 1, false, true); else RM_LAUNCH(false, 0, false, true); }
     } else if (bulb) {
       if (count == 1) RM_LAUNCH(true, 1, false, false);
       else if (count == 2) RM_LAUNCH(true, 2, false, false);
@@ -880,10 +884,13 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (timing) ds.timed.push_back(tl);
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
-    unsigned long long hc[5];
+    unsigned long long hc[9];
     HIP_OK(hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
-    if (countersOut) { countersOut->sceneEvals = hc[0]; countersOut->bulbIters = hc[1]; countersOut->hitPixels = hc[2]; }
+    if (countersOut) {
+      countersOut->sceneEvals = hc[0]; countersOut->bulbIters = hc[1]; countersOut->hitPixels = hc[2];
+      countersOut->shadedPoints = hc[6]; countersOut->terrainEvals = hc[7]; countersOut->cloudEvals = hc[8];
+    }
     if (clockMHz) *clockMHz = hc[4] ? 100.0 * (double)hc[3] / (double)hc[4] : 0.0;
   }
   return RM_OK;
@@ -953,6 +960,16 @@ int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjec
   int n = rowEnd - rowBegin;
   RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, mode, out);
+}
+int rm_render_counted_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+                          const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int rowBegin, int rowEnd,
+                          float *d_rgba, float *d_bright, int mode, RmCounters *out) {
+  if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
+  if (mode != RM_COUNT_REFERENCE && mode != RM_COUNT_EXECUTED) { set_error("bad counting mode"); return RM_ERR_INVALID_ARGUMENT; }
+  int n = rowEnd - rowBegin;
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, mode, out,
+                       res ? *res : kNoResources);
 }
 int rm_render_counted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                       const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin, int rowEnd, float *d_rgba,

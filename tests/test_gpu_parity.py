@@ -866,14 +866,14 @@ def _ieq(a, b):
 
 
 def test_config1_unit_sphere_256(renderer):
-    """configs[0]: scenefiles/simple/unit_sphere.json through the product's loader, 256×256, 64 steps, Phong only — the
-    whole frame against the oracle.  The floor's texture file is an asset of the reference (not in this repo): a
-    synthetic texture takes its slot."""
+    """configs[0]: scenefiles/simple/unit_sphere.json through the product's loader and PNG reader, 256×256, 64 steps, Phong
+    only — the whole frame against the oracle, the floor textured with the reference's own texture_store/blackmarble.png
+    (tests/golden/scenes/texture_store/, input data)."""
     from raymarcher_amd import Scene
     W = H = 256
-    t = Scene(path=os.path.join(SCENES, "simple", "unit_sphere.json")).tables(W, H, load_textures=False)
-    t.textures = [synthetic_textures()[1]]
+    t = Scene(path=os.path.join(SCENES, "simple", "unit_sphere.json")).tables(W, H)
     assert t.num_objects == 2 and t.num_lights == 3 and sum(t.objects[i].texLoc == 0 for i in range(2)) == 1
+    assert len(t.textures) == 1 and t.textures[0].shape == (1320, 1990, 4)  # blackmarble.png, decoded by rm_image_load
     s = abi.default_settings(maxSteps=64)
     ref = h.oracle_render(_scene_tuple(t), s, W, H, textures=t.textures)
     assert_bit_equal(renderer.render(t, s, W, H).cpu().numpy(), ref, "unit_sphere 256²")
