@@ -262,10 +262,25 @@ int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int t
  */
 typedef struct RmGather RmGather;
 int rm_gather_create(const int *devices, int numDevices, RmGather **out);
+/* flags: RM_GATHER_FORCE_COMM builds the RCCL communicator(s) even for ONE device and sends the root's own tiles to itself
+ * through ncclSend / ncclRecv instead of a device copy — the whole RCCL path (library load, ncclCommInitAll, a grouped
+ * send / receive pair) on a one-GPU box; tests and bring-up.  A grouped call that fails aborts the communicators
+ * (ncclCommAbort: no unmatched send is left on a stream) and the object refuses further use. */
+enum { RM_GATHER_FORCE_COMM = 1u };
+int rm_gather_create_ex(const int *devices, int numDevices, unsigned flags, RmGather **out);
 void rm_gather_destroy(RmGather *g);
 int rm_gather_slot_rows(int H, int tileRows, int numShards);
 int rm_gather_tiles(RmGather *g, const float *const *d_tiles, float *d_gathered, int W, int H, int tileRows, int root,
                     void *const *streams);
+/* The same gather with 4 bytes per pixel instead of 16, for hosts that only need the 8-bit image (saveViewportImage writes
+ * a PNG, src/realtime.cpp:284-350): every shard converts its packed tiles with rm_tiles_to_rgba8 (clamp → ×255 → round, no
+ * flip) on its own stream, rm_gather_tiles_rgba8 moves them (a quarter of the xGMI traffic into the root), and
+ * rm_deinterleave_rgba8 writes the frame — rows in frame order, or flipped top-down like rm_frame_to_rgba8 (flip != 0). */
+int rm_tiles_to_rgba8(const float *d_tiles, uint8_t *d_tiles8, int W, int rows, void *stream);
+int rm_gather_tiles_rgba8(RmGather *g, const uint8_t *const *d_tiles8, uint8_t *d_gathered8, int W, int H, int tileRows, int root,
+                          void *const *streams);
+int rm_deinterleave_rgba8(const uint8_t *d_gathered8, uint8_t *d_frame8, int W, int H, int tileRows, int numShards,
+                          int shardStrideRows, int flip, void *stream);
 
 /* Fractal / shading work counters of the last counted render (debug/roofline accounting). */
 typedef struct RmCounters {

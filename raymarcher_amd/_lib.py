@@ -42,7 +42,11 @@ SIGNATURES = {
     "rm_shard_row_to_frame": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rm_deinterleave": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rm_gather_create": (C.c_int, [_P(C.c_int), C.c_int, _P(C.c_void_p)]),
+    "rm_gather_create_ex": (C.c_int, [_P(C.c_int), C.c_int, C.c_uint, _P(C.c_void_p)]),
     "rm_gather_destroy": (None, [C.c_void_p]),
+    "rm_tiles_to_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rm_gather_tiles_rgba8": (C.c_int, [C.c_void_p, _P(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_void_p)]),
+    "rm_deinterleave_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rm_gather_slot_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "rm_gather_tiles": (C.c_int, [C.c_void_p, _P(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_void_p)]),
     "rm_render_counted": (C.c_int, _SCENE_ARGS + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

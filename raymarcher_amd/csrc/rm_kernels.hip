@@ -251,6 +251,26 @@ __global__ void to_rgba8_kernel(const float4 *__restrict__ in, uchar4 *__restric
   out[(size_t)(H - 1 - y) * W + x] = make_uchar4(q(c.x), q(c.y), q(c.z), q(c.w));
 }
 
+// packed tiles → RGBA8, rows as they are (the multi-GPU shard's share of to_rgba8_kernel's conversion)
+__global__ void tiles_to_rgba8_kernel(const float4 *__restrict__ in, uchar4 *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 c = in[i];
+  auto q = [](float v) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); return (unsigned char)(v * 255.0f + 0.5f); };
+  out[i] = make_uchar4(q(c.x), q(c.y), q(c.z), q(c.w));
+}
+// gathered RGBA8 slots → frame rows (flip: row 0 of the output is the top of the image, as rm_frame_to_rgba8 writes it)
+__global__ void deinterleave_rgba8_kernel(const uchar4 *__restrict__ in, uchar4 *__restrict__ out, int W, int H, int tileRows,
+                                          int numShards, int strideRows, int flip) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;  // y = frame row (0 = bottom)
+  if (x >= W) return;
+  int tile = y / tileRows, shard = tile % numShards;
+  int before = shard * strideRows;
+  if (strideRows == 0)
+    for (int s = 0; s < shard; s++) before += shard_rows(H, tileRows, s, numShards);
+  int local = (tile / numShards) * tileRows + (y % tileRows);
+  out[(size_t)(flip ? H - 1 - y : y) * W + x] = in[(size_t)(before + local) * W + x];
+}
 // gathered[shard-major packed rows] → frame rows
 __global__ void deinterleave_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int W, int H, int tileRows,
                                     int numShards, int strideRows) {
@@ -1027,6 +1047,33 @@ int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int t
   hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4 *>(d_gathered), reinterpret_cast<float4 *>(d_frame), W, H, tileRows,
                      numShards, shardStrideRows);
+  HIP_OK(hipGetLastError());
+  return RM_OK;
+}
+
+int rm_tiles_to_rgba8(const float *d_tiles, uint8_t *d_tiles8, int W, int rows, void *stream) {
+  if (W <= 0 || rows < 0) { set_error("bad tile arguments"); return RM_ERR_INVALID_ARGUMENT; }
+  if (rows == 0) return RM_OK;
+  if (!d_tiles || !d_tiles8) { set_error("null tile buffer"); return RM_ERR_INVALID_ARGUMENT; }
+  if (int st = require_device_pointers({{"d_tiles", d_tiles}, {"d_tiles8", d_tiles8}})) return st;
+  const size_t n = (size_t)rows * W;
+  hipLaunchKernelGGL(tiles_to_rgba8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4 *>(d_tiles), reinterpret_cast<uchar4 *>(d_tiles8), n);
+  HIP_OK(hipGetLastError());
+  return RM_OK;
+}
+int rm_deinterleave_rgba8(const uint8_t *d_gathered8, uint8_t *d_frame8, int W, int H, int tileRows, int numShards,
+                          int shardStrideRows, int flip, void *stream) {
+  if (!d_gathered8 || !d_frame8 || W <= 0 || H <= 0 || tileRows <= 0 || numShards <= 0 || numShards > 64 ||
+      (shardStrideRows != 0 && shardStrideRows < shard_rows(H, tileRows, 0, numShards))) {
+    set_error("bad deinterleave arguments");
+    return RM_ERR_INVALID_ARGUMENT;
+  }
+  if (int st = require_device_pointers({{"d_gathered8", d_gathered8}, {"d_frame8", d_frame8}})) return st;
+  dim3 grid((W + 255) / 256, H), block(256);
+  hipLaunchKernelGGL(deinterleave_rgba8_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uchar4 *>(d_gathered8), reinterpret_cast<uchar4 *>(d_frame8), W, H, tileRows, numShards,
+                     shardStrideRows, flip);
   HIP_OK(hipGetLastError());
   return RM_OK;
 }

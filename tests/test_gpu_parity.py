@@ -1264,6 +1264,44 @@ int main(int argc, char **argv) {
   if (std::memcmp(got2.data(), ref.data(), got2.size() * 4) != 0) { std::printf("gathered frame differs from the oracle\n"); return 20; }
   if (rm_gather_tiles(ga, tiles.data(), dGathered, W, H, T, ndev, streams.data()) != RM_ERR_INVALID_ARGUMENT) return 21;
   rm_gather_destroy(ga);
+  // the RCCL branch itself, also on a one-GPU box: RM_GATHER_FORCE_COMM loads librccl, builds the communicator(s) with
+  // ncclCommInitAll and moves EVERY shard — the root's own too — through a grouped ncclSend / ncclRecv pair
+  RmGather *gb = nullptr;
+  if (rm_gather_create_ex(devs.data(), ndev, RM_GATHER_FORCE_COMM, &gb) != RM_OK) { std::printf("gather_ex: %s\n", rm_last_error()); return 22; }
+  int cur = -1;
+  hipGetDevice(&cur);
+  if (cur != devs[0]) return 23;  // creating the communicators left the caller's device alone
+  hipMemsetAsync(dGathered, 0, size_t(ndev) * slot * W * 16, static_cast<hipStream_t>(streams[0]));
+  if (rm_gather_tiles(gb, tiles.data(), dGathered, W, H, T, 0, streams.data()) != RM_OK) { std::printf("rccl gather: %s\n", rm_last_error()); return 24; }
+  hipGetDevice(&cur);
+  if (cur != devs[0]) return 25;
+  if (rm_deinterleave(dGathered, dFrame2, W, H, T, ndev, slot, streams[0]) != RM_OK) return 26;
+  if (hipStreamSynchronize(static_cast<hipStream_t>(streams[0])) != hipSuccess) return 27;
+  hipMemcpy(got2.data(), dFrame2, got2.size() * 4, hipMemcpyDeviceToHost);
+  if (std::memcmp(got2.data(), ref.data(), got2.size() * 4) != 0) { std::printf("RCCL-gathered frame differs from the oracle\n"); return 28; }
+  // the 4-bytes-per-pixel gather: every shard quantises its tiles, the bytes travel, the root writes the top-down image
+  std::vector<uint8_t *> tiles8(ndev);
+  uint8_t *dGathered8 = nullptr, *dFrame8 = nullptr;
+  for (int k = 0; k < ndev; k++) {
+    rm_set_device(devs[k]);
+    if (hipMalloc(reinterpret_cast<void **>(&tiles8[k]), size_t(slot) * W * 4) != hipSuccess) return 29;
+    if (rm_tiles_to_rgba8(tiles[k], tiles8[k], W, rm_shard_rows(H, T, k, ndev), streams[k]) != RM_OK) return 30;
+  }
+  rm_set_device(devs[0]);
+  if (hipMalloc(reinterpret_cast<void **>(&dGathered8), size_t(ndev) * slot * W * 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&dFrame8), size_t(W) * H * 4) != hipSuccess) return 31;
+  if (rm_gather_tiles_rgba8(gb, tiles8.data(), dGathered8, W, H, T, 0, streams.data()) != RM_OK) { std::printf("rgba8 gather: %s\n", rm_last_error()); return 32; }
+  if (rm_deinterleave_rgba8(dGathered8, dFrame8, W, H, T, ndev, slot, 1, streams[0]) != RM_OK) return 33;
+  if (hipStreamSynchronize(static_cast<hipStream_t>(streams[0])) != hipSuccess) return 34;
+  std::vector<uint8_t> px2(px.size());
+  hipMemcpy(px2.data(), dFrame8, px2.size(), hipMemcpyDeviceToHost);
+  if (std::memcmp(px2.data(), px.data(), px.size()) != 0) { std::printf("RGBA8 gather differs from rm_frame_to_rgba8 of the whole frame\n"); return 35; }
+  // a null tile buffer is refused before the group opens; the object stays usable
+  std::vector<float *> bad(tiles);
+  bad[0] = nullptr;
+  if (rm_gather_tiles(gb, bad.data(), dGathered, W, H, T, 0, streams.data()) != RM_ERR_INVALID_ARGUMENT) return 36;
+  if (rm_gather_tiles(gb, tiles.data(), dGathered, W, H, T, 0, streams.data()) != RM_OK) return 37;
+  if (hipStreamSynchronize(static_cast<hipStream_t>(streams[0])) != hipSuccess) return 38;
+  rm_gather_destroy(gb);
   rm_scene_free(sc);
   std::printf("ok\n");
   return 0;
@@ -1294,6 +1332,30 @@ def test_cxx_host_without_python(renderer, tmp_path):
     from PIL import Image
     img = np.asarray(Image.open(png))
     assert img.shape == (54, 96, 4) and (img[..., :3] != 255).any(-1).mean() > 0.2
+
+
+def test_single_process_multi_gpu_host_runs(renderer, tmp_path):
+    """scripts/mgpu_host.cpp — one process, every visible device, three frames in flight per device, RCCL gather to device 0 —
+    builds against the C ABI alone and runs here with the communicator forced (one GPU): float4 and RGBA8 gathers."""
+    import json
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "mgpu_host"
+    libdir = os.path.join(root, "raymarcher_amd", "lib")
+    p = subprocess.run([hipcc, "-std=c++17", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "scripts", "mgpu_host.cpp"), "-o",
+                        str(exe), "-L", libdir, "-lraymarcher_amd", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    scene = os.path.join(SCENES, "simple", "unit_mandelbulb.json")
+    for extra in ([], ["--rgba8"]):
+        r = subprocess.run([str(exe), scene, "--size", "640", "360", "--frames", "12", "--iters", "12", "--force-comm"] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.stdout, r.stderr[-800:])
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] >= 1 and line["value"] > 0 and line["gather"] == ("rgba8" if extra else "float4")
 
 
 def test_degenerate_knobs_bit_exact(renderer):
