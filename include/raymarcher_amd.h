@@ -312,7 +312,8 @@ int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjec
  * to a buffer of their own): renders the whole frame once, synchronises and returns the shader clock the chip held under
  * this kernel's own load, in MHz (Σ cycle spans ÷ Σ 100 MHz-tick spans over all waves).  Call it after a few back-to-back
  * renders so that the clock has settled.  d_waveSpans (device, may be NULL): 2 words per wave — its first and last
- * s_memrealtime stamp (100 MHz ticks) — for ceil(W/16)·ceil(H/8)·2 waves in workgroup order, for occupancy timelines. */
+ * s_memrealtime stamp (100 MHz ticks) — indexed tile·w + wave with w = waves per workgroup (1 unless RM_WAVES_PER_BLOCK
+ * overrides) and ceil(W / (8·w)) tiles per tile row: size it for (ceil(W/8) + 3)·ceil(H/8) waves; for occupancy timelines. */
 int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                       const RmGlobals *g, const RmSettings *s, int W, int H, float *d_rgba, double *shaderMHz,
                       unsigned long long *d_waveSpans);
@@ -321,8 +322,10 @@ int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects,
  * hipEvents on their own stream; rm_get_* reads and resets that device's records (the on/off switch is process-wide). */
 int rm_set_timing(int on);
 int rm_get_timing(double *avgKernelMs, int *launches);
-/* Same, split by pipeline stage.  The single-Mandelbulb scene class renders as four kernels (primary march,
- * surface/normals, shadow marches, shading: stage 0..3); every other scene is one kernel (stage 0). */
+/* Same, split by stage.  One-lane-per-pixel kernel with tile-order feedback active (rm_set_tile_order): stage 0 = the two
+ * ordering launches, stage 1 = the render kernel; without it (first frame, small frames, layers / samplers): stage 0 = the
+ * render kernel.  Bulb pipelines (kernel paths 2-4): primary march, surface / normals, shadow marches, shading = stages
+ * 0..3.  Wavefront pipeline (path 5): stage 0 = all of its kernels. */
 int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches);
 /* Which schedule renders a frame: 0 = the measured-fastest one of the scene's class (default), 1 = one lane per pixel
  * (rm::render_kernel).  Single-Mandelbulb class only: 2 = four-kernel pipeline with per-lane state machines and

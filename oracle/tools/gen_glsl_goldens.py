@@ -219,6 +219,15 @@ for _grp, _names in _SWEEP.items():
     for _n in _names:
         SCENEFILE_CASES[f"sweep_{_n}"] = (f"{_grp.split('+')[0]}/{_n}.json", 64, 36,
                                           dict(enableReflection=1) if _grp.endswith("+reflect") else {}, {})
+# Round 3: the reference's refraction scene that is defined (lighting/refract2.json: four glass spheres over a checker floor,
+# reflection + refraction on — refract1.json textures an octahedron, for which the shader has no uv map: its `uv` is read
+# unset, frag:1746-1781), its HDR scene (three textured and four plain cubes under three point lights), the five-texture scene
+# of textures_tests (one of the images a GIF) and the sky-box scene (cubemap/beach.json with the reference's own JPEG faces,
+# texture_store/cube_map/beach, loaded as initCubeMap does: RGBA8888, mirrored; realtimerender.cpp:557-590)
+SCENEFILE_CASES["sweep_refract2"] = ("lighting/refract2.json", 64, 36, dict(enableReflection=1, enableRefraction=1), {})
+SCENEFILE_CASES["sweep_hdr"] = ("lighting/hdr.json", 64, 36, {}, {})
+SCENEFILE_CASES["sweep_directional_light_textured"] = ("textures_tests/directional_light_textured.json", 64, 36, {}, {})
+SCENEFILE_CASES["sweep_beach"] = ("cubemap/beach.json", 64, 36, dict(enableReflection=1, enableRefraction=1, enableSkyBox=1), dict(skybox="beach"))
 
 
 def reference_tables(rel, W, H):
@@ -308,8 +317,14 @@ def scenefile_cases(only=None):
                 raw = np.fromfile(f.name, dtype=np.float32).reshape(2, 64, 64, 4)
             extra = {"ltc1": h.oracle_ltc_quantise(raw[0]), "ltc2": h.oracle_ltc_quantise(raw[1])}
             flags = dict(flags, ltc=(extra["ltc1"], extra["ltc2"]))
+        if "skybox" in flags:  # six faces +x, -x, +y, -y, +z, -z (raymarchscene.cpp:50-86), decoded here with PIL (libjpeg, as Qt does)
+            base = os.path.join(REF_SCENES, "texture_store", "cube_map", flags["skybox"])
+            ext = ".jpg" if os.path.exists(os.path.join(base, "+x.jpg")) else ".png"
+            faces = [np.ascontiguousarray(np.asarray(Image.open(os.path.join(base, f + ext)).convert("RGBA"))[::-1]) for f in ("+x", "-x", "+y", "-y", "+z", "-z")]
+            extra["cubemap"] = {"beach": 1, "night": 2, "island": 3}[flags["skybox"]]  # the product loads the faces itself (rm_skybox_face_path)
+            flags = dict(flags, skybox=faces)
         rgba, bright = run_ref.render(scene, s, W, H, tex, **flags)
-        flags = {k: v for k, v in flags.items() if k != "ltc"}
+        flags = {k: v for k, v in flags.items() if k not in ("ltc", "skybox")}
         # what saveViewportImage writes (realtime.cpp:284-350): clamp, ×255, round, rows top-down
         png8 = (np.clip(rgba[::-1], 0, 1) * 255.0 + 0.5).astype(np.uint8)
         np.savez_compressed(os.path.join(OUT, f"scenefile_{name}.npz"), W=W, H=H, rgba=rgba, bright=bright, png8=png8,

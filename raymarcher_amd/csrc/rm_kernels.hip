@@ -339,9 +339,27 @@ int new_slot(Slot *s) {
 // kSlotsMax launches are in flight does it wait (hipEventSynchronize on the oldest), which bounds pinned memory.
 int acquire_slot(DeviceState &ds, Slot **out) {
   if (ds.slots.empty()) {
-    ds.slots.resize(kSlotsInit);
-    for (auto &s : ds.slots) { int st = new_slot(&s); if (st != RM_OK) return st; }
-    HIP_OK(hipMalloc(reinterpret_cast<void **>(&ds.dCounters), 9 * sizeof(unsigned long long)));
+    // built aside and swapped in only when every allocation has succeeded: a failure part-way (out of memory on the first
+    // call) leaves the device state empty, so the next call tries again instead of handing out half-made slots
+    std::vector<Slot> fresh(kSlotsInit);
+    unsigned long long *counters = nullptr;
+    int st = RM_OK;
+    for (auto &s : fresh)
+      if ((st = new_slot(&s)) != RM_OK) break;
+    if (st == RM_OK && hipMalloc(reinterpret_cast<void **>(&counters), 9 * sizeof(unsigned long long)) != hipSuccess) {
+      set_error("hipMalloc of the counter block failed");
+      st = RM_ERR_DEVICE;
+    }
+    if (st != RM_OK) {
+      for (auto &s : fresh) {
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.done) (void)hipEventDestroy(s.done);
+      }
+      return st;
+    }
+    ds.slots.swap(fresh);
+    ds.dCounters = counters;
   }
   Slot *s = &ds.slots[ds.next];
   if (s->used) {
@@ -773,11 +791,16 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   }
   TimedLaunch tl{};
   const bool timing = g_timing.load();
+  // the events of a launch that fails part-way are destroyed on the way out (kept = handed to ds.timed below)
+  struct TimedGuard {
+    TimedLaunch &t; bool kept = false;
+    ~TimedGuard() { if (!kept) for (int i = 0; i < t.n; i++) (void)hipEventDestroy(t.ev[i]); }
+  } timedGuard{tl};
   auto stamp = [&](int i) -> int {
     if (!timing) return RM_OK;
     HIP_OK(hipEventCreate(&tl.ev[i]));
-    HIP_OK(hipEventRecord(tl.ev[i], stream));
     tl.n = i + 1;
+    HIP_OK(hipEventRecord(tl.ev[i], stream));
     return RM_OK;
   };
   float4 *o = reinterpret_cast<float4 *>(d_rgba), *b = reinterpret_cast<float4 *>(d_bright);
@@ -901,7 +924,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   }
   HIP_OK(hipGetLastError());
   ds.lastPath = pipeline ? path : (wavefront ? 5 : 1);
-  if (timing) ds.timed.push_back(tl);
+  if (timing) { ds.timed.push_back(tl); timedGuard.kept = true; }
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
     unsigned long long hc[9];

@@ -237,7 +237,9 @@ class Renderer:
         t = self.torch
         out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
         mhz = C.c_double()
-        spans = t.zeros((((W + 15) // 16) * ((H + 7) // 8) * 2, 2), dtype=t.int64, device=self.device) if wave_spans else None
+        # one (first, last) pair per wave; the kernel indexes tile·(waves per workgroup) + wave with tiles = ceil(W / (8·wpb)) per
+        # row, so a row holds at most ceil(W/8) + 3 waves for any RM_WAVES_PER_BLOCK in {1, 2, 4}
+        spans = t.zeros(((((W + 7) // 8) + 3) * ((H + 7) // 8), 2), dtype=t.int64, device=self.device) if wave_spans else None
         t.cuda.synchronize(self.device)
         check(lib().rm_render_clocked(*tables.args(settings), W, H, C.c_void_p(out.data_ptr()), C.byref(mhz),
                                       C.c_void_p(spans.data_ptr()) if wave_spans else None))

@@ -5,6 +5,8 @@ functions it implements (iquilezles.org SDF definitions at the unit sizes of sdM
 algebraic properties of the marchers."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -338,3 +340,56 @@ def test_bulb_algebraic_power8_is_the_same_function():
           for f in (0, abi.RM_FEAT_BULB_POWER8_ALGEBRAIC)]
     dd = np.abs(fr[0] - fr[1]).max(-1)
     assert (dd > 1e-3).mean() < 0.003 and dd.mean() < 1e-4, ((dd > 1e-3).mean(), dd.mean())
+
+
+# ---------------------------------------------------------------- an INDEPENDENT binary64 evaluation of the Mandelbulb estimator
+def _bulb_de_float64(pos, power, iters, bailout=2.0):
+    """frag:775-803 transcribed from the SHADER TEXT into NumPy float64 — not the oracle's source with wider types: its own
+    vectorised control flow (a point that has bailed out stops updating), NumPy's arccos / arctan2 / sin / cos / power."""
+    w = np.array(pos, dtype=np.float64)
+    c = w.copy()
+    m = (w * w).sum(-1)
+    trap = np.concatenate([np.abs(w), m[:, None]], -1)
+    dz = np.ones(len(w))
+    live = np.ones(len(w), dtype=bool)
+    with np.errstate(all="ignore"):
+        for _ in range(iters):
+            dz_n = power * np.power(m, (power - 1.0) / 2.0) * dz + 1.0
+            r = np.sqrt((w * w).sum(-1))
+            b = power * np.arccos(w[:, 1] / r)
+            a = power * np.arctan2(w[:, 0], w[:, 2])
+            w_n = c + np.power(r, power)[:, None] * np.stack([np.sin(b) * np.sin(a), np.cos(b), np.sin(b) * np.cos(a)], -1)
+            trap_n = np.minimum(trap, np.concatenate([np.abs(w_n), m[:, None]], -1))
+            m_n = (w_n * w_n).sum(-1)
+            dz = np.where(live, dz_n, dz)
+            w = np.where(live[:, None], w_n, w)
+            trap = np.where(live[:, None], trap_n, trap)
+            m = np.where(live, m_n, m)
+            live = live & ~(m > bailout)
+        return 0.25 * np.log(m) * np.sqrt(m) / dz, m, trap[:, 1:]
+
+
+@pytest.mark.parametrize("fixture,iters", [("probe_sd_bulb_p8_12iters.npz", 12), ("probe_sd_bulb_p8.npz", 20)])
+def test_bulb_estimator_against_an_independent_float64_transcription(fixture, iters):
+    """The binary32 oracle's sdScene on the probe points of the reference-shader fixtures against the transcription above:
+    the arbiter of rm_oracle_f64.c shares the oracle's source, so a mis-transcribed formula would pass there — not here.
+    Points whose orbit passes within rounding distance of the bailout radius run a different number of iterations in the
+    two evaluations (a legitimate flip, ≈0.5 %); all others agree to a few binary32 ulps of the estimate."""
+    import ctypes as C
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "glsl", fixture))
+    pts = np.ascontiguousarray(z["pts"], dtype=np.float32)
+    objs = (abi.RmObject * 1).from_buffer_copy(z["objs"].tobytes()[:C.sizeof(abi.RmObject)])
+    g = abi.RmGlobals.from_buffer_copy(z["globals"].tobytes())
+    s = abi.RmSettings.from_buffer_copy(z["settings"].tobytes())
+    assert s.fractalIters == iters and g.power == 8.0 and objs[0].type == abi.RM_MANDELBULB and objs[0].scaleFactor == 1.0
+    out = np.empty((len(pts), 4), dtype=np.float32)
+    assert h.oracle().rmo_probe_sdscene(objs, 1, C.byref(g), C.byref(s), h.fptr(pts), h.fptr(out), len(pts)) == 0
+    d64, m64, trap64 = _bulb_de_float64(pts, 8.0, iters)
+    err = np.abs(out[:, 0].astype(np.float64) - d64)
+    rel = err / np.maximum(np.abs(d64), 1e-3)
+    close = (err <= 5e-6) | (rel <= 2e-5)
+    assert close.mean() >= 0.99, f"{(~close).sum()} of {len(pts)} points off (median {np.median(err):.2e})"
+    assert np.median(err) < 2e-7
+    # the orbit-trap components the palette reads (frag:2356-2360) on the agreeing points
+    t_err = np.abs(out[close, 2:].astype(np.float64) - trap64[close][:, :2])
+    assert np.percentile(t_err, 99) < 1e-4
