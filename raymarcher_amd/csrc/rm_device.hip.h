@@ -185,7 +185,9 @@ enum BulbMode { BULB_GENERIC = 0, BULB_TRIG8 = 1, BULB_ALGEBRAIC8 = 2 };
 // form the compiler removed it there by itself; the v_min_f32 form is inline asm, so it is spelled out).
 template <int COUNT, int MODE, bool TRAPMIN, bool TRAP>
 RM_DEV float bulbIterate(const SceneBlock *sb, V3 pos, V4 &resColor, Counters &cnt) {
-  const float power = sb->g.power;
+  // the power-8 instantiations are only entered with sb->g.power == 8.0f: the literal (an inline constant of the multiplies)
+  // instead of a scalar-register operand, which halves a VALU instruction's issue rate (profiles/r03_c_valu_microbench.md)
+  const float power = (MODE == BULB_GENERIC) ? sb->g.power : 8.0f;
   const float pexp = (power - 1.0f) / 2.0f;
   const int iters = sb->s.fractalIters;
   const bool julia = len2(sb->g.juliaSeed[0], sb->g.juliaSeed[1]) != 0.0f;  // frag:782

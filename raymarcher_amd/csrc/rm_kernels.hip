@@ -1177,6 +1177,7 @@ __global__ void check_math_kernel(unsigned long long *out) {
     if (!(ay > 0.0f && ay < 1.262177448e-29f)) {
       const float sn = sqrt_noscale_(y);
       if (f2u(sn) != f2u(sref) && !(sn != sn && sref != sref)) badNoscale++;
+
     }
   }
   if (bad) atomicAdd(&out[0], bad);
