@@ -99,6 +99,10 @@ struct SceneBlock {
   const int32_t *tileOrder;
   uint32_t *tileCost;
   int32_t tileCount;
+  // Uniforms of sdMengerSponge's prologue (frag:1052-1053: ani = smoothstep(−0.2, 0.2, −cos(0.5·iTime)), off = 1.5·sin(0.01·iTime)),
+  // evaluated ONCE per launch by scene_prep_kernel with the contract's own sin / cos instead of once per evaluation per lane
+  // (≈45 of the ≈230 vector instructions of a 5-level evaluation); only read when the table holds a Menger sponge.
+  float mengerAni, mengerOff;
 };
 
 struct SceneMin { int idx; float d; V4 trap; };
@@ -298,10 +302,9 @@ template <bool TRAP>
 RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
   float d = sdBox(p, 1.0f, 1.0f, 1.0f);
   float ty = 1.0f, tz = 0.0f;
-  const float ani = smoothstep_(-0.2f, 0.2f, -cos_(0.5f * sb->g.iTime));
-  const float off = 1.5f * sin_(0.01f * sb->g.iTime);
+  const float ani = sb->mengerAni, off = sb->mengerOff;  // scene_prep_kernel (rm_kernels.hip): the prologue's uniforms
   const int levels = sb->s.mengerLevels;
-  const bool still = __builtin_amdgcn_readfirstlane((int)(ani == 0.0f)) != 0;  // iTime is a uniform
+  const bool still = ani == 0.0f;  // wave-uniform (scalar loads)
   // one level (frag:1057-1069); hs = 0.5·s = 0.5·3^m and the divisor 3^(m+1) as compile-time constants (DIVC > 0)
   auto level = [&](int m, float divc, float hs, float sNext) __attribute__((always_inline)) {
     if (!still) {

@@ -141,6 +141,13 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   }
 }
 
+// sdMengerSponge's uniform prologue (frag:1052-1053), once per launch, with the device's own rm_math (bit-exactness with the
+// oracle needs the contract's sin / cos / smoothstep, which only the device and the oracle implement).
+__global__ void scene_prep_kernel(SceneBlock *sb) {
+  sb->mengerAni = smoothstep_(-0.2f, 0.2f, -cos_(0.5f * sb->g.iTime));
+  sb->mengerOff = 1.5f * sin_(0.01f * sb->g.iTime);
+}
+
 // ---- tile order ------------------------------------------------------------------------------------------
 // The cost of a tile (one workgroup of render_kernel) spans three orders of magnitude: background tiles end after one
 // evaluation, while an interior tile may hold ONE ray that creeps through a crevice for all 256 steps without ever
@@ -689,7 +696,14 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   scene_cull_ball(h);
   ray_planes(h);
   h->tileOrder = tileOrder; h->tileCost = tileCost; h->tileCount = tileCount;
+  h->mengerAni = 0.0f; h->mengerOff = 0.0f;
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
+  bool menger = false;
+  for (int i = 0; i < numObjects; i++) menger = menger || objs[i].type == RM_MENGERSPONGE;
+  if (menger) {  // stream-ordered between the upload and the kernels that read the block
+    hipLaunchKernelGGL(scene_prep_kernel, dim3(1), dim3(1), 0, stream, slot->dev);
+    HIP_OK(hipGetLastError());
+  }
   *slotOut = slot;
   return RM_OK;
 }
