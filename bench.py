@@ -126,9 +126,11 @@ def build_config(name, algebraic=False):
     return t, s, W, H, d
 
 
-def flop_model(t, s, cnt):
+def flop_model(t, s, cnt, executed=False):
     """Algorithmic flops of a frame from its deterministic counters and the scene table (the reference's formulation,
-    independent of how the kernels evaluate it).  Returns (flop, breakdown dict)."""
+    independent of how the kernels evaluate it).  executed=True prices what the kernels really evaluate where that differs
+    from the shader text: the Menger sponge without its per-evaluation uniform prologue (computed once per launch) and,
+    at iTime = 0 (ani = 0), without the per-level rotation mix.  Returns (flop, breakdown dict, model dict)."""
     from raymarcher_amd import abi
     bulb_only = t.num_objects == 1 and t.objects[0].type == abi.RM_MANDELBULB
     per_eval = FLOP_PER_STEP
@@ -138,6 +140,8 @@ def flop_model(t, s, cnt):
             sdf = FLOP_PER_EVAL_BULB - FLOP_PER_OBJECT - FLOP_PER_STEP  # prologue + distance estimate (its iterations are counted apart)
         elif ty == abi.RM_MENGERSPONGE:
             sdf = MENGER_BASE + MENGER_PER_LEVEL * s.mengerLevels
+            if executed:
+                sdf = 19 + (MENGER_PER_LEVEL - (27 if t.globals_.iTime == 0.0 else 0)) * s.mengerLevels
         elif ty == abi.RM_SIERPINSKI:
             sdf = SIERPINSKI_FLOP
         else:
@@ -452,7 +456,7 @@ def main():
 
         mpix = W * H * args.steps / dt / 1e6
         flops_frame, parts, model = flop_model(tables, settings, cnt)
-        flops_exec = flop_model(tables, settings, cnt_exec)[0] if cnt_exec is not None else None
+        flops_exec = flop_model(tables, settings, cnt_exec, executed=True)[0] if cnt_exec is not None else None
         kernel_names = {1: "rm::render_kernel<BULB,COUNT=0,ENV,TEX> (one lane per pixel, 8x8 tile per wave)",
                         2: "pipeline A: bulb_primary+surface+shadow+shade kernels (state machines + lane refill)",
                         3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)",
