@@ -538,6 +538,7 @@ int sim_generic(const RmCamera *cam, const RmObject *objs, int numObjects, const
     Ctx c;
     c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
     c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = NULL; c.numTex = 0; c.res = &none; c.W = W;
+      rayPlanes(cam->invProjView, c.rayPlane);  /* since round 2 the primary rays are interpolated from the quad corners */
     SegTrace st[64];
     memset(st, 0, sizeof st);
     t_cullR2 = 0.0f;
@@ -674,6 +675,7 @@ int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmL
       Ctx c;
       c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
       c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = NULL; c.numTex = 0; c.res = &none; c.W = W;
+      rayPlanes(cam->invProjView, c.rayPlane);  /* since round 2 the primary rays are interpolated from the quad corners */
       memset(px, 0, 256 * sizeof(PixTrace));
       for (int w = 0; w < 4; w++)
         for (int l = 0; l < 64; l++) {
@@ -746,5 +748,79 @@ int sim_run(const RmCamera *cam, const RmObject *objs, int numObjects, const RmL
   for (int i = 0; i < NSCHED; i++) out[o++] = tot.normWave[i];
   for (int i = 0; i < NSCHED; i++) out[o++] = tot.shadWave[i];
   out[o++] = tot.pixels; out[o++] = tot.hits; out[o++] = tot.rays; out[o++] = tot.evals; out[o++] = tot.iters;
+  return RM_OK;
+}
+
+/* ---- cost-sorted lane assignment: the 1024 pixels of a 32x32 super-tile dealt to its 16 waves in the order
+ * of a per-pixel cost — the pixel's own cost of THIS frame (the bound: a perfect predictor), or the cost of the pixel (dx, dy)
+ * away (a previous frame under motion) — against the shipped 8x8 tiles.  out[0] = shipped wave cost, out[1] = sorted by own
+ * cost, out[2] / out[3] = sorted by the cost 2 / 6 pixels away, out[4] = pixels. */
+typedef struct { float c; int i; } SortKey;
+static int cmp_key(const void *a, const void *b) {
+  const float x = ((const SortKey *)a)->c, y = ((const SortKey *)b)->c;
+  return x < y ? 1 : (x > y ? -1 : 0);
+}
+int sim_sorted(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
+               const RmGlobals *g, const RmSettings *s, int W, int H, int stride, float cullRadius, const double *cost,
+               double *out, int threads) {
+  if (numObjects != 1 || objs[0].type != RM_MANDELBULB || numLights > SIM_MAXL) return RM_ERR_UNSUPPORTED;
+  RmResources none;
+  memset(&none, 0, sizeof none);
+  const Cost k = {cost[0], cost[1], cost[2], cost[3], cost[4], cost[5], 0};
+  const int gx = (W + 31) / 32, gy = (H + 31) / 32;
+  double tot[5] = {0, 0, 0, 0, 0};
+#pragma omp parallel num_threads(threads)
+  {
+    PixTrace *px = (PixTrace *)malloc(1024 * sizeof(PixTrace));
+    PixTrace *grp = (PixTrace *)malloc(64 * sizeof(PixTrace));
+    float *c = (float *)malloc(1024 * sizeof(float));
+    SortKey *key = (SortKey *)malloc(1024 * sizeof(SortKey));
+    double loc[5] = {0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 1)
+    for (int b = 0; b < gx * gy; b++) {
+      const int bx = b % gx, by = b / gx;
+      if ((bx + 3 * by) % stride != 0) continue;
+      Ctx cx;
+      cx.cam = cam; cx.objs = objs; cx.numObjects = numObjects; cx.lights = lights; cx.numLights = numLights;
+      cx.g = *g; cx.s = *s; cx.nEval = cx.nIter = cx.nHit = 0; cx.tex = NULL; cx.numTex = 0; cx.res = &none; cx.W = W;
+      rayPlanes(cam->invProjView, cx.rayPlane);
+      memset(px, 0, 1024 * sizeof(PixTrace));
+      for (int ly = 0; ly < 32; ly++)
+        for (int lx = 0; lx < 32; lx++) {
+          const int x = bx * 32 + lx, y = by * 32 + ly;
+          if (x >= W || y >= H) continue;
+          float col[4], br[4];
+          t_pix = &px[ly * 32 + lx]; t_light = 0; t_phase = 0; t_cullR2 = cullRadius * cullRadius;
+          shadePixel(&cx, x, y, W, H, col, br);
+          t_pix = NULL;
+        }
+      for (int i = 0; i < 1024; i++) c[i] = (float)pixel_cost(&px[i], numLights, &k);
+      /* shipped: 16 tiles of 8x8 */
+      for (int ty = 0; ty < 4; ty++)
+        for (int tx = 0; tx < 4; tx++) {
+          for (int l = 0; l < 64; l++) grp[l] = px[(ty * 8 + l / 8) * 32 + tx * 8 + (l % 8)];
+          loc[0] += wave_cost_shipped(grp, numLights, &k);
+        }
+      static const int shift[3][2] = {{0, 0}, {2, 1}, {6, 3}};
+      for (int v = 0; v < 3; v++) {
+        for (int i = 0; i < 1024; i++) {
+          int lx = (i % 32) + shift[v][0], ly = (i / 32) + shift[v][1];
+          if (lx > 31) lx = 31;
+          if (ly > 31) ly = 31;
+          key[i].c = c[ly * 32 + lx]; key[i].i = i;
+        }
+        qsort(key, 1024, sizeof(SortKey), cmp_key);
+        for (int w = 0; w < 16; w++) {
+          for (int l = 0; l < 64; l++) grp[l] = px[key[w * 64 + l].i];
+          loc[1 + v] += wave_cost_shipped(grp, numLights, &k);
+        }
+      }
+      loc[4] += 1024;
+    }
+#pragma omp critical
+    for (int i = 0; i < 5; i++) tot[i] += loc[i];
+    free(px); free(grp); free(c); free(key);
+  }
+  for (int i = 0; i < 5; i++) out[i] = tot[i];
   return RM_OK;
 }
