@@ -344,8 +344,9 @@ int rm_debug_last_path(void);
  * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): feedback — every
  * frame records each tile's shader-cycle cost, and the next frame of the same size on the same stream starts its tiles
  * heaviest-first by those costs (the first frame, and the first after a change of size, run in raster order); mode 0:
- * always raster order; -1: back to the default / the RM_TILE_ORDER environment variable.  Applies to scenes without
- * procedural layers or samplers and to frames of at least 2048 tiles. */
+ * always raster order; -1: back to the default / the RM_TILE_ORDER environment variable.  Applies to every launch of the
+ * one-lane-per-pixel kernel with at least 2048 tiles (not to the 2-D Mandelbrot path, the bulb pipelines or the wavefront
+ * pipeline, whose persistent waves balance themselves). */
 int rm_set_tile_order(int mode);
 /* Experiments: force a given launch order (d_order: a device permutation of 0..tileCount-1, or NULL) and / or collect the
  * tiles' costs (d_cost: tileCount device words, accumulated, or NULL) for subsequent launches on the current device. */

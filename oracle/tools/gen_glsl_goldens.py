@@ -224,6 +224,7 @@ for _grp, _names in _SWEEP.items():
 # unset, frag:1746-1781), its HDR scene (three textured and four plain cubes under three point lights), the five-texture scene
 # of textures_tests (one of the images a GIF) and the sky-box scene (cubemap/beach.json with the reference's own JPEG faces,
 # texture_store/cube_map/beach, loaded as initCubeMap does: RGBA8888, mirrored; realtimerender.cpp:557-590)
+SCENEFILE_CASES["sweep_unit_plane"] = ("simple/unit_plane.json", 48, 27, {}, {})  # the third area-light scene (SwiftShader needs over an hour)
 SCENEFILE_CASES["sweep_refract2"] = ("lighting/refract2.json", 64, 36, dict(enableReflection=1, enableRefraction=1), {})
 SCENEFILE_CASES["sweep_hdr"] = ("lighting/hdr.json", 64, 36, {}, {})
 SCENEFILE_CASES["sweep_directional_light_textured"] = ("textures_tests/directional_light_textured.json", 64, 36, {}, {})

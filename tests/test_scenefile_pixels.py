@@ -1,5 +1,5 @@
 """Scenefile → pixels, end to end, against the REFERENCE: for every BASELINE.json scenefile — and, in a sweep, for every
-other scenefile of the reference that the harness can run (62 fixtures, 45 of the reference's 52 scenefiles) — the fixture
+other scenefile of the reference that the harness can run (63 fixtures, 46 of the reference's 52 scenefiles) — the fixture
 tests/golden/glsl/scenefile_*.npz holds (i) the uniform tables the reference's OWN loader + camera produce for the file
 (oracle/_ref/dump_tables, unmodified reference sources) and (ii) the frame the reference SHADER renders from those tables
 (resources/raymarch.frag on SwiftShader, oracle/tools/gen_glsl_goldens.py scenefile), plus the 8-bit image
@@ -71,6 +71,9 @@ CASES["sweepfull_reflections_basic_ub1"] = ("edge", 0.998, 0.999)
 # textured floor; simple/unit_plane.json, the third such scene, SwiftShader did not finish compiling)
 CASES["sweep_depth_of_field"] = ("edge", 0.998, 1.0)  # ten objects, one of them textured
 CASES["sweep_shadow_test"] = ("smooth", 1.0, 1.0)      # two images on two objects: texture units 0 and 1
+# simple/unit_plane.json (round 3; 48×27): the area light seen edge-on from most of the floor — 8.4 % of the pixels are 0/0 in
+# binary32 (true value ≈ 1e-5, which the reference on SwiftShader and the arbiter return); every other pixel within 6e-6
+CASES["sweep_unit_plane"] = ("ltc", 0.999, 0.09)
 CASES["sweep_bloom"] = ("ltc", 0.98, 0.0)
 CASES["sweep_arealight"] = ("ltc", 0.88, 0.0)
 # round 3: the reference's defined refraction scene (four glass spheres, reflection + refraction on), its HDR scene (three
@@ -120,7 +123,7 @@ def check(name, frame, z, scene_ref, s, textures, **res):
         # cancel EXACTLY in binary32 and the form factor is 0/0.  Those pixels (1-2 %) are NaN in the oracle and on the GPU,
         # rounding residue elsewhere; they are compared as "NaN on both" by the GPU test and left out here.
         nan = np.isnan(frame).any(-1)
-        assert nan.mean() <= 0.02 and np.isfinite(frame[..., 3]).all()
+        assert nan.mean() <= (min_bytes if min_bytes > 0 else 0.02) and np.isfinite(frame[..., 3]).all()  # "ltc": third field = NaN allowance
         f64 = h.arbiter_render(scene_ref, s, W, H, textures=textures, **res)
         d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
         assert (d32[~nan] <= 1e-3).all(), f"{name}: the oracle is not within 1e-3 of the arbiter ({np.nanmax(d32):.2e})"
