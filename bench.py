@@ -293,6 +293,9 @@ def main():
                     help="c3 only.  reference: acos/atan/sin/cos/pow as the shader writes the step (the headline); algebraic: "
                          "RM_FEAT_BULB_POWER8_ALGEBRAIC, the same step by complex squarings (also reported as a variant)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timings: profiling runs")
+    ap.add_argument("--gather", choices=["float4", "rgba8"], default="float4",
+                    help="N > 1: what travels to rank 0 — the float4 tiles (16 B/pixel; every frame ends as a float4 frame on rank 0) or "
+                         "their 8-bit conversion (4 B/pixel; every frame ends as the RGBA8 image saveViewportImage would write)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (RCCL process group, pipelined gather, de-interleave) even with one rank: "
                          "a rehearsal of the multi-GPU path on a one-GPU box")
@@ -331,13 +334,27 @@ def main():
     # complete float4 frame on rank 0 (rm_deinterleave), and the timed region ends only when the last one has.
     # three frames in flight, each on its own stream: the renders of consecutive frames overlap as well (a shard's frame
     # cannot end before its longest ray chain, ≈0.7–0.9 ms, which is 3× the shard's work at N = 8; dist.FramePipeline)
-    pipe = FramePipeline(plan, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True,
-                         finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows))) \
-        if distributed else None
+    rgba8 = distributed and args.gather == "rgba8"
+    if rgba8:
+        # the shard's float4 tiles stay on its GPU (one buffer per frame slot); their 8-bit conversion travels
+        tiles32 = [torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device) for _ in range(3)]
+        pipe = FramePipeline(plan, rank, (W, 4), torch.uint8, r.device, depth=3, multi_stream=True,
+                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave_rgba8(g, W, H, TILE_ROWS, world, slot_rows)))
+    else:
+        pipe = FramePipeline(plan, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True,
+                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows))) \
+            if distributed else None
+    submitted = [0]
 
     def step():
         if not distributed:
             frame_holder["f"] = r.render(tables, settings, W, H, out=mine)
+            return
+        if rgba8:
+            buf = tiles32[submitted[0] % 3]
+            submitted[0] += 1
+            pipe.submit(lambda slot: r.tiles_to_rgba8(r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=buf[:my_rows]),
+                                                      out=slot[:my_rows]))
             return
         pipe.submit(lambda slot: r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=slot[:my_rows]))
 
@@ -376,7 +393,7 @@ def main():
     variants = {}
     single = not distributed and not args.no_variants
     nv = max(3, min(args.steps, 10))
-    if single and schedule == 1 and cfg in ("c2", "c3", "c5"):
+    if single and schedule == 1 and cfg in ("c2", "c3", "c4", "c5"):
         # the same frame without the tile-order feedback (raster order: what a first frame, or a frame after a change of
         # size, costs); the headline's timed frames all ran with the previous frame's tile costs
         L.rm_set_tile_order(0)
@@ -444,7 +461,8 @@ def main():
             assert st == 0, L.rm_last_error()
             return c
         cnt = counted(abi.RM_COUNT_REFERENCE)
-        counted_same = bool(torch.equal(frame_c.view(torch.int32), timed_frame.view(torch.int32)))
+        counted_same = (bool(torch.equal(r.to_rgba8(frame_c), timed_frame)) if rgba8 else
+                        bool(torch.equal(frame_c.view(torch.int32), timed_frame.view(torch.int32))))
         plain = not (settings.features & (abi.RM_FEAT_TERRAIN | abi.RM_FEAT_CLOUD | abi.RM_FEAT_SEA | abi.RM_FEAT_SKY_BACKGROUND
                                           | abi.RM_FEAT_NIGHTSKY_BACKGROUND)) and not tables.textures
         cnt_exec = counted(abi.RM_COUNT_EXECUTED) if plain else None
@@ -510,7 +528,8 @@ def main():
             "config": {"workload": desc["workload"], "baseline_config": desc["baseline_config"], "name": cfg,
                        "rows": "whole frame" if not distributed else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; three frames in "
                                "flight per GPU on three streams (renders of consecutive frames overlap, RCCL gather of frame i "
-                               "to rank 0 runs under later renders); every frame de-interleaved on rank 0",
+                               "to rank 0 runs under later renders); every frame de-interleaved on rank 0"
+                               + (" as the RGBA8 image (4 B/pixel gathered)" if rgba8 else " as a float4 frame (16 B/pixel gathered)"),
                        "tile_order": ("feedback: each frame records its tiles' shader-cycle costs, the next frame starts heavy tiles first "
                                       "(same pixels, same work; variants.raster_tile_order = no history, variants.orbiting_camera = a "
                                       "moving sequence)" if ordered else "not used by this schedule"),

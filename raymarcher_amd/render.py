@@ -263,6 +263,23 @@ class Renderer:
                                     num_shards, shard_stride_rows, self._stream()))
         return frame
 
+    def tiles_to_rgba8(self, tiles, out=None):
+        """rm_tiles_to_rgba8: a shard's packed float4 rows → RGBA8, same rows (clamp → ×255 → round, no flip)."""
+        t = self.torch
+        rows, W = tiles.shape[0], tiles.shape[1]
+        if out is None:
+            out = t.empty((rows, W, 4), dtype=t.uint8, device=self.device)
+        check(lib().rm_tiles_to_rgba8(C.c_void_p(tiles.data_ptr()), C.c_void_p(out.data_ptr()), W, rows, self._stream()))
+        return out
+
+    def deinterleave_rgba8(self, gathered8, W, H, tile_rows, num_shards, shard_stride_rows=0, flip=True):
+        """rm_deinterleave_rgba8: gathered RGBA8 slots → the frame's image (flip: row 0 = top, as to_rgba8 writes it)."""
+        t = self.torch
+        img = t.empty((H, W, 4), dtype=t.uint8, device=self.device)
+        check(lib().rm_deinterleave_rgba8(C.c_void_p(gathered8.data_ptr()), C.c_void_p(img.data_ptr()), W, H, tile_rows, num_shards,
+                                          shard_stride_rows, 1 if flip else 0, self._stream()))
+        return img
+
     def post_process(self, frame, bright, post):
         """rm_post_process: bloom / HDR / gamma / FXAA (applyLightEffects + applyFXAA, realtimerender.cpp:78-165)."""
         t = self.torch

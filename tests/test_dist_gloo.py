@@ -65,11 +65,12 @@ plan = ShardPlan(H, T, world)
 rows = torch.tensor(plan.frame_rows(rank), dtype=torch.float32)
 frames = []
 DEPTH = int(os.environ.get("RM_TEST_DEPTH", "2"))
-pipe = FramePipeline(plan, rank, (W, 4), torch.float32, torch.device("cpu"), depth=DEPTH,
+DT = torch.uint8 if os.environ.get("RM_TEST_DTYPE") == "uint8" else torch.float32   # bench.py --gather rgba8 moves bytes
+pipe = FramePipeline(plan, rank, (W, 4), DT, torch.device("cpu"), depth=DEPTH,
                      finish=lambda g: frames.append(deinterleave_host(g, plan).clone()))
 for k in range(K):
     def render_into(slot, k=k):   # pixel value = 1000·frame + frame row: any mix-up of slots, frames or rows shows
-        slot[:len(rows)] = (1000.0 * k + rows)[:, None, None].expand(len(rows), W, 4)
+        slot[:len(rows)] = ((1000.0 if DT is torch.float32 else 50.0) * k + rows)[:, None, None].expand(len(rows), W, 4).to(DT)
     pipe.submit(render_into)
     assert pipe.frames_finished == max(k - (DEPTH - 2), 0), (k, pipe.frames_finished)   # frame k-(DEPTH-1) is joined inside submit(k)
 pipe.drain()
@@ -77,8 +78,8 @@ ok = pipe.frames_finished == K
 if rank == 0:
     ok = ok and len(frames) == K
     for k, f in enumerate(frames):
-        want = (1000.0 * k + torch.arange(H, dtype=torch.float32))[:, None, None].expand(H, W, 4)
-        ok = ok and bool((f == want).all())
+        want = ((1000.0 if DT is torch.float32 else 50.0) * k + torch.arange(H, dtype=torch.float32))[:, None, None].expand(H, W, 4).to(DT)
+        ok = ok and f.dtype == DT and bool((f == want).all())
 flag = torch.tensor([1 if ok else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.barrier()
@@ -87,8 +88,8 @@ sys.exit(0 if int(flag.item()) == 1 else 3)
 '''
 
 
-@pytest.mark.parametrize("world,depth", [(2, 2), (4, 2), (2, 3), (3, 4)])
-def test_frame_pipeline_gloo(world, depth, tmp_path):
+@pytest.mark.parametrize("world,depth,dtype", [(2, 2, "float32"), (4, 2, "float32"), (2, 3, "float32"), (3, 4, "float32"), (2, 3, "uint8")])
+def test_frame_pipeline_gloo(world, depth, dtype, tmp_path):
     """The pipelined gather bench.py uses for N > 1 (`depth` frames in flight: frame i's gather under the renders of the
     frames after it): every frame arrives complete, in order, through the right slot."""
     script = tmp_path / "pipe_worker.py"
@@ -96,5 +97,5 @@ def test_frame_pipeline_gloo(world, depth, tmp_path):
     port = 29900 + world + 10 * depth + (os.getpid() % 400)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth)), capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth), RM_TEST_DTYPE=dtype), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
