@@ -410,9 +410,10 @@ def main():
             "value": round(W * H / ms / 1e3, 2), "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "kernel_ms": round(k, 4), "steps": nv,
             "what": "RM_FEAT_BULB_POWER8_ALGEBRAIC: w^8 by complex squarings instead of acos/atan/sin/cos/pow; same function, "
                     "|ΔDE| median 4e-8, 0.08 % of frame pixels differ by > 1e-3 from the headline frame"}
-    if single and cfg == "c3":
+    if single and cfg in ("c3", "c5"):
         # three frames in flight, each on its own stream and into its own buffer: a frame's last straggler rays (a serial
-        # chain of ≈0.7 ms) overlap the next frames' full waves — what a caller that renders a sequence gets; never `value`
+        # chain of ≈0.7 ms; for the wavefront pipeline the tail of each of its dozen kernels) overlap the next frames' full
+        # waves — what a caller that renders a sequence gets; never `value`
         streams = [torch.cuda.Stream(device=r.device) for _ in range(3)]
         bufs = [torch.empty((slot_rows, W, 4), dtype=torch.float32, device=r.device) for _ in range(3)]
         nf = max(6, min(args.steps, 30))
@@ -428,7 +429,8 @@ def main():
         variants["three_frames_in_flight"] = {"value": round(W * H * nf / df / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(df / nf * 1e3, 4),
                                               "steps": nf, "frames_identical_to_headline": same,
                                               "what": "the same frames submitted round-robin on three HIP streams (three in flight)"}
-        variants["orbiting_camera"] = orbit_variant(r, L, fence, tables, settings, W, H)
+        if cfg == "c3":
+            variants["orbiting_camera"] = orbit_variant(r, L, fence, tables, settings, W, H)
     if single and schedule == 5:
         # the same frame by the one-lane-per-pixel kernel (rm_set_kernel_path(1)); the headline ran the wavefront pipeline
         L.rm_set_kernel_path(1)
