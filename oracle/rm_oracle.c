@@ -144,7 +144,7 @@ typedef struct {
   const RmResources *res; /* noise / skybox / LTC tables (host pointers); never NULL inside the renderer */
   int W;                  /* screenDimensions.x (frag:246, realtimerender.cpp:622-629) */
   v4 rayPlane[2][2][3];   /* [triangle][near, far][P0, P1 − P0, P2 − P0] of nearClip / farClip, see rayPlanes */
-  uint64_t nEval, nIter, nHit; /* per-thread work counters */
+  uint64_t nEval, nIter, nHit, nShade; /* per-thread work counters */
 } Ctx;
 
 typedef struct { int minObjIdx; float minD; v4 trap; } SceneMin;        /* frag:170-182 */
@@ -864,8 +864,11 @@ static v4 noised3(v3 x) {
   float dz = rm_fma(k7 * u.x, u.y, rm_fma(k5, u.y, rm_fma(k6, u.x, k3)));
   return V4(rm_fma(2.0f, v, -1.0f), (2.0f * du.x) * dx, (2.0f * du.y) * dy, (2.0f * du.z) * dz);
 }
+/* work counters of the procedural layers (per thread; rmo_render sums them): fbm_9 / fbmd_8 evaluations */
+static __thread uint64_t t_nFbm9, t_nFbmd8;
 /* frag:630-644: f = 1.9, m2 = (0.8,0.6 | -0.6,0.8), gain .55 */
 static float fbm_9(float x, float y) {
+  t_nFbm9++;
   const float m00 = 1.9f * 0.80f, m01 = 1.9f * 0.60f, m10 = 1.9f * -0.60f, m11 = 1.9f * 0.80f;  /* (f*m2), c[col][row] */
   float a = 0.0f, b = 0.5f;
   for (int i = 0; i < 9; i++) {
@@ -879,6 +882,7 @@ static float fbm_9(float x, float y) {
 }
 /* frag:647-667 */
 static v4 fbmd_8(v3 x) {
+  t_nFbmd8++;
   const m3 fm3 = m3_scale(&kM3, 2.0f), fm3i = m3_scale(&kM3i, 2.0f);
   float a = 0.0f, b = 0.5f;
   v3 d = V3(0.0f, 0.0f, 0.0f);
@@ -1230,6 +1234,7 @@ static RenderInfo render(Ctx *c, v3 ro, v3 rd, IntersectionInfo *info, float sid
     return ri;
   }
   ri.isEnv = 0; ri.d = res.d;
+  c->nShade++;
   v3 p = v3_madd(rd, res.d, ro);
   v3 pn = getNormal(c, p);
   if (c->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p, 10.0f, 2.0f);
@@ -1621,22 +1626,26 @@ int rmo_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, co
   int st = validate(cam, objs, numObjects, lights, numLights, g, s, res);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || rowBegin < 0 || rowEnd > H || rowBegin > rowEnd || !rgba) return RM_ERR_INVALID_ARGUMENT;
-  uint64_t nEval = 0, nIter = 0, nHit = 0;
+  uint64_t nEval = 0, nIter = 0, nHit = 0, nShade = 0, nFbm9 = 0, nFbmd8 = 0;
   if (threads < 1) threads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : nEval, nIter, nHit)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : nEval, nIter, nHit, nShade, nFbm9, nFbmd8)
   for (int y = rowBegin; y < rowEnd; y++) {
     Ctx c;
     c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
-    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = 0; c.tex = res->textures; c.numTex = res->numTextures;
+    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = c.nShade = 0; c.tex = res->textures; c.numTex = res->numTextures;
     c.res = res; c.W = W;
     rayPlanes(cam->invProjView, c.rayPlane);
+    t_nFbm9 = t_nFbmd8 = 0;
     for (int x = 0; x < W; x++) {
       size_t o = ((size_t)(y - rowBegin) * W + x) * 4;
       shadePixel(&c, x, y, W, H, rgba + o, bright ? bright + o : NULL);
     }
-    nEval += c.nEval; nIter += c.nIter; nHit += c.nHit;
+    nEval += c.nEval; nIter += c.nIter; nHit += c.nHit; nShade += c.nShade; nFbm9 += t_nFbm9; nFbmd8 += t_nFbmd8;
   }
-  if (counters) { counters->sceneEvals = nEval; counters->bulbIters = nIter; counters->hitPixels = nHit; }
+  if (counters) {
+    counters->sceneEvals = nEval; counters->bulbIters = nIter; counters->hitPixels = nHit;
+    counters->shadedPoints = nShade; counters->terrainEvals = nFbm9; counters->cloudEvals = nFbmd8;
+  }
   return RM_OK;
 }
 

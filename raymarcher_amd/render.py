@@ -221,14 +221,15 @@ class Renderer:
         return (out, br) if bright else out
 
     def render_counted(self, tables, settings, W, H, mode=abi.RM_COUNT_REFERENCE):
-        """rm_render_counted_ex: the frame plus its work counters — the reference's work (mode RM_COUNT_REFERENCE) or
-        what the production kernel really executes (RM_COUNT_EXECUTED)."""
+        """rm_render_counted_res: the frame plus its work counters — the reference's work (mode RM_COUNT_REFERENCE) or
+        what the production kernel really executes (RM_COUNT_EXECUTED; plain scene classes only)."""
         t = self.torch
         out = t.empty((H, W, 4), dtype=t.float32, device=self.device)
         cnt = abi.RmCounters()
+        res, _keep = self._resources(tables)
         t.cuda.synchronize(self.device)
-        check(lib().rm_render_counted_ex(*tables.args(settings), W, H, 0, H, C.c_void_p(out.data_ptr()), None, mode,
-                                         C.byref(cnt)))
+        check(lib().rm_render_counted_res(*tables.args(settings), C.byref(res), W, H, 0, H, C.c_void_p(out.data_ptr()), None, mode,
+                                          C.byref(cnt)))
         return out, cnt
 
     def render_clocked(self, tables, settings, W, H, wave_spans=False):

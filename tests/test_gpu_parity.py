@@ -809,6 +809,27 @@ def test_counters_match_oracle(renderer):
     _, cnt = h.oracle_render(scene, s, W, H, counters=True)
     out, gcnt = renderer.render_counted(tables_of(scene), s, W, H)
     assert (gcnt.sceneEvals, gcnt.bulbIters, gcnt.hitPixels) == (cnt.sceneEvals, cnt.bulbIters, cnt.hitPixels)
+    assert gcnt.shadedPoints == cnt.shadedPoints == cnt.hitPixels and gcnt.terrainEvals == gcnt.cloudEvals == 0
+
+
+def test_counters_of_every_kernel_class_match_oracle(renderer):
+    """The units of bench.py's work model — sdScene evaluations, shaded points (bounce hits included), terrain / cloud noise
+    evaluations — from the counting instantiations of the plain, layer and sampler kernels against the oracle's own count, and
+    the counted frames against the production frames."""
+    W, H = 64, 40
+    cases = [(reflect_refract_scene(W, H), abi.default_settings(enableReflection=1, enableRefraction=1, numReflection=2), {}),
+             (env_scene(W, H), abi.default_settings(features=ENV_ALL, enableReflection=1), {}),
+             (textured_scene(W, H), abi.default_settings(), {"textures": synthetic_textures()})]
+    for scene, s, res in cases:
+        ref, cnt = h.oracle_render(scene, s, W, H, counters=True, **res)
+        t = tables_of(scene)
+        for k, v in res.items():
+            setattr(t, k, v)
+        out, g = renderer.render_counted(t, s, W, H)
+        assert (g.sceneEvals, g.bulbIters, g.hitPixels, g.shadedPoints, g.terrainEvals, g.cloudEvals) == \
+               (cnt.sceneEvals, cnt.bulbIters, cnt.hitPixels, cnt.shadedPoints, cnt.terrainEvals, cnt.cloudEvals)
+        assert_bit_equal(out.cpu().numpy(), ref, "counted frame")
+    assert cnt.shadedPoints > 0
 
 
 def test_rgba8_flip_and_png(renderer, tmp_path):
