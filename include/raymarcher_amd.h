@@ -339,6 +339,15 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
 int rm_set_kernel_path(int path);
 /* Tests: the schedule (numbering above; never 0) the most recent render launch on the current device ran, -1 on error. */
 int rm_debug_last_path(void);
+/* Shadow rays in lockstep.  The table-walk kernel has a second instantiation for tables of constant-cost primitives (RM_CUBE …
+ * RM_RECTANGLE) with two or more lights, none of them an area light: the shadow rays of up to three lights of a shading point
+ * (frag:1906-1912) march together through ONE walk of the object table per step instead of one light after the other — the
+ * same evaluations per ray, the same sums in light order, the same pixels; a wave's serial chain of evaluations is shorter,
+ * which is what bounds small frames (1080p, soft shadows, three lights: 1.26 -> 0.96 ms).  mode 1: on for that class (default),
+ * 0: off, -1: back to the default / the RM_LOCKSTEP environment variable.  rm_debug_last_lockstep: 1 if the most recent
+ * render launch on the current device ran that instantiation, 0 if not, -1 on error. */
+int rm_set_lockstep(int mode);
+int rm_debug_last_lockstep(void);
 /* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never
  * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely
  * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): feedback — every

@@ -70,7 +70,11 @@ constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 #ifndef RM_TEX_WAVES
 #define RM_TEX_WAVES 6
 #endif
-template <bool BULB, int COUNT, bool ENV, bool TEX>
+// LOCK: the table-walk kernel for tables of constant-cost primitives with two or more (non-area) lights: a shading point's shadow
+// rays march in lockstep through a shared table walk (rm_device.hip.h, shadowLockstep).  A separate instantiation, so that the
+// register allocation of every other class stays what it was.  Plain class only: the same instantiation of the sampler kernel
+// measured slower on unit_sphere.json at 256² (0.151 -> 0.161 ms; its shadow rays are short), profiles/r03_h_lockstep.md.
+template <bool BULB, int COUNT, bool ENV, bool TEX, bool LOCK = false>
 __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? RM_BULB_WAVES : RM_GENERIC_WAVES)))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   V4 col, br;
   Counters cnt{0, 0, 0, 0, 0};
   bool hit;
-  shadePixel<BULB, CM, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, CM, ENV, TEX, LOCK>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -319,7 +323,9 @@ struct DeviceState {
   uint32_t *dbgTileCost = nullptr;
   int dbgTileCount = 0;
   int lastPath = 0;  // rm_debug_last_path: the schedule of the most recent render launch on this device
+  int lastLockstep = 0;  // rm_debug_last_lockstep: whether that launch was render_kernel's lockstep instantiation
 };
+std::atomic<int> g_lockstepMode{-1};   // rm_set_lockstep: -1 = take RM_LOCKSTEP or the default (on)
 std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_ORDER or the default
 constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
@@ -714,6 +720,17 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 // 25.4 -> 20.2 ms, with one 16.8 -> 16.4 ms); at 1080p its dozen launches of persistent waves cost more than the idle lanes
 // they remove (4.5 -> 5.2 ms, 5.4 -> 7.2 ms), and without secondary rays the one-lane-per-pixel kernel keeps 89-95 % of its
 // lanes busy by itself (directional_light_2.json: 1.3 ms against 3.5 ms).
+// The class of render_kernel<…, LOCK = true>: every object a constant-cost primitive (what sdSceneK evaluates), two or more
+// lights, none of them an area light.
+bool lockstep_class(const RmObject *objs, int numObjects, const RmLight *lights, int numLights) {
+  static const bool envOn = [] { const char *e = getenv("RM_LOCKSTEP"); return !e || atoi(e) != 0; }();
+  const int mode = g_lockstepMode.load();
+  bool ok = (mode >= 0 ? mode != 0 : envOn) && numLights >= 2;
+  for (int i = 0; i < numObjects; i++) ok = ok && objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE;
+  for (int i = 0; i < numLights; i++) ok = ok && lights[i].type != RM_LIGHT_AREA;
+  return ok;
+}
+
 bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels) {
   (void)objs; (void)numObjects;
   return bounces >= 1 && pixels >= (size_t(1) << 22);
@@ -784,7 +801,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
                        tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
   uint32_t *oCost = nullptr, *oHist = nullptr;
   int32_t *oOrder = nullptr;
-  bool haveCost = false;
+  bool haveCost = false, lockstepRan = false;
   if (ordered) {
     void *mem = nullptr;
     if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 8 + 256, &mem)) != RM_OK) return st;
@@ -935,6 +952,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     } else {
       if (count == 1) RM_LAUNCH(false, 1, false, false);
       else if (count == 2) RM_LAUNCH(false, 2, false, false);
+      else if (lockstep_class(objs, numObjects, lights, numLights)) {
+        hipLaunchKernelGGL((render_kernel<false, 0, false, false, true>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+        lockstepRan = true;
+      }
       else RM_LAUNCH(false, 0, false, false);
     }
 #undef RM_LAUNCH
@@ -942,6 +963,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   }
   HIP_OK(hipGetLastError());
   ds.lastPath = pipeline ? path : (wavefront ? 5 : 1);
+  ds.lastLockstep = lockstepRan ? 1 : 0;
   if (timing) { ds.timed.push_back(tl); timedGuard.kept = true; }
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
@@ -1245,6 +1267,17 @@ int rm_debug_last_path(void) {
   if (current_device_state(&ds)) return -1;
   std::lock_guard<std::mutex> lock(ds->mu);
   return ds->lastPath;
+}
+int rm_debug_last_lockstep(void) {
+  DeviceState *ds;
+  if (current_device_state(&ds)) return -1;
+  std::lock_guard<std::mutex> lock(ds->mu);
+  return ds->lastLockstep;
+}
+int rm_set_lockstep(int mode) {
+  if (mode < -1 || mode > 1) { set_error("lockstep mode must be -1, 0 or 1"); return RM_ERR_INVALID_ARGUMENT; }
+  g_lockstepMode.store(mode);
+  return RM_OK;
 }
 int rm_set_kernel_path(int path) {
   if (path < 0 || path > 5) { set_error("kernel path must be 0..5"); return RM_ERR_INVALID_ARGUMENT; }
