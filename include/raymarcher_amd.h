@@ -364,6 +364,12 @@ int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCo
  * farClip (raymarch.vert:23-24 evaluated at the corners of the full-screen quad, realtimerender.cpp:225-238; DESIGN.md
  * §2.3), computed on the host exactly as the launcher stages them.  No GPU needed. */
 int rm_debug_ray_planes(const RmCamera *cam, float *out48);
+/* Tests: the bounds the launcher stages for ending marches whose miss distance nobody reads: out13 = { ok,
+ * centre xyz, R² of the ball, R² of the soft-shadow ball (0 = none), boxOk, box lo xyz, box hi xyz }.  Outside the ball — and,
+ * where boxOk, outside the box — every object's distance value exceeds the hit threshold (0.001) by a wide factor, so a ray
+ * that has left ball ∩ box for good can only miss.  The box is staged only where it is much tighter than the ball (volume
+ * ratio < 0.3).  A pure function of the object table and the globals; no GPU needed. */
+int rm_debug_cull_bounds(const RmObject *objs, int numObjects, const RmGlobals *g, float *out13);
 /* Tests: the kernels' cheap exact forms against the IEEE operations for every one of the 2^32 inputs, on the current device
  * (≈2 s).  mismatches5[0]: the reciprocal (v_rcp_f32 + one Newton step inside 2^-126 <= |y| < 2^126, the IEEE expansion
  * outside) vs 1.0f / y; [1]: the bare fast form over its range; [2]: the square root (v_sqrt_f32 + residual selection, the

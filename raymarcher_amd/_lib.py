@@ -66,6 +66,7 @@ SIGNATURES = {
     "rm_debug_last_lockstep": (C.c_int, []),
     "rm_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rm_debug_ray_planes": (C.c_int, [_P(abi.RmCamera), _P(C.c_float)]),
+    "rm_debug_cull_bounds": (C.c_int, [_P(abi.RmObject), C.c_int, _P(abi.RmGlobals), _P(C.c_float)]),
     "rm_debug_check_math": (C.c_int, [_P(C.c_ulonglong)]),
     "rm_frame_to_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rm_post_process": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(abi.RmPostSettings), C.c_void_p]),

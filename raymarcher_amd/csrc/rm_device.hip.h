@@ -94,6 +94,8 @@ struct SceneBlock {
   float cullR2;
   float cullR2Soft;  // larger ball for soft-shadow rays (0 = none): beyond it 8·d/t >= 1, so the penumbra min() is settled
   int32_t cullOk;
+  float cullLo[3], cullHi[3];  // axis-aligned box with the same property (see scene_cull_ball); cullBoxOk = 0: none
+  int32_t cullBoxOk;
   // Launch order of the workgroups (see rm_kernels.hip, "tile order"): workgroup b renders tile tileOrder[b] (a permutation
   // of 0..tileCount-1, heaviest tiles first) or tile b if null; tileCost (or null) accumulates every tile's shader-cycle cost.
   const int32_t *tileOrder;
@@ -460,6 +462,8 @@ RM_DEV float bulbCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end) {
 // to their object's ball; the bound includes a margin δ with minScale·δ >> the hit threshold), and a march whose miss
 // distance is unused ends where its ray leaves the ball around all of them.  Soft-shadow rays use a larger ball, beyond
 // which 8·d/t >= 1 so that the penumbra factor min(pen, 8·d/t) <= 1 can no longer change (none if the bound is too weak).
+// HARD = true (every march but the soft-shadow ones): also end where the ray leaves the launcher's axis-aligned box.
+template <bool HARD = true>
 RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R2) {
   if (!sb->cullOk || !(R2 > 0.0f)) return end;  // wave-uniform
   const V3 po = v3(ro.x - sb->cullC[0], ro.y - sb->cullC[1], ro.z - sb->cullC[2]);
@@ -469,6 +473,16 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R
   tExit = fma(tExit, 1.0001f, 1.0e-3f);
   if (c > 0.0f && (b >= 0.0f || disc < 0.0f)) tExit = -1.0f;
   if (!(a > 0.0f)) return end;
+  if (HARD && sb->cullBoxOk) {  // wave-uniform
+    // the parameter at which the ray passes the far plane of each slab; beyond the smallest of them it is outside the box for
+    // good.  A zero component gives ±inf (or NaN on the plane itself, which the contract's min ignores); an approximate
+    // reciprocal will do — the margins below absorb its error
+    const float tx = ((rd.x >= 0.0f ? sb->cullHi[0] : sb->cullLo[0]) - ro.x) * __builtin_amdgcn_rcpf(rd.x);
+    const float ty = ((rd.y >= 0.0f ? sb->cullHi[1] : sb->cullLo[1]) - ro.y) * __builtin_amdgcn_rcpf(rd.y);
+    const float tz = ((rd.z >= 0.0f ? sb->cullHi[2] : sb->cullLo[2]) - ro.z) * __builtin_amdgcn_rcpf(rd.z);
+    const float tb = min_(min_(tx, ty), tz);
+    tExit = min_(tExit, fma(fabs_(tb), 1.0e-4f, tb) + 1.0e-3f);
+  }
   return min_(end, tExit);
 }
 template <bool BULB, int COUNT, bool SHADOW, bool CULL = false>
@@ -476,7 +490,8 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
   if (CULL && COUNT != 1) {
     const bool softRay = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform
     if (BULB && !softRay) end = bulbCullEnd(sb, ro, rd, end);
-    else end = sceneCullEnd(sb, ro, rd, end, softRay ? sb->cullR2Soft : sb->cullR2);
+    else if (softRay) end = sceneCullEnd<false>(sb, ro, rd, end, sb->cullR2Soft);
+    else end = sceneCullEnd<true>(sb, ro, rd, end, sb->cullR2);
   }
   float depth = 0.0f;
   float pen = 1.0f;
@@ -944,7 +959,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
       for (int j = 0; j < K; j++) {
         const LightGeom g = lightSetup(sb->lights[l[j]], p, far);
         L[j] = g.L;
-        end[j] = sceneCullEnd(sb, so, g.L, g.maxT, soft ? sb->cullR2Soft : sb->cullR2);
+        end[j] = soft ? sceneCullEnd<false>(sb, so, g.L, g.maxT, sb->cullR2Soft) : sceneCullEnd<true>(sb, so, g.L, g.maxT, sb->cullR2);
         if (!(dot(N, g.L) <= 0.005f)) need |= 1u << j;  // a light that N·L drops is not marched (below)
       }
       shadowLockstep<K, COUNT>(sb, so, L, end, need, soft, hitMask, pen, cnt);

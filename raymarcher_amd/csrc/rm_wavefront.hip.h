@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
             if (decodePixel(id, tilesX, W, nRows, x, r)) {  // else: padding lane of an edge tile, stays NEED
               src = (uint32_t)(r * W + x);
               primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
-              end = sceneCullEnd(sb, ro, rd, far, cullR2);
+              end = sceneCullEnd<true>(sb, ro, rd, far, cullR2);
               if (far >= 0.0f && end < 0.0f) {
                 // the ray starts outside the scene's bounding ball and never enters it: its one evaluation cannot hit (the
                 // ball's margin keeps every distance value above the hit threshold) and then depth 0 > end — the background
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
             src = id;
             ro = v3(O.x, O.y, O.z);
             rd = v3(D.x, D.y, D.z);
-            end = sceneCullEnd(sb, ro, rd, far, cullR2);
+            end = sceneCullEnd<true>(sb, ro, rd, far, cullR2);
             depth = 0.0f; steps = 0;
             st = ST_MARCH;
           } else {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
               if (!(dot(N, L) <= 0.005f)) {                  // frag:1912 drops the light otherwise: its ray is not marched
                 ro = shadowOrigin(p, N);
                 rd = L;
-                end = sceneCullEnd(sb, ro, rd, maxT, cullR2);
+                end = soft ? sceneCullEnd<false>(sb, ro, rd, maxT, cullR2) : sceneCullEnd<true>(sb, ro, rd, maxT, cullR2);
                 depth = 0.0f; pen = 1.0f; steps = 0;
                 src = li * ws.cap + h;
                 st = ST_MARCH;

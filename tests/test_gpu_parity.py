@@ -1217,6 +1217,58 @@ def test_bounding_ball_cull_edge_cases(renderer):
             assert (ref[..., :3] != 1.0).any(-1).mean() > 0.02, f"case {k}: the objects must be in view"
 
 
+
+def test_bounding_box_cull_edge_cases(renderer):
+    """The launcher's bounding BOX on top of the ball (flat / elongated scenes; rm_debug_cull_bounds) must never change a bit:
+    rays with exactly zero direction components (axis-aligned views and lights — the slab test divides by them), the camera on
+    a face plane of the box, inside it, below the floor, a far plane inside the box, secondary rays, hard and soft shadows."""
+    from raymarcher_amd import lib
+    W, H = 72, 48
+    mat = dict(ambient=(.1, .1, .1), diffuse=(.7, .6, .5), specular=(.8, .8, .8), shininess=20, reflective=(.5, .5, .5),
+               transparent=(.3, .3, .3), ior=1.3)
+    objs = (abi.RmObject * 5)(
+        h.make_object(abi.RM_CUBE, model=h.translate(0, -1, 0) @ h.scale(14, 0.2, 6), scale_factor=0.2, **mat),
+        h.make_object(abi.RM_SPHERE, model=h.translate(-4, -0.4, 0), **mat),
+        h.make_object(abi.RM_CONE, model=h.translate(-1.5, -0.4, 0.5) @ rot_x(0.3), **mat),
+        h.make_object(abi.RM_CYLINDER, model=h.translate(1.5, -0.4, -0.5), **mat),
+        h.make_object(abi.RM_TORUS, model=h.translate(4.5, -0.3, 0.2) @ rot_x(1.2) @ h.scale(1.5, 1.5, 1.5), scale_factor=1.5, **mat))
+    g = h.make_globals()
+    b = np.zeros(13, dtype=np.float32)
+    assert lib().rm_debug_cull_bounds(objs, 5, C.byref(g), b.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert b[0] == 1 and b[6] == 1, "the scene must have its box"
+    lo, hi = b[7:10], b[10:13]
+    # lights along the axes: direction components exactly zero
+    lights = (abi.RmLight * 3)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (0, -1, 0)),
+                               h.make_light(abi.RM_LIGHT_DIRECTIONAL, (.6, .6, .9), (-1, 0, 0)),
+                               h.make_light(abi.RM_LIGHT_POINT, (.9, .8, .7), pos=(0, 3, 4), func=(0.7, 0.05, 0)))
+    cams = [h.make_camera((0, 0.3, 9), (0, 0, -1), (0, 1, 0), 40.0, W, H),            # along −z: the centre column has rd.x = 0
+            h.make_camera((0, 8, 0.0), (0, -1, 0), (0, 0, -1), 50.0, W, H),           # straight down
+            h.make_camera((float(hi[0]), 0.5, 2), (-1, -0.1, -0.3), (0, 1, 0), 50.0, W, H),   # on the box's +x face plane
+            h.make_camera((0.5, float(hi[1]), 3), (0, -0.2, -1), (0, 1, 0), 50.0, W, H),      # on its top plane
+            h.make_camera((0.2, 0.0, 1.5), (0.3, -0.2, -1), (0, 1, 0), 60.0, W, H),   # inside the box
+            h.make_camera((0, -3, 4), (0, 0.6, -1), (0, 1, 0), 50.0, W, H),           # below the floor, looking up at it
+            h.make_camera((0, 0.3, 9), (0, 0, -1), (0, 1, 0), 40.0, W, H, far=8.0)]   # far plane inside the box
+    for k, cam in enumerate(cams):
+        scene = (cam, objs, 5, lights, 3, g)
+        for over in ({"enableReflection": 1, "enableRefraction": 1, "numReflection": 2}, {"enableSoftShadow": 1, "enableAmbientOcclusion": 1}):
+            s = abi.default_settings(features=abi.RM_FEAT_WHITE_BACKGROUND, **over)
+            ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+            out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+            assert_bit_equal(out.cpu().numpy(), ref, f"box cull camera {k} {over}")
+            assert_bit_equal(br.cpu().numpy(), ref_b, f"box cull camera {k} {over} bright")
+    # the same through the wavefront pipeline (its refill computes the march ends)
+    try:
+        lib().rm_set_kernel_path(5)
+        s = abi.default_settings(features=abi.RM_FEAT_WHITE_BACKGROUND, enableReflection=1, numReflection=2)
+        for k in (0, 2, 4):
+            scene = (cams[k], objs, 5, lights, 3, g)
+            out = renderer.render(tables_of(scene), s, W, H)
+            assert lib().rm_debug_last_path() == 5
+            assert_bit_equal(out.cpu().numpy(), h.oracle_render(scene, s, W, H), f"box cull, wavefront, camera {k}")
+    finally:
+        lib().rm_set_kernel_path(0)
+
+
 CXX_HOST = r'''
 // A C++ host with no Python and no torch: what a maintainer of the reference links (INTEGRATION.md §1).
 #include <hip/hip_runtime_api.h>
