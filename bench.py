@@ -376,7 +376,6 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     schedule = L.rm_debug_last_path()
-    lockstep = L.rm_debug_last_lockstep() == 1
     timed_frame = frame_holder["f"].clone() if rank == 0 else None  # what the timed region produced (checked below)
     import ctypes as C
     kms, kn = C.c_double(), C.c_int()
@@ -403,16 +402,6 @@ def main():
         variants["raster_tile_order"] = {"value": round(W * H / ms / 1e3, 2), "unit": "Mpixels/s", "ms_per_step": round(ms, 4),
                                          "kernel_ms": round(k, 4), "steps": nv,
                                          "what": "rm_set_tile_order(0): tiles start in raster order — a frame with no history"}
-    if single and lockstep:
-        # the same frame with the shadow rays of a shading point marched light after light (rm_set_lockstep(0)); the headline
-        # ran the lockstep instantiation (up to three shadow rays per table walk); never `value`
-        L.rm_set_lockstep(0)
-        ms, k = timed_frames(r, L, fence, lambda: r.render(tables, settings, W, H, out=mine), nv)
-        same = bool(torch.equal(mine.view(torch.int32), timed_frame.view(torch.int32)))
-        L.rm_set_lockstep(-1)
-        variants["shadow_rays_light_after_light"] = {"value": round(W * H / ms / 1e3, 2), "unit": "Mpixels/s", "ms_per_step": round(ms, 4),
-                                                     "kernel_ms": round(k, 4), "steps": nv, "frame_identical_to_headline": same,
-                                                     "what": "rm_set_lockstep(0): render_kernel without the lockstep shadow marches"}
     if single and cfg == "c3" and args.bulb_eval == "reference":
         # the opt-in evaluation scheme of the same step, timed beside the headline (single GPU only; never `value`)
         vs = abi.default_settings(fractalIters=12, features=abi.RM_FEAT_REFERENCE_DEFAULT | abi.RM_FEAT_BULB_POWER8_ALGEBRAIC)
@@ -488,8 +477,7 @@ def main():
         mpix = W * H * args.steps / dt / 1e6
         flops_frame, parts, model = flop_model(tables, settings, cnt)
         flops_exec = flop_model(tables, settings, cnt_exec, executed=True)[0] if cnt_exec is not None else None
-        kernel_names = {1: "rm::render_kernel<BULB,COUNT=0,ENV,TEX" + (",LOCK" if lockstep else "") + "> (one lane per pixel, 8x8 tile per wave"
-                           + ("; the shadow rays of a shading point in lockstep through a shared table walk)" if lockstep else ")"),
+        kernel_names = {1: "rm::render_kernel<BULB,COUNT=0,ENV,TEX> (one lane per pixel, 8x8 tile per wave)",
                         2: "pipeline A: bulb_primary+surface+shadow+shade kernels (state machines + lane refill)",
                         3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)",
                         4: "pipeline C: pipeline B with step-budgeted march passes and re-compaction",

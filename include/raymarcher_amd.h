@@ -339,15 +339,6 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
 int rm_set_kernel_path(int path);
 /* Tests: the schedule (numbering above; never 0) the most recent render launch on the current device ran, -1 on error. */
 int rm_debug_last_path(void);
-/* Shadow rays in lockstep.  The table-walk kernel has a second instantiation for tables of constant-cost primitives (RM_CUBE …
- * RM_RECTANGLE) with two or more lights, none of them an area light: the shadow rays of up to three lights of a shading point
- * (frag:1906-1912) march together through ONE walk of the object table per step instead of one light after the other — the
- * same evaluations per ray, the same sums in light order, the same pixels; a wave's serial chain of evaluations is shorter,
- * which is what bounds small frames (1080p, soft shadows, three lights: 1.26 -> 0.96 ms).  mode 1: on for that class (default),
- * 0: off, -1: back to the default / the RM_LOCKSTEP environment variable.  rm_debug_last_lockstep: 1 if the most recent
- * render launch on the current device ran that instantiation, 0 if not, -1 on error. */
-int rm_set_lockstep(int mode);
-int rm_debug_last_lockstep(void);
 /* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never
  * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely
  * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): feedback — every
@@ -364,12 +355,13 @@ int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCo
  * farClip (raymarch.vert:23-24 evaluated at the corners of the full-screen quad, realtimerender.cpp:225-238; DESIGN.md
  * §2.3), computed on the host exactly as the launcher stages them.  No GPU needed. */
 int rm_debug_ray_planes(const RmCamera *cam, float *out48);
-/* Tests: the bounds the launcher stages for ending marches whose miss distance nobody reads: out13 = { ok,
- * centre xyz, R² of the ball, R² of the soft-shadow ball (0 = none), boxOk, box lo xyz, box hi xyz }.  Outside the ball — and,
+/* Tests: the bounds the launcher stages for ending marches whose miss distance nobody reads: out14 = { ok,
+ * centre xyz, R² of the ball, R² of the soft-shadow ball (0 = none), boxOk, box lo xyz, box hi xyz, lip }.  Outside the ball — and,
  * where boxOk, outside the box — every object's distance value exceeds the hit threshold (0.001) by a wide factor, so a ray
  * that has left ball ∩ box for good can only miss.  The box is staged only where it is much tighter than the ball (volume
- * ratio < 0.3).  A pure function of the object table and the globals; no GPU needed. */
-int rm_debug_cull_bounds(const RmObject *objs, int numObjects, const RmGlobals *g, float *out13);
+ * ratio < 0.3).  lip: no object's distance value changes by more than lip per unit of world length (+inf with a fractal in
+ * the table): the seed of the table walk's skip test.  A pure function of the object table and the globals; no GPU needed. */
+int rm_debug_cull_bounds(const RmObject *objs, int numObjects, const RmGlobals *g, float *out14);
 /* Tests: the kernels' cheap exact forms against the IEEE operations for every one of the 2^32 inputs, on the current device
  * (≈2 s).  mismatches5[0]: the reciprocal (v_rcp_f32 + one Newton step inside 2^-126 <= |y| < 2^126, the IEEE expansion
  * outside) vs 1.0f / y; [1]: the bare fast form over its range; [2]: the square root (v_sqrt_f32 + residual selection, the

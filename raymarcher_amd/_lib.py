@@ -62,8 +62,6 @@ SIGNATURES = {
     "rm_set_kernel_path": (C.c_int, [C.c_int]),
     "rm_debug_last_path": (C.c_int, []),
     "rm_set_tile_order": (C.c_int, [C.c_int]),
-    "rm_set_lockstep": (C.c_int, [C.c_int]),
-    "rm_debug_last_lockstep": (C.c_int, []),
     "rm_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rm_debug_ray_planes": (C.c_int, [_P(abi.RmCamera), _P(C.c_float)]),
     "rm_debug_cull_bounds": (C.c_int, [_P(abi.RmObject), C.c_int, _P(abi.RmGlobals), _P(C.c_float)]),

@@ -66,7 +66,9 @@ struct EvalRecord {
   float m[12];  // invModel[0..2], [4..6], [8..10], [12..14]
   float scaleFactor;
   int32_t type;
-  int32_t pad[2];
+  // object-space bound for the table walk's skip test: the unit shape lies inside the ball |p| <= boundR (sdMatch's sizes,
+  // +inf for types without one), so its distance value is >= (|p_object| − boundR)·scaleFactor; invScale = 1 / scaleFactor
+  float invScale, boundR;
 };
 static_assert(sizeof(EvalRecord) == 64, "one cache line");
 struct SceneBlock {
@@ -94,6 +96,7 @@ struct SceneBlock {
   float cullR2;
   float cullR2Soft;  // larger ball for soft-shadow rays (0 = none): beyond it 8·d/t >= 1, so the penumbra min() is settled
   int32_t cullOk;
+  float cullLip;  // Lipschitz bound of every object's distance value per unit of world length (+inf with a fractal in the table)
   float cullLo[3], cullHi[3];  // axis-aligned box with the same property (see scene_cull_ball); cullBoxOk = 0: none
   int32_t cullBoxOk;
   // Launch order of the workgroups (see rm_kernels.hip, "tile order"): workgroup b renders tile tileOrder[b] (a permutation
@@ -353,8 +356,17 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
 // ---- scene union (frag:1406-1430) ---------------------------------------------------------------------
 // BULB=true is the single-Mandelbulb scene class (numObjects == 1, type MANDELBULB): same arithmetic,
 // no table walk.
-template <bool BULB, int COUNT, bool TRAP = true>
-RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
+// SKIP (table-walk classes, march loops): an object whose bounding ball is farther from EVERY live lane's point than that
+// lane's current minimum cannot lower it (its value is >= (|p_object| − boundR)·scaleFactor, and the update below is a strict
+// <): the wave passes over it after the transform — 6 instructions and a wave-uniform branch instead of the shape's 20-50.
+// The 8×8 pixel tile of a wave is spatially coherent, so whole waves agree often; a wave down to its last straggler lanes
+// (the serial chains that end small frames) agrees almost always.
+// ub: an upper bound of the minimum this call will return (+inf: none).  The march loops know one: every admitted shape's
+// distance value changes by at most sb->cullLip per unit of world length (exact SDFs are 1-Lipschitz and scaleFactor undoes the
+// model matrix's stretch), so the minimum at the next point is at most the minimum at this one plus cullLip × the step.  With
+// it the test does not depend on the nearest object coming early in the table.
+template <bool BULB, int COUNT, bool TRAP = true, bool SKIP = false>
+RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __builtin_inff()) {
   SceneMin res;
   res.d = 1000000.0f;
   res.idx = -1;
@@ -373,6 +385,11 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
     V3 po = v3(fma(M[6], p.z, fma(M[3], p.y, fma(M[0], p.x, M[9]))),
                fma(M[7], p.z, fma(M[4], p.y, fma(M[1], p.x, M[10]))),
                fma(M[8], p.z, fma(M[5], p.y, fma(M[2], p.x, M[11]))));  // frag:1417
+    if (SKIP && !BULB) {
+      const float lim = fma(ub, o.invScale, o.boundR);
+      const bool far = (lim >= 0.0f) && (dot(po, po) > (lim * lim) * 1.00003f);
+      if (__ballot(!far) == 0ull) continue;
+    }
     float d;
     const int type = BULB ? (int)RM_MANDELBULB : o.type;
     switch (type) {  // sdMatch, frag:1262-1293 — wave-uniform branch
@@ -393,13 +410,22 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt) {
     }
     float cur = d * scaleFactor;  // frag:1419
     if (cur < res.d) { res.d = cur; res.idx = i; }
+    if (SKIP && !BULB) ub = min_(ub, cur);
   }
   return res;
 }
+// The bound for the next evaluation of a march that has just stepped by |d| along rd: d + cullLip·|d|·|rd|, with slack for
+// the rounding of the point (lipLen = cullLip·|rd|, padded, once per march).  NaN / inf (a fractal in the table: cullLip = inf)
+// disable the test.
+RM_DEV float nextMinBound(float d, float lipLen, float depth) {
+  const float ub = fma(fabs_(d), lipLen, d);
+  return fma(fabs_(ub), 1.0e-4f, ub) + fma(depth, 1.0e-6f, 1.0e-5f);
+}
 
 // frag:1436-1444
-template <bool BULB, int COUNT>
-RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
+// ub: an upper bound of sdScene at p + any tap (the taps are 0.0005 from p), +inf = none; SKIP as in sdScene.
+template <bool BULB, int COUNT, bool SKIP = false>
+RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __builtin_inff()) {
   const float ex = (1.0f * 0.5773f) * 0.0005f, ey = (-1.0f * 0.5773f) * 0.0005f;
   float d[4];
 #pragma unroll 1
@@ -408,7 +434,7 @@ RM_DEV V3 getNormal(const SceneBlock *sb, V3 p, Counters &cnt) {
     float ox = (k == 0 || k == 3) ? ex : ey;
     float oy = (k >= 2) ? ex : ey;
     float oz = (k == 1 || k == 3) ? ex : ey;
-    float v = sdScene<BULB, COUNT, false>(sb, v3(p.x + ox, p.y + oy, p.z + oz), cnt).d;
+    float v = sdScene<BULB, COUNT, false, SKIP>(sb, v3(p.x + ox, p.y + oy, p.z + oz), cnt, ub).d;
     d[0] = (k == 0) ? v : d[0];
     d[1] = (k == 1) ? v : d[1];
     d[2] = (k == 2) ? v : d[2];
@@ -485,8 +511,9 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R
   }
   return min_(end, tExit);
 }
+// ub0: an upper bound of sdScene at ro (+inf = none), for the first evaluation's skip test.
 template <bool BULB, int COUNT, bool SHADOW, bool CULL = false>
-RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt) {
+RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt, float ub0 = __builtin_inff()) {
   if (CULL && COUNT != 1) {
     const bool softRay = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform
     if (BULB && !softRay) end = bulbCullEnd(sb, ro, rd, end);
@@ -499,8 +526,11 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
   c.d = 1000000.0f; c.idx = -1; c.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
   const int steps = sb->s.maxSteps;
   const bool soft = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform: the penumbra factor is read only then
+  constexpr bool SKIP = CULL && !BULB && COUNT != 1;
+  const float lipLen = SKIP ? (sb->cullLip * len(rd)) * 1.0001f : 0.0f;
+  float ub = ub0;
   for (int i = 0; i < steps; i++) {
-    c = sdScene<BULB, COUNT, !SHADOW>(sb, madd(rd, depth, ro), cnt);
+    c = sdScene<BULB, COUNT, !SHADOW, SKIP>(sb, madd(rd, depth, ro), cnt, ub);
     if (fabs_(c.d) < kSurfaceDist || depth > end) break;
     if (SHADOW) {
       if (soft) pen = min_(pen, divr_(8.0f * c.d, depth));
@@ -508,6 +538,7 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
     } else {
       depth = fma(c.d, side, depth);
     }
+    if (SKIP) ub = nextMinBound(c.d, lipLen, depth);
   }
   MarchRes r;
   bool hit = fabs_(c.d) < kSurfaceDist;
@@ -584,12 +615,14 @@ RM_DEV V3 bumpNormal(V3 normal, V3 pos) {  // frag:1679-1691, BUMP_SCALE 10, BUM
 
 // ---- shading --------------------------------------------------------------------------------------------
 // frag:1729-1740
-template <bool BULB, int COUNT>
-RM_DEV float calcAO(const SceneBlock *sb, V3 pos, V3 nor, Counters &cnt) {
+// ubPos: an upper bound of sdScene at pos (+inf = none); a tap lies h·|nor| from it.
+template <bool BULB, int COUNT, bool SKIP = false>
+RM_DEV float calcAO(const SceneBlock *sb, V3 pos, V3 nor, Counters &cnt, float ubPos = __builtin_inff()) {
   float occ = 0.0f, sca = 1.0f;
+  const float lipN = SKIP ? (sb->cullLip * len(nor)) * 1.001f : 0.0f;
   for (int i = 0; i < 5; i++) {
     float h = 0.01f + ((0.12f * (float)i) / 4.0f);
-    float d = sdScene<BULB, COUNT, false>(sb, madd(nor, h, pos), cnt).d;
+    float d = sdScene<BULB, COUNT, false, SKIP>(sb, madd(nor, h, pos), cnt, SKIP ? fma(h, lipN, ubPos) : ubPos).d;
     occ = fma(h - d, sca, occ);
     sca = sca * 0.95f;
     if (occ > 0.35f) break;
@@ -812,111 +845,19 @@ RM_DEV uint32_t shadowQueue(const SceneBlock *sb, V3 so, uint32_t need, float fa
   return hitMask;
 }
 
-// ---- K shadow rays of one shading point in lockstep (table-walk classes, constant-cost primitives only) -------------
-// getPhong's light loop marches the shadow rays of a shading point one light after the other: a wave's shading phase is a serial
-// chain of numLights × (longest ray) evaluations, and every evaluation pays the table walk's scalar side (record loads,
-// the sdMatch branch chain) for ONE point per lane.  A 1080p frame holds too few waves to hide that: the frame ends with a few
-// waves finishing their chains alone (three frames in flight run 35 % faster per frame, profiles/r03_h_lockstep.md).
-// sdSceneK walks the table once for K points per lane — one record load and one branch chain per object, K independent
-// dependency chains for the vector pipe — and shadowLockstep marches K rays with it: every ray is the very same sequence
-// of evaluations as in march<…, SHADOW = true> (same origin, direction, cull end, step cap, hit test, penumbra update); while
-// all K rays are live somewhere in the wave they share the walk, afterwards the remaining ones run as single evaluations.
-template <int K>
-RM_DEV void sdSceneK(const SceneBlock *sb, const V3 (&p)[K], float (&dmin)[K]) {
-#pragma unroll
-  for (int j = 0; j < K; j++) dmin[j] = 1000000.0f;
-  const int n = sb->numObjects;
-  for (int i = 0; i < n; i++) {
-    const EvalRecord &o = sb->evalRec[i];
-    float M[12];
-#pragma unroll
-    for (int c = 0; c < 12; c++) M[c] = o.m[c];
-    const float scaleFactor = o.scaleFactor;
-    V3 po[K];
-#pragma unroll
-    for (int j = 0; j < K; j++)
-      po[j] = v3(fma(M[6], p[j].z, fma(M[3], p[j].y, fma(M[0], p[j].x, M[9]))),
-                 fma(M[7], p[j].z, fma(M[4], p[j].y, fma(M[1], p[j].x, M[10]))),
-                 fma(M[8], p[j].z, fma(M[5], p[j].y, fma(M[2], p[j].x, M[11]))));  // frag:1417
-    float d[K];
-#define RM_EACH(expr) _Pragma("unroll") for (int j = 0; j < K; j++) d[j] = (expr)
-    switch (o.type) {  // sdMatch, frag:1262-1293 — wave-uniform branch; the launcher admits only these types (lockstep_class)
-      case RM_CUBE: RM_EACH(sdBox(po[j], 0.5f, 0.5f, 0.5f)); break;
-      case RM_CONE: RM_EACH(sdCone(po[j], 0.5f, 0.5f)); break;
-      case RM_CYLINDER: RM_EACH(sdCylinder(po[j], 0.5f, 0.5f)); break;
-      case RM_SPHERE: RM_EACH(len(po[j]) - 0.5f); break;
-      case RM_OCTAHEDRON: RM_EACH(sdOctahedron(po[j], 0.5f)); break;
-      case RM_TORUS: RM_EACH(sdTorus(po[j], 0.5f, 0.125f)); break;
-      case RM_CAPSULE: RM_EACH(sdCapsule(po[j], 0.5f, 0.1f)); break;
-      case RM_DEATHSTAR: RM_EACH(sdDeathStar(po[j], 0.5f, 0.35f, 0.5f)); break;
-      case RM_RECTANGLE: RM_EACH(sdBox(po[j], 0.5f, 0.5f, 0.0f)); break;
-      default: continue;
-    }
-#undef RM_EACH
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      const float cur = d[j] * scaleFactor;  // frag:1419
-      dmin[j] = (cur < dmin[j]) ? cur : dmin[j];
-    }
-  }
-}
-// need: bit j = this lane marches ray j.  Out: hitMask bit j and pen[j] = what march<…, SHADOW = true> returns as obj != −1 and d.
-// While all K rays are live SOMEWHERE in the wave they share one table walk; afterwards the remaining ones are plain sdScene
-// evaluations.
-template <int K, int COUNT>
-RM_DEV void shadowLockstep(const SceneBlock *sb, V3 so, const V3 (&L)[K], const float (&end)[K], uint32_t need, bool soft,
-                           uint32_t &hitMask, float (&pen)[K], Counters &cnt) {
-  float depth[K];
-#pragma unroll
-  for (int j = 0; j < K; j++) { depth[j] = 0.0f; pen[j] = 1.0f; }
-  hitMask = 0u;
-  uint32_t live = need;
-  const int steps = sb->s.maxSteps;
-  for (int i = 0; i < steps; i++) {
-    uint32_t U = 0u;  // rays live somewhere in the wave (wave-uniform)
-#pragma unroll
-    for (int j = 0; j < K; j++) U |= (__ballot((live >> j) & 1u) != 0ull) ? (1u << j) : 0u;
-    if (U == 0u) break;
-    float d[K];
-    if (U == (1u << K) - 1u) {
-      V3 p[K];
-#pragma unroll
-      for (int j = 0; j < K; j++) p[j] = madd(L[j], depth[j], so);
-      sdSceneK<K>(sb, p, d);
-    } else {
-      Counters none{0, 0, 0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        d[j] = 0.0f;
-        if ((U >> j) & 1u) d[j] = sdScene<false, 0, false>(sb, madd(L[j], depth[j], so), none).d;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      if ((live >> j) & 1u) {
-        if (COUNT) cnt.evals++;
-        const bool h = fabs_(d[j]) < kSurfaceDist;
-        if (h || depth[j] > end[j]) {
-          live &= ~(1u << j);
-          hitMask |= h ? (1u << j) : 0u;
-        } else {
-          if (soft) pen[j] = min_(pen[j], divr_(8.0f * d[j], depth[j]));
-          depth[j] = depth[j] + fabs_(d[j]);
-        }
-      }
-    }
-  }
-}
-
 // frag:1842-1933 with getDiffuse's untextured path (frag:1749-1752) and getSpecular (frag:1787-1792)
 // RES = true adds the area-light branch (frag:1884-1905); `objs` is only read there.
-// CULLS: 1 = end marches at the scene's bounding ball (0 in the ENV instantiations, whose register budget it would break);
-// 2 = that, and the shadow rays of a shading point in lockstep (the LOCK instantiation of the table-walk kernel).
-template <bool BULB, int COUNT, bool RES, int CULLS>
-RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt) {
+// CULLS: end marches at the scene's bounds and pass over far objects in the table walk (off in the ENV instantiations, whose
+// register budget it would break).
+template <bool BULB, int COUNT, bool RES, bool CULLS>
+RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt,
+                   float ubPos = __builtin_inff()) {
+  constexpr bool SKIP = CULLS && !BULB && COUNT != 1;
   const float ka = sb->g.ka, ks = sb->g.ks;
   float ao = 1.0f;
-  if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT>(sb, p, N, cnt);
+  if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT, SKIP>(sb, p, N, cnt, ubPos);
+  // the shadow rays start 0.005·|N| from p
+  const float ubSo = SKIP ? fma(0.005f, (sb->cullLip * len(N)) * 1.001f, ubPos) : ubPos;
   V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);
   const V3 V = normalize(neg(rd));
   const V3 so = shadowOrigin(p, N);
@@ -935,7 +876,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
         const V3 L = normalize(v3(-li.dir[0], -li.dir[1], -li.dir[2]));
         if (!(dot(N, L) <= 0.005f)) need |= 1u << i;  // a light that N·L drops is not marched (see below)
       }
-      const uint32_t hitMask = shadowQueue<BULB, COUNT, CULLS != 0>(sb, so, need, far, cnt);
+      const uint32_t hitMask = shadowQueue<BULB, COUNT, CULLS>(sb, so, need, far, cnt);
       for (int i = 0; i < nl; i++) {
         const RmLight &li = sb->lights[i];
         const LightGeom g = lightSetup(li, p, far);
@@ -944,60 +885,6 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
       }
       return total;
     }
-  }
-  if (!BULB && !RES && CULLS == 2) {
-    // the lockstep instantiation (the launcher picks it for tables of constant-cost primitives with two or more lights, none
-    // of them an area light): the shadow rays of up to three lights at a time (shadowLockstep), contributions in light order
-    // Lights that no lane of the wave needs (N·L <= 0.005 everywhere) contribute nothing and are left out, so the groups are
-    // formed from the lights the wave does march: l[] are wave-uniform indices, ascending.
-    auto group = [&](auto kTag, const int (&l)[3]) __attribute__((always_inline)) {
-      constexpr int K = decltype(kTag)::value;
-      V3 L[K];
-      float end[K], pen[K];
-      uint32_t need = 0u, hitMask;
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        const LightGeom g = lightSetup(sb->lights[l[j]], p, far);
-        L[j] = g.L;
-        end[j] = soft ? sceneCullEnd<false>(sb, so, g.L, g.maxT, sb->cullR2Soft) : sceneCullEnd<true>(sb, so, g.L, g.maxT, sb->cullR2);
-        if (!(dot(N, g.L) <= 0.005f)) need |= 1u << j;  // a light that N·L drops is not marched (below)
-      }
-      shadowLockstep<K, COUNT>(sb, so, L, end, need, soft, hitMask, pen, cnt);
-#pragma unroll 1
-      for (int j = 0; j < K; j++) {
-        const int lj = (j == 0) ? l[0] : ((j == 1) ? l[1] : l[2]);
-        const RmLight &li = sb->lights[lj];
-        const LightGeom g = lightSetup(li, p, far);
-        float pj = pen[0];
-#pragma unroll
-        for (int q = 1; q < K; q++) pj = (j == q) ? pen[q] : pj;
-        V3 cur;
-        if (lightTerm(li, g, mat, N, V, ks, ((hitMask >> j) & 1u) ? 0 : -1, pj, soft, cur)) total = add(total, cur);
-      }
-    };
-    uint32_t rest = 0u;  // lights some lane of the wave marches (wave-uniform)
-    for (int i = 0; i < nl; i++) {
-      const LightGeom g = lightSetup(sb->lights[i], p, far);
-      if (__ballot(!(dot(N, g.L) <= 0.005f)) != 0ull) rest |= 1u << i;
-    }
-    while (rest) {
-      int l[3] = {0, 0, 0}, k = 0;
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (rest) { l[j] = __builtin_ctz(rest); rest &= rest - 1u; k++; }
-      if (k == 3) group(std::integral_constant<int, 3>{}, l);
-      else if (k == 2) group(std::integral_constant<int, 2>{}, l);
-      else {
-        const RmLight &li = sb->lights[l[0]];
-        const LightGeom g = lightSetup(li, p, far);
-        MarchRes sh;
-        sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, true>(sb, so, g.L, g.maxT, 1.0f, cnt);
-        V3 cur;
-        if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
-      }
-    }
-    return total;
   }
   for (int i = 0; i < nl; i++) {
     const RmLight &li = sb->lights[i];  // uniform index → scalar loads
@@ -1008,7 +895,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
       V3 toL = sub(madd(side2, rd.y + 0.0f, madd(side1, rd.x + 0.0f, p1)), p);
       V3 L = normalize(toL);
       if (dot(N, L) <= 0.005f) continue;
-      MarchRes sh = march<BULB, COUNT, true, CULLS != 0>(sb, so, L, len(toL), 1.0f, cnt);
+      MarchRes sh = march<BULB, COUNT, true, CULLS>(sb, so, L, len(toL), 1.0f, cnt, ubSo);
       if (sh.obj != -1 && objs[sh.obj].lightIdx != i) continue;  // only the light's own rectangle may be "in the way"
       total = add(total, getAreaLight(sb, N, V, p, li, mat));
       continue;
@@ -1019,7 +906,7 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
     // work so that the counters stay the algorithmic ones).
     MarchRes sh;
     sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (COUNT == 1 || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, CULLS != 0>(sb, so, g.L, g.maxT, 1.0f, cnt);
+    if (COUNT == 1 || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt, ubSo);
     V3 cur;
     if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
@@ -1036,12 +923,12 @@ RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
 }
 
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
-template <bool BULB, int COUNT, bool TEX, int CULLS>
+template <bool BULB, int COUNT, bool TEX, bool CULLS>
 RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
                         V3 bg, Counters &cnt) {
   RenderOut out;
   info.obj = -1;
-  MarchRes res = march<BULB, COUNT, false, CULLS != 0>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
+  MarchRes res = march<BULB, COUNT, false, CULLS>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
   if (res.obj == -1) {
     out.col = (TEX && sb->s.enableSkyBox) ? sampleCube(sb->skybox, rd) : bg;  // frag:2325-2327
     out.isEnv = 1;
@@ -1052,7 +939,15 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   out.d = res.d;  // frag:2332
   if (COUNT) cnt.shades++;
   V3 p = madd(rd, res.d, ro);
-  V3 pn = getNormal<BULB, COUNT>(sb, p, cnt);
+  // The march stopped at a point whose distance value is below SURFACE_DIST and p lies at most that far (× |rd|) from it: an
+  // upper bound of sdScene at p, the seed of the skip test for the normal taps (0.0005 away), the AO taps and the shadow rays.
+  constexpr bool SKIP = CULLS && !BULB && COUNT != 1;
+  float ubP = __builtin_inff();
+  if (SKIP) {
+    const float lipLen = (sb->cullLip * len(rd)) * 1.0001f;
+    ubP = fma(kSurfaceDist, lipLen, kSurfaceDist) * 1.001f + fma(fabs_(res.d), 1.0e-6f, 1.0e-5f);
+  }
+  V3 pn = getNormal<BULB, COUNT, SKIP>(sb, p, cnt, SKIP ? fma(0.0005f, sb->cullLip * 1.001f, ubP) : ubP);
   if (sb->s.features & RM_FEAT_PERLIN_BUMP) pn = bumpNormal(pn, p);
   const RmObject &o = objs[BULB ? 0 : res.obj];
   if (TEX && o.isEmissive) {  // frag:2339-2342: the rectangle of an area light; info.obj stays -1
@@ -1065,7 +960,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   const int type = BULB ? (int)RM_MANDELBULB : o.type;
-  V3 ph = getPhong<BULB, COUNT, TEX, CULLS>(sb, objs, mat, pn, p, rd, maxT, cnt);
+  V3 ph = getPhong<BULB, COUNT, TEX, CULLS>(sb, objs, mat, pn, p, rd, maxT, cnt, ubP);
   V3 col = ph;
   if (type == RM_MANDELBULB) {  // frag:2354-2361
     V3 c = bulbTrapColor(res.trap.y, res.trap.z, res.trap.w);
@@ -1139,7 +1034,7 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
 // raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
 // ENV = false compiles the procedural layers out (the launcher picks the instantiation from the feature bits),
 // so the common kernels do not carry their registers and code.
-template <bool BULB, int COUNT, bool ENV, bool TEX, bool LOCK = false>
+template <bool BULB, int COUNT, bool ENV, bool TEX>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
                        V4 &bright, Counters &cnt, bool &hitFlag) {
   float ndcx, ndcy;
@@ -1160,7 +1055,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   const float iTime = sb->g.iTime;
 
   Hit info;
-  RenderOut ri = render<BULB, COUNT, TEX, (ENV ? 0 : (LOCK ? 2 : 1))>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
+  RenderOut ri = render<BULB, COUNT, TEX, !ENV>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
   EnvOut e;
   e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
   if (env) e = envLayers(feat, sb->noise, iTime, W, ro, rd, ri.d, bg, cnt);  // frag:2444-2456
@@ -1193,7 +1088,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
       V3 sro = v3(fma(r.x * kSurfaceDist, 3.0f, info.p.x), fma(r.y * kSurfaceDist, 3.0f, info.p.y),
                   fma(r.z * kSurfaceDist, 3.0f, info.p.z));
       fil = mul(fil, cRefl);
-      RenderOut res = render<BULB, COUNT, TEX, (ENV ? 0 : (LOCK ? 2 : 1))>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
+      RenderOut res = render<BULB, COUNT, TEX, !ENV>(sb, objs, sro, r, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2506-2518 (a sea hit sets sr.isEnv, not res.isEnv: the bounce loop goes on)
         EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, r, res.d, bg, cnt);
         if (b.seaHit) res.col = b.scol;
@@ -1218,7 +1113,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
     if (len(rdOut) != 0.0f) {
       V3 sro = v3(fma(-(nExit.x * kSurfaceDist), 5.0f, pExit.x), fma(-(nExit.y * kSurfaceDist), 5.0f, pExit.y),
                   fma(-(nExit.z * kSurfaceDist), 5.0f, pExit.z));
-      RenderOut res = render<BULB, COUNT, TEX, (ENV ? 0 : (LOCK ? 2 : 1))>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
+      RenderOut res = render<BULB, COUNT, TEX, !ENV>(sb, objs, sro, rdOut, info, 1.0f, far, bg, cnt);
       if (env) {  // frag:2555-2567
         EnvOut b = envLayers(feat, sb->noise, iTime, W, sro, rdOut, res.d, bg, cnt);
         if (b.seaHit) res.col = b.scol;

@@ -70,11 +70,7 @@ constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
 #ifndef RM_TEX_WAVES
 #define RM_TEX_WAVES 6
 #endif
-// LOCK: the table-walk kernel for tables of constant-cost primitives with two or more (non-area) lights: a shading point's shadow
-// rays march in lockstep through a shared table walk (rm_device.hip.h, shadowLockstep).  A separate instantiation, so that the
-// register allocation of every other class stays what it was.  Plain class only: the same instantiation of the sampler kernel
-// measured slower on unit_sphere.json at 256² (0.151 -> 0.161 ms; its shadow rays are short), profiles/r03_h_lockstep.md.
-template <bool BULB, int COUNT, bool ENV, bool TEX, bool LOCK = false>
+template <bool BULB, int COUNT, bool ENV, bool TEX>
 __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? RM_BULB_WAVES : RM_GENERIC_WAVES)))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
@@ -109,7 +105,7 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   V4 col, br;
   Counters cnt{0, 0, 0, 0, 0};
   bool hit;
-  shadePixel<BULB, CM, ENV, TEX, LOCK>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, CM, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -323,9 +319,7 @@ struct DeviceState {
   uint32_t *dbgTileCost = nullptr;
   int dbgTileCount = 0;
   int lastPath = 0;  // rm_debug_last_path: the schedule of the most recent render launch on this device
-  int lastLockstep = 0;  // rm_debug_last_lockstep: whether that launch was render_kernel's lockstep instantiation
 };
-std::atomic<int> g_lockstepMode{-1};   // rm_set_lockstep: -1 = take RM_LOCKSTEP or the default (on)
 std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_ORDER or the default
 constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
@@ -579,6 +573,29 @@ int validate_scene(const RmCamera *cam, const RmObject *objs, int numObjects, co
 // (distance value) / (world distance to the object's ball) for the exact SDFs.  The Mandelbulb (power 8, |seed| <= 2)
 // enters with r = 2.1: beyond it the estimate is >= 0.68·scaleFactor.  Scenes with a type that has no bound here
 // (2-D Mandelbrot, Sierpinski) get cullOk = 0.
+// Largest singular value of a 3×3 matrix: the largest eigenvalue of the symmetric M·Mᵀ in closed form, padded.
+double sigma_max3(const double m[3][3]) {
+  double B[3][3];
+  for (int r0 = 0; r0 < 3; r0++)
+    for (int c0 = 0; c0 < 3; c0++) B[r0][c0] = m[r0][0] * m[c0][0] + m[r0][1] * m[c0][1] + m[r0][2] * m[c0][2];
+  const double p1 = B[0][1] * B[0][1] + B[0][2] * B[0][2] + B[1][2] * B[1][2];
+  const double q = (B[0][0] + B[1][1] + B[2][2]) / 3.0;
+  const double p2 = (B[0][0] - q) * (B[0][0] - q) + (B[1][1] - q) * (B[1][1] - q) + (B[2][2] - q) * (B[2][2] - q) + 2.0 * p1;
+  double lmax;
+  if (!(p2 > 1e-300)) lmax = q;
+  else {
+    const double pp = std::sqrt(p2 / 6.0);
+    double C3[3][3];
+    for (int r0 = 0; r0 < 3; r0++)
+      for (int c0 = 0; c0 < 3; c0++) C3[r0][c0] = (B[r0][c0] - (r0 == c0 ? q : 0.0)) / pp;
+    double hd = (C3[0][0] * (C3[1][1] * C3[2][2] - C3[1][2] * C3[2][1]) - C3[0][1] * (C3[1][0] * C3[2][2] - C3[1][2] * C3[2][0]) +
+                 C3[0][2] * (C3[1][0] * C3[2][1] - C3[1][1] * C3[2][0])) / 2.0;
+    hd = hd < -1.0 ? -1.0 : (hd > 1.0 ? 1.0 : hd);
+    lmax = q + 2.0 * pp * std::cos(std::acos(hd) / 3.0);
+  }
+  return std::sqrt(lmax > 0.0 ? lmax : 0.0) * (1.0 + 1e-6);
+}
+
 void scene_cull_ball(SceneBlock *h) {
   h->cullOk = 0;
   h->cullC[0] = h->cullC[1] = h->cullC[2] = 0.0f;
@@ -586,6 +603,19 @@ void scene_cull_ball(SceneBlock *h) {
   h->cullR2Soft = 0.0f;
   h->cullBoxOk = 0;
   for (int k = 0; k < 3; k++) h->cullLo[k] = h->cullHi[k] = 0.0f;
+  {  // Lipschitz bound of the distance values per unit of world length (the skip test's seed, rm_device.hip.h nextMinBound):
+     // scaleFactor × the stretch of invModel's linear part, for the shapes whose SDF is 1-Lipschitz in object space
+    double lip = 0.0;
+    for (int i = 0; i < h->numObjects; i++) {
+      const RmObject &o = h->objs[i];
+      const bool lipschitz = (o.type >= RM_CUBE && o.type <= RM_RECTANGLE) || o.type == RM_MENGERSPONGE;
+      const float *M = o.invModel;
+      const double a[3][3] = {{M[0], M[4], M[8]}, {M[1], M[5], M[9]}, {M[2], M[6], M[10]}};
+      const double li = lipschitz ? std::fabs((double)o.scaleFactor) * sigma_max3(a) : INFINITY;
+      lip = (li > lip || !(li == li)) ? li : lip;
+    }
+    h->cullLip = (std::isfinite(lip) && lip < 1e6) ? (float)(lip * (1.0 + 1e-5)) : INFINITY;
+  }
   const int n = h->numObjects;
   if (n <= 0) return;
   // half-extents of the unit shapes' object-space bounding boxes (sdMatch's sizes; the capsule's segment runs from 0 to 0.5 in y)
@@ -619,28 +649,7 @@ void scene_cull_ball(SceneBlock *h) {
     // nf = the largest singular value of A⁻¹ (how much the model matrix can stretch a length): the largest eigenvalue of the
     // symmetric B = A⁻¹·A⁻¹ᵀ in closed form, with a relative safety margin.  (The Frobenius norm used before is an upper bound
     // too, but √3 too large for a uniform scale: every ball was 1.7× wider than it had to be.)
-    double nf;
-    {
-      double B[3][3];
-      for (int r0 = 0; r0 < 3; r0++)
-        for (int c0 = 0; c0 < 3; c0++) B[r0][c0] = inv[r0][0] * inv[c0][0] + inv[r0][1] * inv[c0][1] + inv[r0][2] * inv[c0][2];
-      const double p1 = B[0][1] * B[0][1] + B[0][2] * B[0][2] + B[1][2] * B[1][2];
-      const double q = (B[0][0] + B[1][1] + B[2][2]) / 3.0;
-      const double p2 = (B[0][0] - q) * (B[0][0] - q) + (B[1][1] - q) * (B[1][1] - q) + (B[2][2] - q) * (B[2][2] - q) + 2.0 * p1;
-      double lmax;
-      if (!(p2 > 1e-300)) lmax = q;
-      else {
-        const double pp = std::sqrt(p2 / 6.0);
-        double C3[3][3];
-        for (int r0 = 0; r0 < 3; r0++)
-          for (int c0 = 0; c0 < 3; c0++) C3[r0][c0] = (B[r0][c0] - (r0 == c0 ? q : 0.0)) / pp;
-        double hd = (C3[0][0] * (C3[1][1] * C3[2][2] - C3[1][2] * C3[2][1]) - C3[0][1] * (C3[1][0] * C3[2][2] - C3[1][2] * C3[2][0]) +
-                     C3[0][2] * (C3[1][0] * C3[2][1] - C3[1][1] * C3[2][0])) / 2.0;
-        hd = hd < -1.0 ? -1.0 : (hd > 1.0 ? 1.0 : hd);
-        lmax = q + 2.0 * pp * std::cos(std::acos(hd) / 3.0);
-      }
-      nf = std::sqrt(lmax) * (1.0 + 1e-6);
-    }
+    const double nf = sigma_max3(inv);
     const double b[3] = {M[12], M[13], M[14]};
     cx[i] = -(inv[0][0] * b[0] + inv[0][1] * b[1] + inv[0][2] * b[2]);
     cy[i] = -(inv[1][0] * b[0] + inv[1][1] * b[1] + inv[1][2] * b[2]);
@@ -748,7 +757,15 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
       for (int r = 0; r < 3; r++) e.m[c * 3 + r] = objs[i].invModel[c * 4 + r];
     e.scaleFactor = objs[i].scaleFactor;
     e.type = objs[i].type;
-    e.pad[0] = e.pad[1] = 0;
+    {  // the skip test's bound (rm_device.hip.h, sdScene<…, SKIP>): radius of the unit shape's bounding ball, with a margin
+      static const float kBound[] = {0.8662f, 0.7073f, 0.7073f, 0.5001f, 0.5001f, 0.6252f, 0.6002f, 0.5001f, 0.7073f};  // cube … rectangle
+      const float sf = objs[i].scaleFactor;
+      const bool ok = std::isfinite(sf) && sf > 1e-6f && sf < 1e6f;
+      e.invScale = ok ? 1.0f / sf : 0.0f;
+      // the primitives only: a fractal's evaluation also writes the orbit trap that sdScene returns — the trap of the LAST
+      // evaluated fractal in table order, nearest or not — so passing over one would change it
+      e.boundR = (ok && objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE) ? kBound[objs[i].type] : INFINITY;
+    }
   }
   for (int i = 0; i < numLights; i++) h->lights[i] = lights[i];
   h->numTextures = res.numTextures;
@@ -777,20 +794,16 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 // 25.4 -> 20.2 ms, with one 16.8 -> 16.4 ms); at 1080p its dozen launches of persistent waves cost more than the idle lanes
 // they remove (4.5 -> 5.2 ms, 5.4 -> 7.2 ms), and without secondary rays the one-lane-per-pixel kernel keeps 89-95 % of its
 // lanes busy by itself (directional_light_2.json: 1.3 ms against 3.5 ms).
-// The class of render_kernel<…, LOCK = true>: every object a constant-cost primitive (what sdSceneK evaluates), two or more
-// lights, none of them an area light.
-bool lockstep_class(const RmObject *objs, int numObjects, const RmLight *lights, int numLights) {
-  static const bool envOn = [] { const char *e = getenv("RM_LOCKSTEP"); return !e || atoi(e) != 0; }();
-  const int mode = g_lockstepMode.load();
-  bool ok = (mode >= 0 ? mode != 0 : envOn) && numLights >= 2;
-  for (int i = 0; i < numObjects; i++) ok = ok && objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE;
-  for (int i = 0; i < numLights; i++) ok = ok && lights[i].type != RM_LIGHT_AREA;
-  return ok;
+// Round 3, after the table walk learnt to pass over far objects (sdScene<…, SKIP>): for tables it applies to — primitives
+// among two or more objects — the one-lane-per-pixel kernel is ahead with one bounce (reflections_complex.json 4K: 10.5 ms
+// against 12.4) and level with two (16.1 against 15.6).
+bool skip_applies(const RmObject *objs, int numObjects) {
+  bool prim = false;
+  for (int i = 0; i < numObjects; i++) prim = prim || (objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE);
+  return prim && numObjects >= 2;
 }
-
 bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels) {
-  (void)objs; (void)numObjects;
-  return bounces >= 1 && pixels >= (size_t(1) << 22);
+  return bounces >= (skip_applies(objs, numObjects) ? 2 : 1) && pixels >= (size_t(1) << 22);
 }
 
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -838,6 +851,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   const int wfBounces = (s->enableReflection && anyReflective) ? s->numReflection : 0;
   // 32-bit ray ids: (hit slots) x lights must stay below 2^32 (a 16K frame with ten lights still does)
   if ((double)((size_t)nRows * W + (size_t)(1u << 22)) * (numLights > 0 ? numLights : 1) >= 4.0e9) wfOk = false;
+  const bool wfSkip = skip_applies(objs, numObjects);
   const bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W)));
   // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
   // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident: one wave
@@ -858,7 +872,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
                        tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
   uint32_t *oCost = nullptr, *oHist = nullptr;
   int32_t *oOrder = nullptr;
-  bool haveCost = false, lockstepRan = false;
+  bool haveCost = false;
   if (ordered) {
     void *mem = nullptr;
     if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 8 + 256, &mem)) != RM_OK) return st;
@@ -976,10 +990,17 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     const int thr = flushThr > 0 && flushThr <= 64 ? flushThr : 16;
     if ((st = stamp(0)) != RM_OK) return st;
     for (int gen = 0; gen <= wfBounces; gen++) {
-      if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, pixelChunk, maxChunk, slotChunk);
-      else hipLaunchKernelGGL((wf_march_kernel<1>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
-      hipLaunchKernelGGL(wf_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws, gen);
-      if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
+      if (wfSkip) {
+        if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0, true>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, pixelChunk, maxChunk, slotChunk);
+        else hipLaunchKernelGGL((wf_march_kernel<1, true>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
+        hipLaunchKernelGGL(wf_surface_kernel<true>, dense, block, 0, stream, slot->dev, map, W, H, ws, gen);
+        if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2, true>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
+      } else {
+        if (gen == 0) hipLaunchKernelGGL((wf_march_kernel<0, false>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, pixelChunk, maxChunk, slotChunk);
+        else hipLaunchKernelGGL((wf_march_kernel<1, false>), pgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
+        hipLaunchKernelGGL(wf_surface_kernel<false>, dense, block, 0, stream, slot->dev, map, W, H, ws, gen);
+        if (numLights > 0) hipLaunchKernelGGL((wf_march_kernel<2, false>), mgrid, mblock, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, gen, thr, rayChunk, maxChunk, slotChunk);
+      }
       hipLaunchKernelGGL(wf_light_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws, gen, wfBounces);
     }
     if ((st = stamp(1)) != RM_OK) return st;
@@ -1009,10 +1030,6 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     } else {
       if (count == 1) RM_LAUNCH(false, 1, false, false);
       else if (count == 2) RM_LAUNCH(false, 2, false, false);
-      else if (lockstep_class(objs, numObjects, lights, numLights)) {
-        hipLaunchKernelGGL((render_kernel<false, 0, false, false, true>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
-        lockstepRan = true;
-      }
       else RM_LAUNCH(false, 0, false, false);
     }
 #undef RM_LAUNCH
@@ -1020,7 +1037,6 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   }
   HIP_OK(hipGetLastError());
   ds.lastPath = pipeline ? path : (wavefront ? 5 : 1);
-  ds.lastLockstep = lockstepRan ? 1 : 0;
   if (timing) { ds.timed.push_back(tl); timedGuard.kept = true; }
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
@@ -1307,8 +1323,8 @@ int rm_debug_ray_planes(const RmCamera *cam, float *out48) {
   std::memcpy(out48, blk.rayPlane, sizeof(blk.rayPlane));
   return RM_OK;
 }
-int rm_debug_cull_bounds(const RmObject *objs, int numObjects, const RmGlobals *g, float *out13) {
-  if ((!objs && numObjects > 0) || !g || !out13) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
+int rm_debug_cull_bounds(const RmObject *objs, int numObjects, const RmGlobals *g, float *out14) {
+  if ((!objs && numObjects > 0) || !g || !out14) { set_error("null pointer"); return RM_ERR_INVALID_ARGUMENT; }
   if (numObjects < 0 || numObjects > RM_MAX_OBJECTS) { set_error("numObjects out of range"); return RM_ERR_INVALID_ARGUMENT; }
   static SceneBlock blk;  // host-only scratch; the bounds are a pure function of the object table and the globals
   static std::mutex mu;
@@ -1317,9 +1333,10 @@ int rm_debug_cull_bounds(const RmObject *objs, int numObjects, const RmGlobals *
   blk.numObjects = numObjects;
   for (int i = 0; i < numObjects; i++) blk.objs[i] = objs[i];
   scene_cull_ball(&blk);
-  out13[0] = (float)blk.cullOk;
-  for (int k = 0; k < 3; k++) { out13[1 + k] = blk.cullC[k]; out13[7 + k] = blk.cullLo[k]; out13[10 + k] = blk.cullHi[k]; }
-  out13[4] = blk.cullR2; out13[5] = blk.cullR2Soft; out13[6] = (float)blk.cullBoxOk;
+  out14[0] = (float)blk.cullOk;
+  for (int k = 0; k < 3; k++) { out14[1 + k] = blk.cullC[k]; out14[7 + k] = blk.cullLo[k]; out14[10 + k] = blk.cullHi[k]; }
+  out14[4] = blk.cullR2; out14[5] = blk.cullR2Soft; out14[6] = (float)blk.cullBoxOk;
+  out14[13] = blk.cullLip;
   return RM_OK;
 }
 int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCount) {
@@ -1339,17 +1356,6 @@ int rm_debug_last_path(void) {
   if (current_device_state(&ds)) return -1;
   std::lock_guard<std::mutex> lock(ds->mu);
   return ds->lastPath;
-}
-int rm_debug_last_lockstep(void) {
-  DeviceState *ds;
-  if (current_device_state(&ds)) return -1;
-  std::lock_guard<std::mutex> lock(ds->mu);
-  return ds->lastLockstep;
-}
-int rm_set_lockstep(int mode) {
-  if (mode < -1 || mode > 1) { set_error("lockstep mode must be -1, 0 or 1"); return RM_ERR_INVALID_ARGUMENT; }
-  g_lockstepMode.store(mode);
-  return RM_OK;
 }
 int rm_set_kernel_path(int path) {
   if (path < 0 || path > 5) { set_error("kernel path must be 0..5"); return RM_ERR_INVALID_ARGUMENT; }

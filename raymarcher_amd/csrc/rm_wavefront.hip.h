@@ -109,7 +109,9 @@ constexpr uint32_t wfRayChunk(int kind) { return kind == 0 ? RM_WF_PIXEL_CHUNK :
 
 // KIND 0: primary rays from the tile-major pixel cursor; 1: bounce rays of generation `gen` from the ray queue;
 // 2: shadow rays of generation `gen`, ray id = light·(hit slots) + hit slot.
-template <int KIND>
+// SKIP: the table walk's skip test (tables with primitives among two or more objects; the launcher decides — a lone Menger
+// sponge has nothing to pass over and the test's registers cost it 5 %).
+template <int KIND, bool SKIP = false>
 __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                                           int nRows, float4 *__restrict__ out,
                                                                           float4 *__restrict__ bright, WfWs ws, int gen,
@@ -138,6 +140,10 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
   uint32_t src = 0;
   V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
   float depth = 0.0f, end = 0.0f, pen = 1.0f;
+  // the table walk's skip test (rm_device.hip.h, sdScene<…, SKIP>): ub = upper bound of the next evaluation's minimum; every ray
+  // direction here is a normalised vector (|rd| within a few ulp of 1), hence one padded constant for all lanes
+  float ub = __builtin_inff();
+  const float lipLen = sb->cullLip * 1.001f;
   uint32_t srcCur = 0, srcEnd = 0, slotCur = 0, slotEnd = 0;  // wave-uniform cursors into the reserved chunks
   bool exhausted = false;
 
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
                 if (bright) bright[src] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
               } else {
                 depth = 0.0f; steps = 0;
-                st = ST_MARCH;
+                st = ST_MARCH; if (SKIP) ub = __builtin_inff();
               }
             }
           } else if (KIND == 1) {
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
             rd = v3(D.x, D.y, D.z);
             end = sceneCullEnd<true>(sb, ro, rd, far, cullR2);
             depth = 0.0f; steps = 0;
-            st = ST_MARCH;
+            st = ST_MARCH; if (SKIP) ub = __builtin_inff();
           } else {
             const uint32_t li = id / nSlots, h = id - li * nSlots;  // light-major: a wave marches toward one light
             if (ws.hit[h].x >= 0) {                                   // else a hole: stays NEED
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
                 end = soft ? sceneCullEnd<false>(sb, ro, rd, maxT, cullR2) : sceneCullEnd<true>(sb, ro, rd, maxT, cullR2);
                 depth = 0.0f; pen = 1.0f; steps = 0;
                 src = li * ws.cap + h;
-                st = ST_MARCH;
+                st = ST_MARCH; if (SKIP) ub = __builtin_inff();
               }
             }
           }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
     float hitD = 0.0f, hitTz = 0.0f;
     int hitObj = -1;
     if (st == ST_MARCH) {
-      const SceneMin c = sdScene<false, 0, KIND != 2>(sb, madd(rd, depth, ro), none);
+      const SceneMin c = sdScene<false, 0, KIND != 2, SKIP>(sb, madd(rd, depth, ro), none, ub);
       const bool hit = fabs_(c.d) < kSurfaceDist;
       bool fin = hit || depth > end;
       if (!fin) {
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
         } else {
           depth = fma(c.d, 1.0f, depth);
         }
+        if (SKIP) ub = nextMinBound(c.d, lipLen, depth);
         steps++;
         fin = steps >= maxSteps;  // the loop runs out: a miss
       }
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
 }
 
 // One lane per hit of generation `gen`: frag:2333-2336 and getPhong's ambient-occlusion term (frag:1859).
+template <bool SKIP>
 __global__ __launch_bounds__(256) void wf_surface_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H, WfWs ws,
                                                           int gen) {
   const uint32_t nSlots = ws.counters[WF_STRIDE * gen + WF_HITS];
@@ -293,10 +301,12 @@ __global__ __launch_bounds__(256) void wf_surface_kernel(const SceneBlock *__res
     uint32_t path;
     wfRayOf(sb, map, W, H, ws, gen, rec.x, ro, rd, path, h);
     const V3 p = madd(rd, u2f((uint32_t)rec.y), ro);
-    V3 n = getNormal<false, 0>(sb, p, none);
+    // seeds of the skip test as in render(): the march stopped within SURFACE_DIST of a surface, p at most that far (× |rd|) from there
+    const float ubP = fma(kSurfaceDist, (sb->cullLip * len(rd)) * 1.0001f, kSurfaceDist) * 1.001f + fma(fabs_(u2f((uint32_t)rec.y)), 1.0e-6f, 1.0e-5f);
+    V3 n = getNormal<false, 0, SKIP>(sb, p, none, fma(0.0005f, sb->cullLip * 1.001f, ubP));
     if (sb->s.features & RM_FEAT_PERLIN_BUMP) n = bumpNormal(n, p);
     float ao = 1.0f;
-    if (sb->s.enableAmbientOcclusion) ao = calcAO<false, 0>(sb, p, n, none);
+    if (sb->s.enableAmbientOcclusion) ao = calcAO<false, 0, SKIP>(sb, p, n, none, ubP);
     ws.surfP[h] = make_float4(p.x, p.y, p.z, ao);
     ws.surfN[h] = make_float4(n.x, n.y, n.z, 0.0f);
   }

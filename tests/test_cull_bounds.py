@@ -25,10 +25,10 @@ def rot(axis, a):
 
 
 def bounds(objs, n, g):
-    out = np.zeros(13, dtype=np.float32)
+    out = np.zeros(14, dtype=np.float32)
     assert lib().rm_debug_cull_bounds(objs, n, C.byref(g), out.ctypes.data_as(C.POINTER(C.c_float))) == 0
     return {"ok": bool(out[0]), "c": out[1:4].astype(np.float64), "R": float(np.sqrt(out[4])), "Rsoft": float(np.sqrt(out[5])),
-            "box": bool(out[6]), "lo": out[7:10].astype(np.float64), "hi": out[10:13].astype(np.float64)}
+            "box": bool(out[6]), "lo": out[7:10].astype(np.float64), "hi": out[10:13].astype(np.float64), "lip": float(out[13])}
 
 
 def distances(objs, n, g, pts):
@@ -102,3 +102,30 @@ def test_box_only_where_it_is_much_tighter_than_the_ball():
     o = (abi.RmObject * 1)(h.make_object(abi.RM_SIERPINSKI))
     assert not bounds(o, 1, g)["ok"]
     assert not bounds(o, 0, g)["ok"]
+
+
+def test_distance_values_are_lipschitz_and_bounded_below_by_the_object_ball():
+    """What the table walk's skip test (sdScene<…, SKIP>, nextMinBound) rests on: (i) sdScene's value changes by at most
+    `lip` per unit of world length; (ii) a primitive's value is at least (|p_object| − boundR)·scaleFactor."""
+    rng = np.random.default_rng(7)
+    g = h.make_globals(itime=5.1)
+    for i in range(40):
+        objs, n = random_scene(rng, flat=(i % 2 == 0))
+        b = bounds(objs, n, g)
+        assert np.isfinite(b["lip"]) and 0.99 < b["lip"] < 1.01  # scaleFactor = the smallest scale undoes the stretch
+        p = rng.uniform(-8, 8, (20000, 3))
+        step = rng.normal(size=(20000, 3)) * (10.0 ** rng.uniform(-3, 0.5, (20000, 1)))
+        a, c = distances(objs, n, g, p), distances(objs, n, g, p + step)
+        dist = np.linalg.norm((p + step).astype(np.float32).astype(np.float64) - p.astype(np.float32).astype(np.float64), axis=1)
+        assert (np.abs(c.astype(np.float64) - a) <= b["lip"] * dist * 1.0001 + 2e-5).all(), f"scene {i}"
+    bound_r = {abi.RM_CUBE: 0.8662, abi.RM_CONE: .7073, abi.RM_CYLINDER: .7073, abi.RM_SPHERE: .5001, abi.RM_OCTAHEDRON: .5001,
+               abi.RM_TORUS: .6252, abi.RM_CAPSULE: .6002, abi.RM_DEATHSTAR: .5001, abi.RM_RECTANGLE: .7073}
+    for ty, r in bound_r.items():
+        o = (abi.RmObject * 1)(h.make_object(ty))
+        d = rng.normal(size=(200000, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts = (d * np.concatenate([rng.uniform(0, 3, 100000), 10 ** rng.uniform(0, 4, 100000)])[:, None]).astype(np.float32)
+        lb = np.linalg.norm(pts.astype(np.float64), axis=1) - r
+        assert (distances(o, 1, g, pts) >= lb * (1 - 1e-5) - 1e-6).all(), f"type {ty}"
+    o = (abi.RmObject * 2)(h.make_object(abi.RM_SPHERE), h.make_object(abi.RM_MANDELBULB))
+    assert bounds(o, 2, g)["lip"] == np.inf  # a fractal in the table: no seed

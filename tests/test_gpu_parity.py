@@ -1269,6 +1269,65 @@ def test_bounding_box_cull_edge_cases(renderer):
         lib().rm_set_kernel_path(0)
 
 
+
+def test_table_walk_skip_edge_cases(renderer):
+    """The table walk passes over objects that cannot lower a lane's minimum (sdScene<…, SKIP>, seeded by a Lipschitz bound from
+    the previous step): it must never change a bit — ties between identical objects (the lower index wins: different materials
+    show it), the camera inside an object (negative distances), a full table of 30, a scaleFactor that is NOT the smallest
+    scale (the distance values are then 2-Lipschitz and the march overshoots, as the reference's would), sheared model
+    matrices, every shading option, both schedules."""
+    from raymarcher_amd import lib
+    W, H = 72, 48
+    lights = (abi.RmLight * 3)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.3, -1, -0.5)),
+                               h.make_light(abi.RM_LIGHT_POINT, (.9, .8, .7), pos=(3, 4, 4), func=(0.7, 0.05, 0)),
+                               h.make_light(abi.RM_LIGHT_SPOT, (.8, .8, 1), direction=(0, -1, -0.2), pos=(0, 5, 1), func=(0.8, 0.02, 0),
+                                            angle=0.8, penumbra=0.2))
+    red = dict(ambient=(.2, 0, 0), diffuse=(.9, .1, .1), specular=(.5, .5, .5), shininess=15, reflective=(.4, .4, .4))
+    blue = dict(ambient=(0, 0, .2), diffuse=(.1, .1, .9), specular=(.5, .5, .5), shininess=15, transparent=(.4, .4, .4), ior=1.4)
+    floor = h.make_object(abi.RM_CUBE, model=h.translate(0, -1.1, 0) @ h.scale(12, 0.2, 8), scale_factor=0.2, diffuse=(.6, .6, .6))
+    cam = h.make_camera((0, 1.2, 6), (0, -0.2, -1), (0, 1, 0), 45.0, W, H)
+    cases = []
+    # ties: the same sphere twice (and the same torus twice, the second pair in the other order of materials)
+    cases.append((cam, [h.make_object(abi.RM_SPHERE, model=h.translate(-1.5, 0, 0), **red),
+                        h.make_object(abi.RM_SPHERE, model=h.translate(-1.5, 0, 0), **blue),
+                        h.make_object(abi.RM_TORUS, model=h.translate(1.5, 0, 0) @ rot_x(0.8) @ h.scale(2, 2, 2), scale_factor=2, **blue),
+                        h.make_object(abi.RM_TORUS, model=h.translate(1.5, 0, 0) @ rot_x(0.8) @ h.scale(2, 2, 2), scale_factor=2, **red), floor]))
+    # the camera inside a large cube that holds everything else
+    cases.append((cam, [h.make_object(abi.RM_CUBE, model=h.scale(30, 30, 30), scale_factor=30, diffuse=(.3, .5, .3)),
+                        h.make_object(abi.RM_CONE, model=h.translate(0, 0, 0) @ h.scale(2, 2, 2), scale_factor=2, **red),
+                        h.make_object(abi.RM_OCTAHEDRON, model=h.translate(2.5, 0.3, -1), **blue)]))
+    # a full table
+    grid = [h.make_object([abi.RM_SPHERE, abi.RM_CUBE, abi.RM_CYLINDER, abi.RM_CAPSULE, abi.RM_DEATHSTAR][k % 5],
+                          model=h.translate(-4.5 + (k % 10), -0.4 + 0.9 * (k // 10), -1.5 * (k // 10)) @ h.scale(.7, .7, .7), scale_factor=.7,
+                          **(red if k % 2 else blue)) for k in range(29)]
+    cases.append((cam, grid + [floor]))
+    # scaleFactor twice the smallest scale; a sheared model
+    shear = np.eye(4)
+    shear[0, 1], shear[2, 0] = 0.6, -0.4
+    cases.append((cam, [h.make_object(abi.RM_SPHERE, model=h.translate(-2, 0, 0) @ h.scale(1.5, 0.5, 1.5), scale_factor=1.0, **red),
+                        h.make_object(abi.RM_CYLINDER, model=h.translate(0.5, 0, 0) @ shear @ h.scale(1.2, 1.2, 1.2), scale_factor=1.2, **blue),
+                        h.make_object(abi.RM_RECTANGLE, model=h.translate(2.5, 0.2, -0.5) @ rot_x(0.4) @ h.scale(2, 2, 2), scale_factor=2, **red), floor]))
+    g = h.make_globals()
+    for k, (c, objs) in enumerate(cases):
+        arr = (abi.RmObject * len(objs))(*objs)
+        scene = (c, arr, len(objs), lights, 3, g)
+        for over in ({"enableReflection": 1, "enableRefraction": 1, "numReflection": 2},
+                     {"enableSoftShadow": 1, "enableAmbientOcclusion": 1, "features": abi.RM_FEAT_WHITE_BACKGROUND | abi.RM_FEAT_PERLIN_BUMP}):
+            s = abi.default_settings(**over)
+            ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+            out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+            assert_bit_equal(out.cpu().numpy(), ref, f"skip case {k} {over}")
+            assert_bit_equal(br.cpu().numpy(), ref_b, f"skip case {k} {over} bright")
+        try:  # the wavefront pipeline's instantiation of the test
+            lib().rm_set_kernel_path(5)
+            s = abi.default_settings(enableReflection=1, numReflection=2, enableAmbientOcclusion=1)
+            out = renderer.render(tables_of(scene), s, W, H)
+            assert lib().rm_debug_last_path() == 5
+            assert_bit_equal(out.cpu().numpy(), h.oracle_render(scene, s, W, H), f"skip case {k}, wavefront")
+        finally:
+            lib().rm_set_kernel_path(0)
+
+
 CXX_HOST = r'''
 // A C++ host with no Python and no torch: what a maintainer of the reference links (INTEGRATION.md §1).
 #include <hip/hip_runtime_api.h>
