@@ -308,8 +308,8 @@ int rm_render_counted_res(const RmCamera *cam, const RmObject *objs, int numObje
 int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights,
                          int numLights, const RmGlobals *g, const RmSettings *s, int W, int H, int rowBegin,
                          int rowEnd, float *d_rgba, float *d_bright, int mode, RmCounters *out);
-/* Diagnostic build of the single-Mandelbulb kernel (production code + s_memtime / s_memrealtime stamps per wave, written
- * to a buffer of their own): renders the whole frame once, synchronises and returns the shader clock the chip held under
+/* Diagnostic build of the single-Mandelbulb kernel and of the plain table-walk kernel (no samplers, no procedural layers;
+ * RM_ERR_UNSUPPORTED otherwise): production code + s_memtime / s_memrealtime stamps per wave, written to a buffer of their own: renders the whole frame once, synchronises and returns the shader clock the chip held under
  * this kernel's own load, in MHz (Σ cycle spans ÷ Σ 100 MHz-tick spans over all waves).  Call it after a few back-to-back
  * renders so that the clock has settled.  d_waveSpans (device, may be NULL): 2 words per wave — its first and last
  * s_memrealtime stamp (100 MHz ticks) — indexed tile·w + wave with w = waves per workgroup (1 unless RM_WAVES_PER_BLOCK

@@ -1030,6 +1030,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     } else {
       if (count == 1) RM_LAUNCH(false, 1, false, false);
       else if (count == 2) RM_LAUNCH(false, 2, false, false);
+      else if (count == 3) RM_LAUNCH(false, 3, false, false);
       else RM_LAUNCH(false, 0, false, false);
     }
 #undef RM_LAUNCH
@@ -1138,8 +1139,13 @@ int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects,
                       unsigned long long *d_waveSpans) {
   if (!shaderMHz) { set_error("null shaderMHz"); return RM_ERR_INVALID_ARGUMENT; }
   if (d_waveSpans && !device_accessible(d_waveSpans)) { set_error("d_waveSpans is not device-accessible memory"); return RM_ERR_INVALID_ARGUMENT; }
-  if (!(numObjects == 1 && objs && objs[0].type == RM_MANDELBULB)) {
-    set_error("rm_render_clocked covers the single-Mandelbulb scene class");
+  // the stamped build exists for the single-Mandelbulb class and for the plain table walk (no samplers, no procedural layers)
+  bool plain = objs != nullptr && s != nullptr && numObjects >= 1 &&
+               (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SEA | RM_FEAT_SKY_BACKGROUND | RM_FEAT_NIGHTSKY_BACKGROUND)) == 0 && !s->enableSkyBox;
+  for (int i = 0; plain && i < numObjects; i++) plain = objs[i].texLoc < 0 && !objs[i].isEmissive;
+  for (int i = 0; plain && i < numLights; i++) plain = lights[i].type != RM_LIGHT_AREA;
+  if (!plain) {
+    set_error("rm_render_clocked covers the single-Mandelbulb class and the plain table walk (no samplers, no procedural layers)");
     return RM_ERR_UNSUPPORTED;
   }
   RowMap map{0, H > 0 ? H : 1, 0, 1};
