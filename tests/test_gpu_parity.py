@@ -1328,6 +1328,28 @@ def test_table_walk_skip_edge_cases(renderer):
             lib().rm_set_kernel_path(0)
 
 
+
+def test_stamped_diagnostic_builds_render_the_same_frame(renderer):
+    """rm_render_clocked (production code + per-wave clock stamps; scripts/wave_timeline.py, wave_lives.py): the frame is the
+    production frame, the shader clock plausible, every wave that holds pixels has a life span — for the single-Mandelbulb class
+    and the plain table walk; other classes are refused."""
+    from raymarcher_amd import Scene
+    W, H = 200, 120
+    cases = [(tables_of(h.scene_mandelbulb(W, H)), abi.default_settings(fractalIters=8)),
+             (Scene(path=os.path.join(SCENES, "lighting", "directional_light_2.json")).tables(W, H),
+              abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1))]
+    for t, s in cases:
+        ref = renderer.render(t, s, W, H)
+        out, mhz, spans = renderer.render_clocked(t, s, W, H, wave_spans=True)
+        assert _ieq(out, ref)
+        assert 500.0 < mhz < 4000.0
+        sp = spans.cpu().numpy()
+        live = sp[sp[:, 1] > 0]
+        assert len(live) == ((W + 7) // 8) * ((H + 7) // 8) and (live[:, 1] >= live[:, 0]).all()
+    with pytest.raises(Exception):
+        renderer.render_clocked(tables_of(env_scene(W, H)), abi.default_settings(features=ENV_ALL), W, H)
+
+
 CXX_HOST = r'''
 // A C++ host with no Python and no torch: what a maintainer of the reference links (INTEGRATION.md §1).
 #include <hip/hip_runtime_api.h>
