@@ -514,7 +514,6 @@ RM_DEV float sceneCullEnd(const SceneBlock *sb, V3 ro, V3 rd, float end, float R
 // ub0: an upper bound of sdScene at ro (+inf = none), for the first evaluation's skip test.
 template <bool BULB, int COUNT, bool SHADOW, bool CULL = false>
 RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side, Counters &cnt, float ub0 = __builtin_inff()) {
-  const float endIn = end;
   if (CULL && COUNT != 1) {
     const bool softRay = SHADOW && sb->s.enableSoftShadow != 0;  // wave-uniform
     if (BULB && !softRay) end = bulbCullEnd(sb, ro, rd, end);
@@ -530,11 +529,6 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
   constexpr bool SKIP = CULL && !BULB && COUNT != 1;
   const float lipLen = SKIP ? (sb->cullLip * len(rd)) * 1.0001f : 0.0f;
   float ub = ub0;
-  // A ray that starts outside the bounds and never enters them (the cull turned a non-negative end negative): its one
-  // evaluation — at depth 0 > end the loop ends right after it — cannot hit (out there every distance value is above 4× the
-  // hit threshold), so it is not made: a miss at depth 0, as the loop would report.
-  const bool never = CULL && COUNT != 1 && end < 0.0f && endIn >= 0.0f;
-  if (!never)
   for (int i = 0; i < steps; i++) {
     c = sdScene<BULB, COUNT, !SHADOW, SKIP>(sb, madd(rd, depth, ro), cnt, ub);
     if (fabs_(c.d) < kSurfaceDist || depth > end) break;
