@@ -96,6 +96,7 @@ struct SceneBlock {
   float cullR2;
   float cullR2Soft;  // larger ball for soft-shadow rays (0 = none): beyond it 8·d/t >= 1, so the penumbra min() is settled
   int32_t cullOk;
+  int32_t cullOneOk;  // 1 = every object is a primitive (cube … rectangle): the march loops may take the single-object fast path
   float cullLip;  // Lipschitz bound of every object's distance value per unit of world length (+inf with a fractal in the table)
   float cullLo[3], cullHi[3];  // axis-aligned box with the same property (see scene_cull_ball); cullBoxOk = 0: none
   int32_t cullBoxOk;
@@ -365,9 +366,13 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
 // distance value changes by at most sb->cullLip per unit of world length (exact SDFs are 1-Lipschitz and scaleFactor undoes the
 // model matrix's stretch), so the minimum at the next point is at most the minimum at this one plus cullLip × the step.  With
 // it the test does not depend on the nearest object coming early in the table.
-template <bool BULB, int COUNT, bool TRAP = true, bool SKIP = false>
-RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __builtin_inff()) {
+// TRACK (with SKIP): also return in `second` a lower bound of every OTHER object's value at p — the runner-up of the minimum:
+// the values of the objects evaluated, and (|p_object|·(1 − ε) − boundR)·scaleFactor for the ones passed over.  The march
+// loops use it for the single-object fast path (sdSceneOne below).
+template <bool BULB, int COUNT, bool TRAP, bool SKIP, bool TRACK>
+RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub, float &second) {
   SceneMin res;
+  if (TRACK) second = __builtin_inff();
   res.d = 1000000.0f;
   res.idx = -1;
   res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -386,9 +391,12 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __
                fma(M[7], p.z, fma(M[4], p.y, fma(M[1], p.x, M[10]))),
                fma(M[8], p.z, fma(M[5], p.y, fma(M[2], p.x, M[11]))));  // frag:1417
     if (SKIP && !BULB) {
-      const float lim = fma(ub, o.invScale, o.boundR);
-      const bool far = (lim >= 0.0f) && (dot(po, po) > (lim * lim) * 1.00003f);
-      if (__ballot(!far) == 0ull) continue;
+      const float lim = fma(ub, o.invScale, o.boundR), pp = dot(po, po);
+      const bool far = (lim >= 0.0f) && (pp > (lim * lim) * 1.00003f);
+      if (__ballot(!far) == 0ull) {
+        if (TRACK) second = min_(second, (fma(__builtin_amdgcn_sqrtf(pp), 0.9999f, -o.boundR) * scaleFactor) * 0.9999f);
+        continue;
+      }
     }
     float d;
     const int type = BULB ? (int)RM_MANDELBULB : o.type;
@@ -409,9 +417,49 @@ RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __
       default: continue;
     }
     float cur = d * scaleFactor;  // frag:1419
+    if (TRACK) {
+      // the runner-up: the old minimum if cur replaces it, else cur; a NaN value (it never becomes the minimum) voids the bound
+      const float other = (cur < res.d) ? res.d : ((cur >= res.d) ? cur : -__builtin_inff());
+      second = min_(second, other);
+    }
     if (cur < res.d) { res.d = cur; res.idx = i; }
     if (SKIP && !BULB) ub = min_(ub, cur);
   }
+  return res;
+}
+template <bool BULB, int COUNT, bool TRAP = true, bool SKIP = false>
+RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __builtin_inff()) {
+  float unused;
+  return sdSceneImpl<BULB, COUNT, TRAP, SKIP, false>(sb, p, cnt, ub, unused);
+}
+// One object of the table alone (wave-uniform index j, a primitive): what sdScene returns when every other object is known to
+// be farther than the minimum (see march()).
+template <int COUNT>
+RM_DEV SceneMin sdSceneOne(const SceneBlock *sb, int j, V3 p, Counters &cnt) {
+  SceneMin res;
+  res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
+  res.idx = j;
+  if (COUNT) cnt.evals++;
+  const EvalRecord &o = sb->evalRec[j];
+  float M[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) M[c] = o.m[c];
+  const V3 po = v3(fma(M[6], p.z, fma(M[3], p.y, fma(M[0], p.x, M[9]))),
+                   fma(M[7], p.z, fma(M[4], p.y, fma(M[1], p.x, M[10]))),
+                   fma(M[8], p.z, fma(M[5], p.y, fma(M[2], p.x, M[11]))));  // frag:1417
+  float d = 0.0f;
+  switch (o.type) {  // primitives only (the fast path is off with a fractal in the table)
+    case RM_CUBE: d = sdBox(po, 0.5f, 0.5f, 0.5f); break;
+    case RM_CONE: d = sdCone(po, 0.5f, 0.5f); break;
+    case RM_CYLINDER: d = sdCylinder(po, 0.5f, 0.5f); break;
+    case RM_SPHERE: d = len(po) - 0.5f; break;
+    case RM_OCTAHEDRON: d = sdOctahedron(po, 0.5f); break;
+    case RM_TORUS: d = sdTorus(po, 0.5f, 0.125f); break;
+    case RM_CAPSULE: d = sdCapsule(po, 0.5f, 0.1f); break;
+    case RM_DEATHSTAR: d = sdDeathStar(po, 0.5f, 0.35f, 0.5f); break;
+    default: d = sdBox(po, 0.5f, 0.5f, 0.0f); break;  // RM_RECTANGLE
+  }
+  res.d = d * o.scaleFactor;  // frag:1419
   return res;
 }
 // The bound for the next evaluation of a march that has just stepped by |d| along rd: d + cullLip·|d|·|rd|, with slack for
@@ -529,8 +577,21 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
   constexpr bool SKIP = CULL && !BULB && COUNT != 1;
   const float lipLen = SKIP ? (sb->cullLip * len(rd)) * 1.0001f : 0.0f;
   float ub = ub0;
+  // Single-object fast path (SKIP classes): `second` is a lower bound of every object's value except the nearest one's at the
+  // point just evaluated, carried along the ray by the same Lipschitz argument as ub (it can only have dropped by cullLip × the
+  // step).  While it stays above ub for every live lane, and the lanes agree on the nearest object, no other object can be
+  // the minimum at the next point — strictly — so sdScene there IS that object's value: one record, one shape, no table walk.
+  float second = -__builtin_inff();
   for (int i = 0; i < steps; i++) {
-    c = sdScene<BULB, COUNT, !SHADOW, SKIP>(sb, madd(rd, depth, ro), cnt, ub);
+    const V3 p = madd(rd, depth, ro);
+    bool one = false;
+    int nearU = 0;
+    if (SKIP) {
+      nearU = __builtin_amdgcn_readfirstlane(c.idx);
+      one = sb->cullOneOk && __ballot(!(c.idx == nearU && nearU >= 0 && second > ub)) == 0ull;
+    }
+    if (SKIP && one) c = sdSceneOne<COUNT>(sb, nearU, p, cnt);
+    else c = sdSceneImpl<BULB, COUNT, !SHADOW, SKIP, SKIP>(sb, p, cnt, ub, second);
     if (fabs_(c.d) < kSurfaceDist || depth > end) break;
     if (SHADOW) {
       if (soft) pen = min_(pen, divr_(8.0f * c.d, depth));
@@ -538,7 +599,10 @@ RM_DEV MarchRes march(const SceneBlock *sb, V3 ro, V3 rd, float end, float side,
     } else {
       depth = fma(c.d, side, depth);
     }
-    if (SKIP) ub = nextMinBound(c.d, lipLen, depth);
+    if (SKIP) {
+      ub = nextMinBound(c.d, lipLen, depth);
+      second = fma(fabs_(c.d), -(lipLen * 1.0001f), second) - fma(depth, 1.0e-6f, 1.0e-5f);
+    }
   }
   MarchRes r;
   bool hit = fabs_(c.d) < kSurfaceDist;

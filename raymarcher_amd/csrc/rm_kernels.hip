@@ -615,6 +615,9 @@ void scene_cull_ball(SceneBlock *h) {
       lip = (li > lip || !(li == li)) ? li : lip;
     }
     h->cullLip = (std::isfinite(lip) && lip < 1e6) ? (float)(lip * (1.0 + 1e-5)) : INFINITY;
+    bool prim = h->numObjects > 0;
+    for (int i = 0; i < h->numObjects; i++) prim = prim && h->objs[i].type >= RM_CUBE && h->objs[i].type <= RM_RECTANGLE;
+    h->cullOneOk = (prim && std::isfinite(h->cullLip)) ? 1 : 0;
   }
   const int n = h->numObjects;
   if (n <= 0) return;
@@ -794,15 +797,23 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
 // 25.4 -> 20.2 ms, with one 16.8 -> 16.4 ms); at 1080p its dozen launches of persistent waves cost more than the idle lanes
 // they remove (4.5 -> 5.2 ms, 5.4 -> 7.2 ms), and without secondary rays the one-lane-per-pixel kernel keeps 89-95 % of its
 // lanes busy by itself (directional_light_2.json: 1.3 ms against 3.5 ms).
-// Round 3, after the table walk learnt to pass over far objects (sdScene<…, SKIP>): for tables it applies to — primitives
-// among two or more objects — the one-lane-per-pixel kernel is ahead with one bounce (reflections_complex.json 4K: 10.5 ms
-// against 12.4) and level with two (16.1 against 15.6).
+// Round 3, after the table walk learnt to pass over far objects (sdScene<…, SKIP>) and to follow a single object (march()'s
+// fast path, all-primitive tables): for all-primitive tables the one-lane-per-pixel kernel is ahead at every bounce count
+// (reflections_complex.json 4K: 7.5 ms against 12.4 with one bounce, 12.4 against 15.7 with two) — in the wavefront kernels a
+// wave's lanes are unrelated rays, and both tests need the whole wave to agree.  Mixed tables (primitives and a fractal): the
+// pass-over test applies, the fast path does not; two or more bounces as measured before the fast path.
 bool skip_applies(const RmObject *objs, int numObjects) {
   bool prim = false;
   for (int i = 0; i < numObjects; i++) prim = prim || (objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE);
   return prim && numObjects >= 2;
 }
+bool all_primitives(const RmObject *objs, int numObjects) {
+  bool prim = numObjects > 0;
+  for (int i = 0; i < numObjects; i++) prim = prim && objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE;
+  return prim;
+}
 bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels) {
+  if (all_primitives(objs, numObjects)) return false;
   return bounces >= (skip_applies(objs, numObjects) ? 2 : 1) && pixels >= (size_t(1) << 22);
 }
 

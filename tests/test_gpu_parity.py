@@ -1104,6 +1104,68 @@ def test_random_scenes_bit_exact(renderer):
     assert len(kinds) >= 10
 
 
+def _random_primitive_case(rng, W, H):
+    """A random all-primitive table (the class of the table walk's pass-over test AND of the march loops' single-object fast
+    path), one to eight objects, sometimes over a floor slab, two to ten lights of the three plain kinds, every shading option."""
+    f = rng.uniform
+    types = [abi.RM_CUBE, abi.RM_CONE, abi.RM_CYLINDER, abi.RM_SPHERE, abi.RM_OCTAHEDRON, abi.RM_TORUS, abi.RM_CAPSULE,
+             abi.RM_DEATHSTAR, abi.RM_RECTANGLE]
+    objs = []
+    for _ in range(int(rng.integers(1, 9))):
+        ty = int(rng.choice(types))
+        sc = float(f(0.6, 1.8))
+        sx, sy, sz = (sc * float(f(0.8, 1.25)) for _ in range(3))
+        M = h.translate(f(-2.2, 2.2), f(-1.0, 1.2), f(-2.5, 1.0)) @ rot_x(f(-0.6, 0.6)) @ h.scale(sx, sy, sz)
+        objs.append(h.make_object(ty, model=M, scale_factor=min(sx, sy, sz), ambient=tuple(f(0, .3, 3)), diffuse=tuple(f(.2, 1, 3)),
+                                  specular=tuple(f(0, 1, 3)), shininess=float(rng.choice([0, 1, 7.5, 25, 100])),
+                                  reflective=tuple(f(0, .8, 3)) if f() < 0.4 else (0, 0, 0),
+                                  transparent=tuple(f(0, .8, 3)) if f() < 0.3 else (0, 0, 0), ior=float(f(1.05, 1.6))))
+    if f() < 0.5:  # a floor: long grazing shadow rays
+        objs.append(h.make_object(abi.RM_CUBE, model=h.translate(0, -1.6, -1) @ h.scale(9, 0.2, 9), scale_factor=0.2,
+                                  diffuse=(.7, .7, .7), ambient=(.1, .1, .1)))
+    lights = []
+    for _ in range(int(rng.choice([2, 2, 3, 3, 3, 4, 5, 6, 7, 10]))):
+        kind = int(rng.integers(0, 3))
+        col = tuple(f(.2, 1.2, 3))
+        if kind == abi.RM_LIGHT_DIRECTIONAL:
+            lights.append(h.make_light(kind, col, direction=(f(-1, 1), f(-1, 0.6), f(-1, 1))))
+        elif kind == abi.RM_LIGHT_POINT:
+            lights.append(h.make_light(kind, col, pos=(f(-4, 4), f(-1, 5), f(-3, 5)), func=(f(.5, 1), f(0, .1), f(0, .02))))
+        else:
+            lights.append(h.make_light(kind, col, direction=(f(-.3, .3), -1, f(-.6, 0)), pos=(f(-2, 2), f(3, 5), f(0, 3)),
+                                       func=(f(.5, 1), f(0, .1), 0), angle=float(f(.4, .9)), penumbra=float(f(.05, .3))))
+    feats = int(rng.choice([abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND, 0]))
+    if f() < 0.5:
+        feats |= abi.RM_FEAT_PERLIN_BUMP
+    s = abi.default_settings(features=feats, enableSoftShadow=int(f() < 0.5), enableAmbientOcclusion=int(f() < 0.4),
+                             enableReflection=int(f() < 0.4), enableRefraction=int(f() < 0.3),
+                             maxSteps=int(rng.choice([16, 64, 256])), numReflection=int(rng.choice([1, 2, 3])))
+    g = h.make_globals(ka=f(.2, .8), kd=f(.3, 1), ks=f(.2, 1), kt=f(.2, 1))
+    cam = h.make_camera((f(-1, 1), f(0.5, 2.5), f(4.5, 6.5)), (f(-.15, .15), f(-.45, -.05), -1), (0, 1, 0), float(f(35, 60)), W, H)
+    return (cam, (abi.RmObject * len(objs))(*objs), len(objs), (abi.RmLight * len(lights))(*lights), len(lights), g), s
+
+
+def test_random_primitive_scenes_bit_exact(renderer):
+    """Seeded random all-primitive scenes (the general random test draws a fractal into most tables, which switches the
+    single-object fast path off): the GPU equals the oracle in every bit, through both schedules."""
+    from raymarcher_amd import lib
+    W, H = 56, 40
+    rng = np.random.default_rng(int(os.environ.get("RM_FUZZ_SEED", "20261007")))
+    for i in range(int(os.environ.get("RM_FUZZ_CASES", "32"))):
+        scene, s = _random_primitive_case(rng, W, H)
+        ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+        out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+        assert_bit_equal(out.cpu().numpy(), ref, f"random primitive scene {i}")
+        assert_bit_equal(br.cpu().numpy(), ref_b, f"random primitive scene {i} bright")
+        if not s.enableRefraction and i % 4 == 0:
+            try:
+                lib().rm_set_kernel_path(5)
+                wf = renderer.render(tables_of(scene), s, W, H)
+                assert lib().rm_debug_last_path() == 5 and _ieq(wf, out)
+            finally:
+                lib().rm_set_kernel_path(0)
+
+
 def _random_bulb_case(rng, W, H):
     """A random scene of the single-Mandelbulb class (its own kernel instantiation: bounding-ball culls of two radii,
     v_min orbit trap, per-lane shadow-ray queue): model transform incl. anisotropic scales and tiny objects, Julia seeds
@@ -1272,7 +1334,8 @@ def test_bounding_box_cull_edge_cases(renderer):
 
 def test_table_walk_skip_edge_cases(renderer):
     """The table walk passes over objects that cannot lower a lane's minimum (sdScene<…, SKIP>, seeded by a Lipschitz bound from
-    the previous step): it must never change a bit — ties between identical objects (the lower index wins: different materials
+    the previous step) and follows a single object while the runner-up stays above that bound (march()'s fast path): neither may
+    ever change a bit — ties between identical objects (the lower index wins: different materials
     show it), the camera inside an object (negative distances), a full table of 30, a scaleFactor that is NOT the smallest
     scale (the distance values are then 2-Lipschitz and the march overshoots, as the reference's would), sheared model
     matrices, every shading option, both schedules."""
@@ -1307,6 +1370,14 @@ def test_table_walk_skip_edge_cases(renderer):
     cases.append((cam, [h.make_object(abi.RM_SPHERE, model=h.translate(-2, 0, 0) @ h.scale(1.5, 0.5, 1.5), scale_factor=1.0, **red),
                         h.make_object(abi.RM_CYLINDER, model=h.translate(0.5, 0, 0) @ shear @ h.scale(1.2, 1.2, 1.2), scale_factor=1.2, **blue),
                         h.make_object(abi.RM_RECTANGLE, model=h.translate(2.5, 0.2, -0.5) @ rot_x(0.4) @ h.scale(2, 2, 2), scale_factor=2, **red), floor]))
+    # a single object (the runner-up bound is +inf: the march follows that object alone from its second step on)
+    cases.append((cam, [h.make_object(abi.RM_TORUS, model=rot_x(0.9) @ h.scale(3, 3, 3), scale_factor=3, **red)]))
+    # objects that touch: crevices where two of them stay equally near for hundreds of steps, rays that pass one object closely
+    # and hit the next (the nearest object changes along the ray)
+    cases.append((cam, [h.make_object(abi.RM_SPHERE, model=h.translate(-0.5, -0.5, 0), **red),
+                        h.make_object(abi.RM_SPHERE, model=h.translate(0.5, -0.5, 0), **blue),
+                        h.make_object(abi.RM_CUBE, model=h.translate(0, -0.5, -1.0), **red),
+                        h.make_object(abi.RM_CAPSULE, model=h.translate(1.2, -1.0, 0.8) @ h.scale(2, 2, 2), scale_factor=2, **blue), floor]))
     g = h.make_globals()
     for k, (c, objs) in enumerate(cases):
         arr = (abi.RmObject * len(objs))(*objs)
