@@ -151,10 +151,23 @@ def flop_model(t, s, cnt, executed=False):
         per_eval = FLOP_PER_EVAL_BULB
     per_shade = FLOP_PER_SHADE + FLOP_PER_LIGHT * t.num_lights + (4 * FLOP_PER_PNOISE if s.features & abi.RM_FEAT_PERLIN_BUMP else 0)
     shades = cnt.shadedPoints if cnt.shadedPoints else cnt.hitPixels
-    parts = {"iterations": cnt.bulbIters * FLOP_PER_ITER, "evaluations": cnt.sceneEvals * per_eval, "shading": shades * per_shade,
+    eval_flop = cnt.sceneEvals * per_eval
+    shapes = getattr(cnt, "shapeEvals", 0)
+    if executed and not bulb_only and t.num_objects > 0 and 0 < shapes < cnt.sceneEvals * t.num_objects:
+        # the table walk passed over objects (or followed one alone): price the shapes really evaluated at the table's mean
+        # cost per object, plus transform + test (27) for the ones passed over in full walks — an upper bound, since the
+        # single-object fast path does not even touch the others
+        mean_obj = (per_eval - FLOP_PER_STEP) / t.num_objects
+        eval_flop = cnt.sceneEvals * FLOP_PER_STEP + shapes * mean_obj + (cnt.sceneEvals * t.num_objects - shapes) * 27
+        model_note = "evaluations priced by shapeEvals (objects really evaluated) + 27 flop per object passed over"
+    else:
+        model_note = None
+    parts = {"iterations": cnt.bulbIters * FLOP_PER_ITER, "evaluations": eval_flop, "shading": shades * per_shade,
              "terrain": cnt.terrainEvals * FLOP_PER_FBM9, "cloud": cnt.cloudEvals * FLOP_PER_FBMD8}
     model = {"flop_per_evaluation": per_eval, "flop_per_iteration": FLOP_PER_ITER, "flop_per_shaded_point": per_shade,
              "flop_per_terrain_eval": FLOP_PER_FBM9, "flop_per_cloud_eval": FLOP_PER_FBMD8}
+    if model_note:
+        model["note"] = model_note
     return float(sum(parts.values())), parts, model
 
 
@@ -511,7 +524,9 @@ def main():
             # executed = the work the one-lane-per-pixel kernel really does (bounding-ball culls, no shadow march for dropped lights)
             executed = flops_exec / world / secs / 1e12 if secs > 0 else 0.0
             roof["executed"] = {"achieved": round(executed, 3), "frac": round(executed / PEAK_FP32_TFLOPS, 4),
-                                "sceneEvals": cnt_exec.sceneEvals, "bulbIters": cnt_exec.bulbIters, "flop_per_launch": flops_exec / world}
+                                "sceneEvals": cnt_exec.sceneEvals, "bulbIters": cnt_exec.bulbIters, "shapeEvals": cnt_exec.shapeEvals,
+                                "shapes_per_evaluation": round(cnt_exec.shapeEvals / max(cnt_exec.sceneEvals, 1), 3),
+                                "flop_per_launch": flops_exec / world}
         if cfg == "c3":
             roof["slots"] = {"algorithmic_frac": round(slots_model(cnt) / world / secs / PEAK_LANE_SLOTS, 4) if secs > 0 else 0.0,
                              "executed_frac": round(slots_model(cnt_exec) / world / secs / PEAK_LANE_SLOTS, 4) if secs > 0 else 0.0,

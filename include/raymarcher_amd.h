@@ -290,6 +290,8 @@ typedef struct RmCounters {
   uint64_t shadedPoints;  /* surface points shaded by render() (frag:2333-2373): primary hits and reflection / refraction hits */
   uint64_t terrainEvals;  /* fbm_9 evaluations (frag:630-644): terrain height samples of the TERRAIN layer */
   uint64_t cloudEvals;    /* fbmd_8 evaluations (frag:647-667): cloud density samples (CLOUD) and the terrain's bump / cloud shadow */
+  uint64_t shapeEvals;    /* sdMatch evaluations (frag:1262-1293): objects evaluated, summed over the sdScene evaluations — numObjects
+                             per evaluation as the shader is written; fewer in RM_COUNT_EXECUTED where the table walk passes over objects */
 } RmCounters;
 /* Same as rm_render but also accumulates counters with device atomics (slower; synchronises).  Counts the REFERENCE's
  * work: every evaluation the shader as written performs, i.e. without the bit-identical shortcuts of the production

@@ -144,7 +144,7 @@ typedef struct {
   const RmResources *res; /* noise / skybox / LTC tables (host pointers); never NULL inside the renderer */
   int W;                  /* screenDimensions.x (frag:246, realtimerender.cpp:622-629) */
   v4 rayPlane[2][2][3];   /* [triangle][near, far][P0, P1 − P0, P2 − P0] of nearClip / farClip, see rayPlanes */
-  uint64_t nEval, nIter, nHit, nShade; /* per-thread work counters */
+  uint64_t nEval, nIter, nHit, nShade, nShape; /* per-thread work counters */
 } Ctx;
 
 typedef struct { int minObjIdx; float minD; v4 trap; } SceneMin;        /* frag:170-182 */
@@ -368,6 +368,7 @@ static SceneMin sdScene(Ctx *c, v3 p) {
       case RM_SIERPINSKI: d = sdSierpinski(po); break;
       default: continue; /* UB4 */
     }
+    c->nShape++;
     float currD = d * obj->scaleFactor; /* frag:1419 */
     if (currD < minD) { minD = currD; minObj = i; }
   }
@@ -1626,13 +1627,13 @@ int rmo_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, co
   int st = validate(cam, objs, numObjects, lights, numLights, g, s, res);
   if (st != RM_OK) return st;
   if (W <= 0 || H <= 0 || rowBegin < 0 || rowEnd > H || rowBegin > rowEnd || !rgba) return RM_ERR_INVALID_ARGUMENT;
-  uint64_t nEval = 0, nIter = 0, nHit = 0, nShade = 0, nFbm9 = 0, nFbmd8 = 0;
+  uint64_t nEval = 0, nIter = 0, nHit = 0, nShade = 0, nShape = 0, nFbm9 = 0, nFbmd8 = 0;
   if (threads < 1) threads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : nEval, nIter, nHit, nShade, nFbm9, nFbmd8)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : nEval, nIter, nHit, nShade, nShape, nFbm9, nFbmd8)
   for (int y = rowBegin; y < rowEnd; y++) {
     Ctx c;
     c.cam = cam; c.objs = objs; c.numObjects = numObjects; c.lights = lights; c.numLights = numLights;
-    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = c.nShade = 0; c.tex = res->textures; c.numTex = res->numTextures;
+    c.g = *g; c.s = *s; c.nEval = c.nIter = c.nHit = c.nShade = c.nShape = 0; c.tex = res->textures; c.numTex = res->numTextures;
     c.res = res; c.W = W;
     rayPlanes(cam->invProjView, c.rayPlane);
     t_nFbm9 = t_nFbmd8 = 0;
@@ -1640,11 +1641,11 @@ int rmo_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, co
       size_t o = ((size_t)(y - rowBegin) * W + x) * 4;
       shadePixel(&c, x, y, W, H, rgba + o, bright ? bright + o : NULL);
     }
-    nEval += c.nEval; nIter += c.nIter; nHit += c.nHit; nShade += c.nShade; nFbm9 += t_nFbm9; nFbmd8 += t_nFbmd8;
+    nEval += c.nEval; nIter += c.nIter; nHit += c.nHit; nShade += c.nShade; nShape += c.nShape; nFbm9 += t_nFbm9; nFbmd8 += t_nFbmd8;
   }
   if (counters) {
     counters->sceneEvals = nEval; counters->bulbIters = nIter; counters->hitPixels = nHit;
-    counters->shadedPoints = nShade; counters->terrainEvals = nFbm9; counters->cloudEvals = nFbmd8;
+    counters->shadedPoints = nShade; counters->terrainEvals = nFbm9; counters->cloudEvals = nFbmd8; counters->shapeEvals = nShape;
   }
   return RM_OK;
 }

@@ -89,7 +89,7 @@ class RmSettings(C.Structure):
 
 class RmCounters(C.Structure):
     _fields_ = [("sceneEvals", C.c_uint64), ("bulbIters", C.c_uint64), ("hitPixels", C.c_uint64),
-                ("shadedPoints", C.c_uint64), ("terrainEvals", C.c_uint64), ("cloudEvals", C.c_uint64)]
+                ("shadedPoints", C.c_uint64), ("terrainEvals", C.c_uint64), ("cloudEvals", C.c_uint64), ("shapeEvals", C.c_uint64)]
 
 
 class RmPostSettings(C.Structure):

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void bulb_primary_kernel(const SceneBlock *__r
 __global__ __launch_bounds__(256) void bulb_surface_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                             BulbWs ws) {
   const uint32_t nHits = ws.counters[1];  // reserved slots (multiple of kSlotChunk); holes have pix < 0
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nHits; h += gridDim.x * blockDim.x) {
     const int pix = ws.hitPix[h];
     if (pix < 0) continue;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void bulbB_primary_kernel(const SceneBlock *__
   if (inside) {
     V3 ro, rd;
     primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
-    Counters cnt{0, 0, 0, 0, 0};
+    Counters cnt{0, 0, 0, 0, 0, 0};
     res = march<true, false, false>(sb, ro, rd, sb->cam.initialFar, 1.0f, cnt);  // frag:2322
     hit = res.obj != -1;
     if (!hit) {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void bulbB_surface_kernel(const SceneBlock *__
   const uint32_t nHits = ws.counters[1];
   const int nl = sb->numLights;
   const float far = sb->cam.initialFar;
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   const uint32_t stride = gridDim.x * blockDim.x;
   // every thread of a block runs the same number of trips so that the block-level appends stay collective
   for (uint32_t h0 = blockIdx.x * blockDim.x; h0 < nHits; h0 += stride) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void bulbB_surface_kernel(const SceneBlock *__
 __global__ __launch_bounds__(256) void bulbB_shadow_kernel(const SceneBlock *__restrict__ sb, BulbWsB ws) {
   const int nl = sb->numLights;
   const float far = sb->cam.initialFar;
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   const uint32_t stride = gridDim.x * blockDim.x;
   for (int i = 0; i < nl; i++) {
     const uint32_t nRays = ws.counters[4 + i];
@@ -569,7 +569,7 @@ constexpr int kCntShadow = 24;   // counters[24 + pass] : rays queued FOR shadow
 // 2 = hit (res filled).
 RM_DEV int marchBudget(const SceneBlock *sb, V3 ro, V3 rd, float end, int maxSteps, int budget, float &t, int &steps,
                        MarchRes &res) {
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   for (int local = 0; ; ) {
     if (steps >= maxSteps) return 1;
     const SceneMin c = sdScene<true, false>(sb, madd(rd, t, ro), cnt);
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void bulbC_primary_kernel(const SceneBlock *__
 // One budgeted stretch of softshadow() (frag:1708-1714).  Returns 0 = budget used up, 1 = ended, hit flag in `hit`.
 RM_DEV int shadowBudget(const SceneBlock *sb, V3 so, V3 L, float maxT, int maxSteps, int budget, float &t, float &pen,
                         int &steps, bool &hit) {
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   for (int local = 0; ; ) {
     hit = false;
     if (steps >= maxSteps) return 1;

@@ -52,8 +52,8 @@ constexpr float kSurfaceDist = 0.001f;  // frag:32
 // dropped lights still marched — the algorithmic figure of the roofline), 2 = count the work the production kernel really
 // executes (culls and skips honoured).  evals = sdScene evaluations, iters = Mandelbulb iterations, shades = surface points
 // shaded by render() (normal + bump + Phong; primary hits and bounce hits), fbm9 / fbmd8 = terrain-height and cloud-noise
-// evaluations of the procedural layers (frag:630-667).
-struct Counters { unsigned long long evals, iters, shades, fbm9, fbmd8; };
+// evaluations of the procedural layers (frag:630-667), shapes = sdMatch evaluations (objects really evaluated by the table walk).
+struct Counters { unsigned long long evals, iters, shades, fbm9, fbmd8, shapes; };
 
 }  // namespace rm
 #include "rm_sampler.hip.h"
@@ -398,6 +398,7 @@ RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub,
         continue;
       }
     }
+    if (COUNT) cnt.shapes++;
     float d;
     const int type = BULB ? (int)RM_MANDELBULB : o.type;
     switch (type) {  // sdMatch, frag:1262-1293 — wave-uniform branch
@@ -439,7 +440,7 @@ RM_DEV SceneMin sdSceneOne(const SceneBlock *sb, int j, V3 p, Counters &cnt) {
   SceneMin res;
   res.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
   res.idx = j;
-  if (COUNT) cnt.evals++;
+  if (COUNT) { cnt.evals++; cnt.shapes++; }
   const EvalRecord &o = sb->evalRec[j];
   float M[12];
 #pragma unroll

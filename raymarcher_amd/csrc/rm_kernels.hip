@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   if (x >= W || r >= nRows) return;
   const int y = map.frameRow(r);
   V4 col, br;
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   bool hit;
   shadePixel<BULB, CM, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
     if (cnt.shades) atomicAdd(&counters[6], cnt.shades);
     if (cnt.fbm9) atomicAdd(&counters[7], cnt.fbm9);
     if (cnt.fbmd8) atomicAdd(&counters[8], cnt.fbmd8);
+    if (cnt.shapes) atomicAdd(&counters[9], cnt.shapes);
   }
   if (sb->tileCost && sb->tileCount == (int)(gridDim.x * gridDim.y)) {  // wave-uniform
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
@@ -241,7 +242,7 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
 __global__ void probe_sdscene_kernel(const SceneBlock *__restrict__ sb, const float *pts, float *out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   SceneMin m = sdScene<false, 0>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
   out[4 * i] = m.d;
   out[4 * i + 1] = (float)m.idx;
@@ -311,7 +312,7 @@ struct DeviceState {
   std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
   std::vector<Slot> slots;       // ring of scene-table slots; grows (to kSlotsMax) instead of waiting for a busy slot
   size_t next = 0;
-  unsigned long long *dCounters = nullptr;  // 9 words: evals, iterations, hits, clock stamps (2), span pointer, shades, fbm9, fbmd8
+  unsigned long long *dCounters = nullptr;  // 10 words: evals, iterations, hits, clock stamps (2), span pointer, shades, fbm9, fbmd8, shapes
   std::vector<TimedLaunch> timed;           // rm_set_timing / rm_get_timing, per device
   int numCUs = 0;
   std::map<hipStream_t, TileOrderState> tileOrder;  // what the feedback costs of each stream belong to
@@ -353,7 +354,7 @@ int acquire_slot(DeviceState &ds, Slot **out) {
     int st = RM_OK;
     for (auto &s : fresh)
       if ((st = new_slot(&s)) != RM_OK) break;
-    if (st == RM_OK && hipMalloc(reinterpret_cast<void **>(&counters), 9 * sizeof(unsigned long long)) != hipSuccess) {
+    if (st == RM_OK && hipMalloc(reinterpret_cast<void **>(&counters), 10 * sizeof(unsigned long long)) != hipSuccess) {
       set_error("hipMalloc of the counter block failed");
       st = RM_ERR_DEVICE;
     }
@@ -903,7 +904,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (st != RM_OK) return st;
   unsigned long long *dc = ds.dCounters;
   if (count) {
-    HIP_OK(hipMemsetAsync(dc, 0, 9 * sizeof(unsigned long long), stream));
+    HIP_OK(hipMemsetAsync(dc, 0, 10 * sizeof(unsigned long long), stream));
     if (d_waveSpans) HIP_OK(hipMemcpyAsync(dc + 5, &d_waveSpans, sizeof(d_waveSpans), hipMemcpyHostToDevice, stream));
   }
   TimedLaunch tl{};
@@ -1052,12 +1053,13 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (timing) { ds.timed.push_back(tl); timedGuard.kept = true; }
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
-    unsigned long long hc[9];
+    unsigned long long hc[10];
     HIP_OK(hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (countersOut) {
       countersOut->sceneEvals = hc[0]; countersOut->bulbIters = hc[1]; countersOut->hitPixels = hc[2];
       countersOut->shadedPoints = hc[6]; countersOut->terrainEvals = hc[7]; countersOut->cloudEvals = hc[8];
+      countersOut->shapeEvals = hc[9];
     }
     if (clockMHz) *clockMHz = hc[4] ? 100.0 * (double)hc[3] / (double)hc[4] : 0.0;
   }

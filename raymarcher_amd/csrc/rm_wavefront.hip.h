@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
   const float ks = sb->g.ks;
   const unsigned long long lt = laneMaskLt();
   const int cur = gen & 1;
-  Counters none{0, 0, 0, 0, 0};
+  Counters none{0, 0, 0, 0, 0, 0};
 
   int st = ST_NEED, steps = 0;
   uint32_t src = 0;
@@ -293,7 +293,7 @@ template <bool SKIP>
 __global__ __launch_bounds__(256) void wf_surface_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H, WfWs ws,
                                                           int gen) {
   const uint32_t nSlots = ws.counters[WF_STRIDE * gen + WF_HITS];
-  Counters none{0, 0, 0, 0, 0};
+  Counters none{0, 0, 0, 0, 0, 0};
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nSlots; h += gridDim.x * blockDim.x) {
     const int4 rec = ws.hit[h];
     if (rec.x < 0) continue;

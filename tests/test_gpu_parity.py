@@ -826,10 +826,16 @@ def test_counters_of_every_kernel_class_match_oracle(renderer):
         for k, v in res.items():
             setattr(t, k, v)
         out, g = renderer.render_counted(t, s, W, H)
-        assert (g.sceneEvals, g.bulbIters, g.hitPixels, g.shadedPoints, g.terrainEvals, g.cloudEvals) == \
-               (cnt.sceneEvals, cnt.bulbIters, cnt.hitPixels, cnt.shadedPoints, cnt.terrainEvals, cnt.cloudEvals)
+        assert (g.sceneEvals, g.bulbIters, g.hitPixels, g.shadedPoints, g.terrainEvals, g.cloudEvals, g.shapeEvals) == \
+               (cnt.sceneEvals, cnt.bulbIters, cnt.hitPixels, cnt.shadedPoints, cnt.terrainEvals, cnt.cloudEvals, cnt.shapeEvals)
         assert_bit_equal(out.cpu().numpy(), ref, "counted frame")
+        assert g.shapeEvals == g.sceneEvals * scene[2]  # as the shader is written: every object at every evaluation
     assert cnt.shadedPoints > 0
+    # the executed-work count of the plain class: the table walk passes over objects, the same frame
+    scene, s, _ = cases[0]
+    out, g1 = renderer.render_counted(tables_of(scene), s, W, H)
+    out2, g2 = renderer.render_counted(tables_of(scene), s, W, H, abi.RM_COUNT_EXECUTED)
+    assert _ieq(out, out2) and g2.sceneEvals <= g1.sceneEvals and 0 < g2.shapeEvals < g1.shapeEvals
 
 
 def test_rgba8_flip_and_png(renderer, tmp_path):
