@@ -37,6 +37,18 @@ def main():
     for name, t, s in cases:
         out = torch.empty((H, W, 4), dtype=torch.float32, device=r.device)
         row = [name]
+        # round 3: orders from a classification of the tiles a launcher could get from the scene's projected bounds — here the
+        # ideal version of it, from the frame itself (which tiles hold object pixels): objects first / background last, and
+        # silhouette tiles (object and background pixels) before full-object tiles
+        r.render(t, s, W, H, out=out)
+        bgc = out[H - 1, 0].clone()
+        isbg = (out == bgc).all(dim=-1)  # (H, W)
+        pad = torch.ones((ty * 8, tx * 8), dtype=torch.bool, device=r.device)
+        pad[:H, :W] = isbg
+        tiles = pad.view(ty, 8, tx, 8).permute(0, 2, 1, 3).reshape(n, 64)
+        nbg = tiles.sum(dim=1)
+        orders["objects first, background last"] = torch.argsort((nbg == 64).to(torch.int32), stable=True)
+        orders["silhouette, objects, background"] = torch.argsort(torch.where(nbg == 64, 2, torch.where(nbg > 0, 0, 1)).to(torch.int32), stable=True)
         for oname, o in orders.items():
             oo = None if o is None else o.to(torch.int32).contiguous()
             L.rm_debug_set_tile_order(C.c_void_p(oo.data_ptr()) if oo is not None else None, None, n if oo is not None else 0)
