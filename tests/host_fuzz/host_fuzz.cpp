@@ -1,0 +1,175 @@
+// Sanitizer harness for the host side of the library (TEST INFRASTRUCTURE): the scenefile loader (rm_scene.cpp) and the image readers
+// (PNG in rm_host.cpp, rm_jpeg.cpp, rm_gif.cpp) compiled with g++ -fsanitize=address,undefined — the GPU build cannot run
+// under a sanitizer on this pool — and driven over (1) every scenefile and image of tests/golden/scenes and (2) seeded random
+// mutations of them (truncations, byte flips, spliced ranges, structural JSON tokens).  Any out-of-bounds access, overflow or
+// leak aborts the run; a mutated input may of course be REJECTED (RM_ERR_*), it must not crash.
+// Usage: host_fuzz <scenes dir> <tmp dir> <iterations> <seed>
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/raymarcher_amd.h"
+#include "../../raymarcher_amd/csrc/rm_internal.h"
+
+// the two helpers the launcher (rm_kernels.hip) defines for the host files
+namespace rm {
+static thread_local std::string t_err;
+bool device_accessible(const void *) { return false; }
+int require_device_pointers(std::initializer_list<std::pair<const char *, const void *>>) { return RM_ERR_INVALID_ARGUMENT; }
+}  // namespace rm
+
+static void walk(const std::string &dir, std::vector<std::string> &out) {
+  DIR *d = opendir(dir.c_str());
+  if (!d) return;
+  while (dirent *e = readdir(d)) {
+    std::string n = e->d_name;
+    if (n == "." || n == "..") continue;
+    std::string p = dir + "/" + n;
+    struct stat st;
+    if (stat(p.c_str(), &st) != 0) continue;
+    if (S_ISDIR(st.st_mode)) walk(p, out); else out.push_back(p);
+  }
+  closedir(d);
+}
+static std::vector<uint8_t> slurp(const std::string &p) {
+  std::ifstream f(p, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static bool ends(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
+
+static uint64_t g_sum = 0;
+static int touch_scene(RmScene *sc) {
+  const int no = rm_scene_num_objects(sc), nl = rm_scene_num_lights(sc);
+  const RmObject *o = rm_scene_objects(sc);
+  const RmLight *l = rm_scene_lights(sc);
+  const uint8_t *b = reinterpret_cast<const uint8_t *>(o);
+  for (size_t i = 0; i < sizeof(RmObject) * (size_t)no; i++) g_sum += b[i];
+  b = reinterpret_cast<const uint8_t *>(l);
+  for (size_t i = 0; i < sizeof(RmLight) * (size_t)nl; i++) g_sum += b[i];
+  RmCameraData cd;
+  if (rm_scene_camera_data(sc, &cd) == RM_OK) {
+    float view[16], proj[16], invVP[16];
+    (void)view; (void)proj; (void)invVP;
+  }
+  RmHostSettings hs;
+  rm_host_settings_default(&hs);
+  RmGlobals g;
+  rm_scene_globals(sc, &hs, &g);
+  for (int i = 0; i < no; i++) { const char *t = rm_scene_object_texture(sc, i); if (t) g_sum += strlen(t); }
+  return no + nl;
+}
+static void try_scene_string(const std::string &js) {
+  RmScene *sc = nullptr;
+  if (rm_scene_load_string(js.c_str(), &sc) == RM_OK && sc) { touch_scene(sc); rm_scene_free(sc); }
+}
+static void try_image(const std::string &path) {
+  for (int flip = 0; flip < 2; flip++) {
+    uint8_t *px = nullptr;
+    int w = 0, h = 0;
+    if (rm_image_load(path.c_str(), flip, &px, &w, &h) == RM_OK && px) {
+      for (size_t i = 0; i < (size_t)w * (size_t)h * 4; i += 97) g_sum += px[i];
+      rm_image_free(px);
+    }
+  }
+}
+static void mutate(std::vector<uint8_t> &d, std::mt19937 &rng, bool json) {
+  static const char *toks[] = {"{", "}", "[", "]", ",", ":", "\"", "null", "true", "-", "1e999", "1e-999", "0", "\\u", "\\", "-0", "99999999999999999999", "\"type\"", "\"primitive\"", "\"children\"", "\"matrix\"", "\"rotate\"", "\"translate\"", "\"scale\"", "\"lights\"", "\"groups\"", "\"textureFile\"", "\"cameraData\"", "\"globalData\""};
+  const int n = 1 + (int)(rng() % 4);
+  for (int k = 0; k < n && !d.empty(); k++) {
+    const size_t pos = rng() % d.size();
+    if (json && rng() % 2) {
+      // value-level mutation that keeps the document well-formed: a numeric token replaced by an extreme, or a quoted string by another
+      static const char *nums[] = {"0", "-0", "1e38", "-1e38", "1e-45", "1e999", "-1", "255", "256", "65536", "2147483648", "-2147483649", "0.5", "360", "1e10", "3.4028236e38", "4", "64", "1000"};
+      static const char *strs[] = {"\"sphere\"", "\"cube\"", "\"cone\"", "\"cylinder\"", "\"mandelbulb\"", "\"mengersponge\"", "\"custom\"", "\"point\"", "\"spot\"", "\"directional\"", "\"area\"", "\"\"", "\"../../../../etc/passwd\"", "\"x\""};
+      size_t i = pos;
+      const bool wantNum = rng() % 4 != 0;
+      for (size_t steps = 0; steps < d.size(); steps++, i = (i + 1) % d.size()) {
+        if (wantNum && ((d[i] >= '0' && d[i] <= '9') || d[i] == '-')) {
+          size_t e = i;
+          while (e < d.size() && ((d[e] >= '0' && d[e] <= '9') || d[e] == '.' || d[e] == '-' || d[e] == '+' || d[e] == 'e' || d[e] == 'E')) e++;
+          const char *t = nums[rng() % (sizeof(nums) / sizeof(nums[0]))];
+          d.erase(d.begin() + i, d.begin() + e);
+          d.insert(d.begin() + i, t, t + strlen(t));
+          break;
+        }
+        if (!wantNum && d[i] == ':') {
+          size_t a = i + 1;
+          while (a < d.size() && (d[a] == ' ' || d[a] == '\n' || d[a] == '\t')) a++;
+          if (a < d.size() && d[a] == '"') {
+            size_t e = a + 1;
+            while (e < d.size() && d[e] != '"') e++;
+            if (e < d.size()) {
+              const char *t = strs[rng() % (sizeof(strs) / sizeof(strs[0]))];
+              d.erase(d.begin() + a, d.begin() + e + 1);
+              d.insert(d.begin() + a, t, t + strlen(t));
+              break;
+            }
+          }
+        }
+      }
+      continue;
+    }
+    switch (rng() % (json ? 7 : 6)) {
+      case 0: d.resize(pos); break;                                                     // truncate
+      case 1: d[pos] ^= (uint8_t)(1u << (rng() % 8)); break;                            // bit flip
+      case 2: d[pos] = (uint8_t)rng(); break;                                           // random byte
+      case 3: { size_t len = 1 + rng() % 64; if (pos + len > d.size()) len = d.size() - pos; d.erase(d.begin() + pos, d.begin() + pos + len); break; }
+      case 4: { size_t len = 1 + rng() % 64; if (pos + len > d.size()) len = d.size() - pos; std::vector<uint8_t> c(d.begin() + pos, d.begin() + pos + len); size_t at = rng() % (d.size() + 1); d.insert(d.begin() + at, c.begin(), c.end()); break; }
+      case 5: { const uint8_t v[] = {0, 0xff, 0x7f, 0x80}; size_t len = 1 + rng() % 4; for (size_t i = 0; i < len && pos + i < d.size(); i++) d[pos + i] = v[rng() % 4]; break; }
+      default: { const char *t = toks[rng() % (sizeof(toks) / sizeof(toks[0]))]; d.insert(d.begin() + pos, t, t + strlen(t)); break; }
+    }
+  }
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "usage: host_fuzz <scenes dir> <tmp dir> <iterations> <seed>\n"); return 2; }
+  const std::string root = argv[1], tmp = argv[2];
+  const int iters = atoi(argv[3]);
+  std::mt19937 rng((unsigned)atoi(argv[4]));
+  std::vector<std::string> files, scenes, images;
+  walk(root, files);
+  for (auto &f : files) {
+    if (ends(f, ".json")) scenes.push_back(f);
+    else if (ends(f, ".png") || ends(f, ".jpg") || ends(f, ".jpeg") || ends(f, ".gif")) images.push_back(f);
+  }
+  if (scenes.empty() || images.empty()) { fprintf(stderr, "no inputs under %s\n", root.c_str()); return 2; }
+  int loaded = 0;
+  for (auto &s : scenes) {
+    RmScene *sc = nullptr;
+    if (rm_scene_load(s.c_str(), &sc) == RM_OK && sc) { touch_scene(sc); rm_scene_free(sc); loaded++; }
+  }
+  for (auto &i : images) try_image(i);
+  // small images only for the mutation phase (a 2.6-megapixel PNG per iteration would spend the budget in zlib)
+  std::vector<std::pair<std::string, std::vector<uint8_t>>> imgData, sceneData;
+  for (auto &i : images) { auto d = slurp(i); if (d.size() <= 600000) imgData.emplace_back(i, std::move(d)); }
+  for (auto &s : scenes) sceneData.emplace_back(s, slurp(s));
+  int accepted = 0;
+  for (int it = 0; it < iters; it++) {
+    if (it % 3 != 0 || imgData.empty()) {
+      auto d = sceneData[rng() % sceneData.size()].second;
+      mutate(d, rng, true);
+      std::string js(d.begin(), d.end());
+      RmScene *sc = nullptr;
+      if (rm_scene_load_string(js.c_str(), &sc) == RM_OK && sc) { touch_scene(sc); rm_scene_free(sc); accepted++; }
+    } else {
+      auto &src = imgData[rng() % imgData.size()];
+      auto d = src.second;
+      mutate(d, rng, false);
+      const std::string ext = src.first.substr(src.first.rfind('.'));
+      const std::string p = tmp + "/fuzz_img" + ext;
+      { std::ofstream o(p, std::ios::binary); o.write(reinterpret_cast<const char *>(d.data()), (std::streamsize)d.size()); }
+      try_image(p);
+    }
+  }
+  printf("host_fuzz ok: %d of %zu scenefiles loaded, %zu images decoded, %d mutations run (%d mutated scenefiles still accepted), checksum %llu\n",
+         loaded, scenes.size(), images.size(), iters, accepted, (unsigned long long)g_sum);
+  return 0;
+}
