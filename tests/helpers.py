@@ -18,9 +18,11 @@ def oracle():
     """ctypes handle of oracle/_build/librm_oracle.so (built on demand with make)."""
     global _ORACLE
     if _ORACLE is None:
-        so = os.path.join(ROOT, "oracle", "_build", "librm_oracle.so")
-        if not os.path.exists(so):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        so = os.environ.get("RM_ORACLE_SO")  # a sanitizer build of the oracle for a one-off check (with LD_PRELOAD=libasan.so)
+        if not so:
+            so = os.path.join(ROOT, "oracle", "_build", "librm_oracle.so")
+            if not os.path.exists(so):
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
         lib = C.CDLL(so)
         lib.rmo_const_bits.restype = C.c_uint32
         _ORACLE = lib

@@ -56,8 +56,12 @@ static int touch_scene(RmScene *sc) {
   for (size_t i = 0; i < sizeof(RmLight) * (size_t)nl; i++) g_sum += b[i];
   RmCameraData cd;
   if (rm_scene_camera_data(sc, &cd) == RM_OK) {
-    float view[16], proj[16], invVP[16];
-    (void)view; (void)proj; (void)invVP;
+    float view[16], proj[16];
+    RmCamera cam;
+    if (rm_camera_build(&cd, 640, 360, 0.1f, 100.0f, view, proj, &cam) == RM_OK) {
+      const uint8_t *c = reinterpret_cast<const uint8_t *>(&cam);
+      for (size_t i = 0; i < sizeof(cam); i++) g_sum += c[i];
+    }
   }
   RmHostSettings hs;
   rm_host_settings_default(&hs);
