@@ -8,18 +8,18 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum { K_BFI = 0, K_BFE, K_LSHLADD, K_ANDOR, K_ASHR, K_XOR, K_CNDMASK, K_CMP, K_CMPVCC_CND, K_SUBABS, K_MINABS, K_ADD3, K_FMA, K_BITOP3, K_MIN2, K_MINABS2, K_MAXABS, K_MINE64, K_BITOP3S, K_FMAS, K_COUNT };
+enum { K_BFI = 0, K_BFE, K_LSHLADD, K_ANDOR, K_ASHR, K_XOR, K_CNDMASK, K_CMP, K_CMPVCC_CND, K_SUBABS, K_MINABS, K_ADD3, K_FMA, K_BITOP3, K_MIN2, K_MINABS2, K_MAXABS, K_MINE64, K_BITOP3S, K_FMAS, K_MAX2, K_MUL2, K_COUNT };
 static const char *kNames[] = {"v_bfi_b32 v,v,v", "v_bfe_i32 v,0,1", "v_lshl_add_u32 v,31,v", "v_and_or_b32 v,v,v", "v_ashrrev_i32 31,v (VOP2)",
                                "v_xor_b32 v,v (VOP2)", "v_cndmask_b32_e64 v,v,s[..] (mask fixed)", "v_cmp_gt_f32_e64 s[..],v,v (no reader)",
                                "v_cmp_gt_f32 vcc + v_cndmask vcc pairs", "v_sub_f32 |v|,|v| (VOP3)", "v_min_f32 1.0,|v| (VOP3)", "v_add3_u32 v,v,v",
                                "v_fma_f32 v,v,v", "v_bitop3_b32 v,v,v", "v_min_f32 v,v (VOP2)", "v_min_f32 v,|v| (VOP3)", "v_max_f32 |v|,|v| (VOP3)",
-                               "v_min_f32_e64 v,v (VOP3, no modifier)", "v_bitop3_b32 v,v,s (mask in an SGPR)", "v_fma_f32 v,s,v (SGPR operand)"};
+                               "v_min_f32_e64 v,v (VOP3, no modifier)", "v_bitop3_b32 v,v,s (mask in an SGPR)", "v_fma_f32 v,s,v (SGPR operand)", "v_max_f32 v,v (VOP2)", "v_mul_f32 v,v (VOP2)"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stamps, unsigned a, unsigned b, int trips) {
   unsigned v[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) v[i] = threadIdx.x * 2654435761u + i * 40503u + a;
+  for (int i = 0; i < 16; i++) v[i] = __builtin_bit_cast(unsigned, threadIdx.x * 0.001f + i * 0.37f + 1.0f) + (a & 1u);  // normal floats: no denormal / NaN operands in the float rows
   unsigned long long m = ((unsigned long long)a << 32) | (b * 0x9e3779b9u);
   unsigned long long acc = 0;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stam
         else if (KIND == K_MAXABS) asm volatile("v_max_f32 %0, |%0|, |%1|" : "+v"(v[i]) : "v"(a));
         else if (KIND == K_MINE64) asm volatile("v_min_f32_e64 %0, %0, %1" : "+v"(v[i]) : "v"(a));
         else if (KIND == K_BITOP3S) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(v[i]) : "v"(a), "s"(b));
-        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "s"(a), "v"(b));
+        else if (KIND == K_FMAS) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "s"(a), "v"(b));
+        else if (KIND == K_MAX2) asm volatile("v_max_f32 %0, %1, %0" : "+v"(v[i]) : "v"(b));
+        else asm volatile("v_mul_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
       }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -125,5 +127,7 @@ int main() {
   if (sweep<K_MAXABS>(cus, out, dStamps, h, e0, e1)) return 1;
   if (sweep<K_BITOP3S>(cus, out, dStamps, h, e0, e1)) return 1;
   if (sweep<K_FMAS>(cus, out, dStamps, h, e0, e1)) return 1;
+  if (sweep<K_MAX2>(cus, out, dStamps, h, e0, e1)) return 1;
+  if (sweep<K_MUL2>(cus, out, dStamps, h, e0, e1)) return 1;
   return 0;
 }
