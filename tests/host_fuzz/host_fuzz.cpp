@@ -2,7 +2,8 @@
 // (PNG in rm_host.cpp, rm_jpeg.cpp, rm_gif.cpp) compiled with g++ -fsanitize=address,undefined — the GPU build cannot run
 // under a sanitizer on this pool — and driven over (1) every scenefile and image of tests/golden/scenes and (2) seeded random
 // mutations of them (truncations, byte flips, spliced ranges, structural JSON tokens).  Any out-of-bounds access, overflow or
-// leak aborts the run; a mutated input may of course be REJECTED (RM_ERR_*), it must not crash.
+// leak aborts the run; a mutated input may of course be REJECTED (RM_ERR_*), it must not crash.  (3) the row-tile partition of the
+// multi-GPU path: every frame row in exactly one (shard, local row) for random heights, tile sizes and shard counts.
 // Usage: host_fuzz <scenes dir> <tmp dir> <iterations> <seed>
 #include <dirent.h>
 #include <sys/stat.h>
@@ -155,6 +156,32 @@ int main(int argc, char **argv) {
   std::vector<std::pair<std::string, std::vector<uint8_t>>> imgData, sceneData;
   for (auto &i : images) { auto d = slurp(i); if (d.size() <= 600000) imgData.emplace_back(i, std::move(d)); }
   for (auto &s : scenes) sceneData.emplace_back(s, slurp(s));
+  // the row-tile partition of the multi-GPU path (rm_shard_rows / rm_shard_row_to_frame): for random frame heights, tile sizes and
+  // shard counts every frame row belongs to exactly one (shard, local row), in increasing order per shard
+  int partitions = 0;
+  for (int it = 0; it < 400; it++) {
+    const int H = 1 + (int)(rng() % 5000), tr = 1 + (int)(rng() % 40), ns = 1 + (int)(rng() % 64);
+    std::vector<uint8_t> seen((size_t)H, 0);
+    long total = 0;
+    for (int sh = 0; sh < ns; sh++) {
+      const int rows = rm_shard_rows(H, tr, sh, ns);
+      if (rows < 0 || rows > H) { fprintf(stderr, "rm_shard_rows(%d,%d,%d,%d) = %d\n", H, tr, sh, ns, rows); return 1; }
+      if (sh > 0 && rows > rm_shard_rows(H, tr, 0, ns)) { fprintf(stderr, "shard %d owns more rows than shard 0\n", sh); return 1; }
+      int prev = -1;
+      for (int r = 0; r < rows; r++) {
+        const int fr = rm_shard_row_to_frame(H, tr, sh, ns, r);
+        if (fr < 0 || fr >= H || fr <= prev || seen[(size_t)fr]) { fprintf(stderr, "partition broken: H %d tile %d shards %d shard %d row %d -> %d\n", H, tr, ns, sh, r, fr); return 1; }
+        seen[(size_t)fr] = 1;
+        prev = fr;
+      }
+      if (rm_shard_row_to_frame(H, tr, sh, ns, rows) != -1 || rm_shard_row_to_frame(H, tr, sh, ns, -1) != -1) { fprintf(stderr, "out-of-range local row accepted\n"); return 1; }
+      total += rows;
+    }
+    if (total != H) { fprintf(stderr, "partition of H %d tile %d shards %d covers %ld rows\n", H, tr, ns, total); return 1; }
+    partitions++;
+  }
+  if (rm_shard_rows(0, 8, 0, 1) != -1 || rm_shard_rows(8, 0, 0, 1) != -1 || rm_shard_rows(8, 8, 1, 1) != -1 || rm_shard_rows(8, 8, 0, 0) != -1) { fprintf(stderr, "bad shard arguments accepted\n"); return 1; }
+  g_sum += (uint64_t)partitions;
   int accepted = 0;
   for (int it = 0; it < iters; it++) {
     if (it % 3 != 0 || imgData.empty()) {
