@@ -337,8 +337,21 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
  * scene): 5 = the wavefront pipeline of rm_wavefront.hip.h — per generation of rays (primary, then each reflection
  * bounce of frag:2491-2524) a persistent march kernel whose lanes are rays refilled from a queue as they end, a dense
  * surface kernel, the same march kernel over the shadow rays, a dense light / bounce kernel.  A request that does not
- * apply to the scene falls back to 1.  All paths produce identical bits; the switch exists for A/B measurement and tests. */
+ * apply to the scene (2-4 outside the bulb class, 5 inside it or on a frame its 32-bit ray ids cannot cover) runs 1.  All
+ * paths produce identical bits; the switch exists for A/B measurement and tests. */
 int rm_set_kernel_path(int path);
+/* Scratch memory the library owns.  Everything the schedules need beyond the caller's frame lives in grow-only buffers per
+ * (device, stream): 8 B per tile for the tile-order feedback, the post passes' ping-pong images, and — by far the largest —
+ * the wavefront pipeline's ray / hit / path records, ≈(160 + 4·numLights) bytes per pixel of the launch (5.8 GB for a
+ * 7680×4320 frame, once per stream that renders such frames).  rm_set_workspace_limit caps the size of any ONE such buffer
+ * (0 = no limit, the default; the environment variable RM_WF_MAX_WORKSPACE_BYTES sets the initial value).  When the wavefront
+ * workspace exceeds the limit or the device cannot allocate it, a launch that chose the pipeline by itself (kernel path 0)
+ * renders with rm::render_kernel instead — identical pixels, no workspace — and remembers the refusal for that stream; only
+ * an explicit rm_set_kernel_path(5) reports RM_ERR_DEVICE.  An allocation failure never leaves HIP's error state set.
+ * rm_release_workspaces drains the current device and frees all of its buffers (freedBytes may be NULL); the next launch
+ * that needs one allocates it again, and the next frame on each stream runs in raster tile order. */
+int rm_set_workspace_limit(unsigned long long bytes);
+int rm_release_workspaces(unsigned long long *freedBytes);
 /* Tests: the schedule (numbering above; never 0) the most recent render launch on the current device ran, -1 on error. */
 int rm_debug_last_path(void);
 /* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never

@@ -723,7 +723,7 @@ static float LTC_Evaluate(const Ctx *c, v3 N, v3 V, v3 P, const m3 *MinvIn, cons
   vsum = v3_add(vsum, IntegrateEdgeVec(L[2], L[3]));
   vsum = v3_add(vsum, IntegrateEdgeVec(L[3], L[0]));
   float len = len3(vsum);
-  float z = vsum.z / len;
+  float z = (len == 0.0f) ? 0.0f : vsum.z / len; /* UB11: 0/0 when the four edge terms cancel exactly */
   if (behind) z = -z;
   float scale = sampleLTC(c->res->ltc2, rm_fma(rm_fma(z, 0.5f, 0.5f), LUT_SCALE, LUT_BIAS), rm_fma(len, LUT_SCALE, LUT_BIAS)).w;
   float sum = len * scale;

@@ -394,7 +394,12 @@ RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub,
       const float lim = fma(ub, o.invScale, o.boundR), pp = dot(po, po);
       const bool far = (lim >= 0.0f) && (pp > (lim * lim) * 1.00003f);
       if (__ballot(!far) == 0ull) {
-        if (TRACK) second = min_(second, (fma(__builtin_amdgcn_sqrtf(pp), 0.9999f, -o.boundR) * scaleFactor) * 0.9999f);
+        if (TRACK) {
+          // lower bound of the value passed over, with its safety margin applied DOWNWARD whatever its sign (a lane inside
+          // this object's ball while ub < 0 gives a negative bound: multiplying that by 0.9999 would raise it)
+          const float v = fma(__builtin_amdgcn_sqrtf(pp), 0.9999f, -o.boundR) * scaleFactor;
+          second = min_(second, fma(-fabs_(v), 1.0e-4f, v));
+        }
         continue;
       }
     }
@@ -795,7 +800,7 @@ RM_DEV float ltcEvaluate(const SceneBlock *sb, V3 N, V3 V, V3 P, const M3 &MinvI
   vsum = add(vsum, integrateEdgeVec(L[2], L[3]));
   vsum = add(vsum, integrateEdgeVec(L[3], L[0]));
   float l = len(vsum);
-  float z = vsum.z / l;
+  float z = (l == 0.0f) ? 0.0f : vsum.z / l;  // UB11: 0/0 when the four edge terms cancel exactly
   z = behind ? -z : z;
   float sc = sampleRGBA8<true>(sb->ltc2, RM_LTC_SIZE, RM_LTC_SIZE, fma(fma(z, 0.5f, 0.5f), kLutScale, kLutBias),
                                fma(l, kLutScale, kLutBias)).w;

@@ -316,6 +316,7 @@ struct DeviceState {
   std::vector<TimedLaunch> timed;           // rm_set_timing / rm_get_timing, per device
   int numCUs = 0;
   std::map<hipStream_t, TileOrderState> tileOrder;  // what the feedback costs of each stream belong to
+  std::map<hipStream_t, size_t> wfDenied;  // smallest wavefront workspace (bytes) that could not be had on a stream
   const int32_t *dbgTileOrder = nullptr;  // rm_debug_set_tile_order (experiments): overrides the modes below
   uint32_t *dbgTileCost = nullptr;
   int dbgTileCount = 0;
@@ -399,6 +400,18 @@ std::mutex g_wsMu;
 std::map<WsKey, WsBuf> g_ws;
 }  // namespace
 
+// Largest single workspace buffer the library may allocate (0 = no limit): rm_set_workspace_limit / RM_WF_MAX_WORKSPACE_BYTES.
+std::atomic<unsigned long long> g_wsLimit{~0ull};  // ~0 = not set yet: the environment variable decides
+unsigned long long workspace_limit() {
+  unsigned long long v = g_wsLimit.load();
+  if (v == ~0ull) {
+    const char *e = std::getenv("RM_WF_MAX_WORKSPACE_BYTES");
+    v = e ? std::strtoull(e, nullptr, 10) : 0ull;
+    g_wsLimit.store(v);
+  }
+  return v;
+}
+
 int stream_workspace(int tag, hipStream_t stream, size_t need, void **out) {
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -409,13 +422,42 @@ int stream_workspace(int tag, hipStream_t stream, size_t need, void **out) {
   }
   // only work enqueued on `stream` uses this buffer, and one host thread enqueues on a stream at a time
   if (b->bytes < need) {
+    const unsigned long long limit = workspace_limit();
+    if (limit && need > limit) {
+      set_error("workspace of " + std::to_string(need) + " bytes exceeds the limit of " + std::to_string(limit) + " (rm_set_workspace_limit)");
+      return RM_ERR_DEVICE;
+    }
     HIP_OK(hipStreamSynchronize(stream));
     if (b->mem) HIP_OK(hipFree(b->mem));
     b->mem = nullptr; b->bytes = 0;
-    HIP_OK(hipMalloc(&b->mem, need));
+    const hipError_t e = hipMalloc(&b->mem, need);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();  // an allocation failure is not sticky for the caller: later HIP calls on this thread start clean
+      b->mem = nullptr;
+      set_error("hipMalloc of a " + std::to_string(need) + "-byte workspace: " + hipGetErrorString(e));
+      return RM_ERR_DEVICE;
+    }
     b->bytes = need;
   }
   *out = b->mem;
+  return RM_OK;
+}
+// Frees every grow-only buffer of the current device (after the device has drained); rm_release_workspaces.
+int release_workspaces(size_t *freedOut) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  HIP_OK(hipDeviceSynchronize());
+  size_t freed = 0;
+  std::lock_guard<std::mutex> lock(g_wsMu);
+  for (auto it = g_ws.begin(); it != g_ws.end();) {
+    if (it->first.dev == dev) {
+      if (it->second.mem) { HIP_OK(hipFree(it->second.mem)); freed += it->second.bytes; }
+      it = g_ws.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  if (freedOut) *freedOut = freed;
   return RM_OK;
 }
 namespace {
@@ -459,14 +501,21 @@ int bulb_workspace(size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWs
 }
 
 // Carve the wavefront pipeline's records for `cap` hit slots and `nl` lights out of the stream's workspace.
-int wavefront_workspace(size_t cap, int nl, hipStream_t stream, WfWs *ws) {
+constexpr int kWfBuffers = 13;
+size_t wavefront_sizes(size_t cap, int nl, size_t sizes[kWfBuffers]) {
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
   const size_t nlq = (size_t)(nl > 0 ? nl : 1);
-  const size_t sizes[] = {align(WF_STRIDE * (kWfMaxBounces + 2) * 4), align(cap * 16), align(cap * 16), align(cap * 16), align(cap * 16),
-                          align(cap * 16), align(cap * 16), align(cap * 16), align(cap * nlq * 4), align(cap * 8), align(cap * 16),
-                          align(cap * 16), align(cap * 8)};
+  const size_t sz[kWfBuffers] = {align(WF_STRIDE * (kWfMaxBounces + 2) * 4), align(cap * 16), align(cap * 16), align(cap * 16), align(cap * 16),
+                                 align(cap * 16), align(cap * 16), align(cap * 16), align(cap * nlq * 4), align(cap * 8), align(cap * 16),
+                                 align(cap * 16), align(cap * 8)};
   size_t total = 0;
-  for (size_t b : sizes) total += b;
+  for (int i = 0; i < kWfBuffers; i++) { sizes[i] = sz[i]; total += sz[i]; }
+  return total;
+}
+size_t wavefront_bytes(size_t cap, int nl) { size_t sizes[kWfBuffers]; return wavefront_sizes(cap, nl, sizes); }
+int wavefront_workspace(size_t cap, int nl, hipStream_t stream, WfWs *ws) {
+  size_t sizes[kWfBuffers];
+  const size_t total = wavefront_sizes(cap, nl, sizes);
   void *mem = nullptr;
   if (int st = stream_workspace(kWsWavefront, stream, total, &mem)) return st;
   char *q = static_cast<char *>(mem);
@@ -842,7 +891,8 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
   const int pathReq = g_kernelPath.load() ? g_kernelPath.load() : envPath;  // 0 = the measured-fastest schedule of the scene's class
   int path = pathReq;
-  if (path == 0 || path == 5) path = kAutoBulbPath;
+  if (path == 0) path = kAutoBulbPath;
+  if (path == 5) path = 1;  // the wavefront pipeline does not cover the bulb class: a request that does not apply runs path 1
   const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND | RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) != 0;
   // anything that reads a sampler or takes the area-light branches: object textures, sky box, emissive rectangles, area lights
   bool textured = s->enableSkyBox != 0;
@@ -861,10 +911,50 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     anyReflective = anyReflective || nonzero3(objs[i].cReflective);
   }
   const int wfBounces = (s->enableReflection && anyReflective) ? s->numReflection : 0;
-  // 32-bit ray ids: (hit slots) x lights must stay below 2^32 (a 16K frame with ten lights still does)
-  if ((double)((size_t)nRows * W + (size_t)(1u << 22)) * (numLights > 0 ? numLights : 1) >= 4.0e9) wfOk = false;
   const bool wfSkip = skip_applies(objs, numObjects);
-  const bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W)));
+  bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W)));
+  // The wavefront pipeline's knobs and records, settled BEFORE anything below depends on `wavefront`: if its workspace
+  // (≈(160 + 4·numLights) B per hit slot, grow-only per (device, stream): 5.8 GB for an 8K frame) cannot be had, the
+  // auto-selected launch falls back to render_kernel — identical bits, no workspace — and only an explicit path-5 request
+  // reports the failure.  A (device, stream) that was refused once is not asked again for as much or more, so a frame
+  // sequence does not pay a failing allocation (and the stream synchronisation in front of it) per frame.
+  // Tuning knobs for A/B runs (defaults are the measured best); chunk sizes are clamped so that slot and ray ids stay 32-bit.
+  auto envInt = [](const char *name) { const char *e = std::getenv(name); return e ? std::atoi(e) : 0; };
+  static const int wavesPerSimd = envInt("RM_WF_WAVES_PER_SIMD"), envFlush = envInt("RM_WF_FLUSH"), envSlotChunk = envInt("RM_WF_SLOT_CHUNK"),
+                   envRayChunk = envInt("RM_WF_RAY_CHUNK"), envPixelChunk = envInt("RM_WF_PIXEL_CHUNK"), envMaxChunk = envInt("RM_WF_MAX_CHUNK");
+  constexpr int kWfChunkMax = 4096;
+  auto clampChunk = [](int v) { return (uint32_t)(v > kWfChunkMax ? kWfChunkMax : v); };
+  const uint32_t slotChunk = envSlotChunk >= 64 ? clampChunk(envSlotChunk) : kWfSlotChunk;  // >= 64: one trip's hits fit one fresh chunk
+  const uint32_t maxChunk = envMaxChunk > 0 ? clampChunk(envMaxChunk) : 0u;  // 0: fixed chunks (guided chunks measured slower)
+  const uint32_t rayChunk = envRayChunk > 0 ? clampChunk(envRayChunk) : wfRayChunk(1), pixelChunk = envPixelChunk > 0 ? clampChunk(envPixelChunk) : wfRayChunk(0);
+  WfWs wfWs{};
+  int wfPrimaryWaves = 0, wfShadowWaves = 0;
+  if (wavefront) {
+    if (ds.numCUs == 0) {
+      hipDeviceProp_t prop;
+      HIP_OK(hipGetDeviceProperties(&prop, dev));
+      ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // persistent waves: as many as are resident at once (4 SIMDs per CU x the kernel's register budget)
+    auto waves = [&](int kind) { return ds.numCUs * 4 * (wavesPerSimd > 0 && wavesPerSimd < wfMarchWaves(kind) ? wavesPerSimd : wfMarchWaves(kind)); };
+    wfPrimaryWaves = waves(0); wfShadowWaves = waves(2);
+    const int marchWaves = wfShadowWaves > wfPrimaryWaves ? wfShadowWaves : wfPrimaryWaves;
+    // hit-slot capacity: every ray may hit, plus one partly used chunk of slots per persistent wave
+    const size_t cap = (size_t)nRows * W + (size_t)slotChunk * marchWaves;
+    // 32-bit ids: hit slots x lights (shadow rays) and the striped cursors' padding (one chunk per stripe) stay below 2^32
+    const size_t chunkMax = rayChunk > pixelChunk ? rayChunk : pixelChunk;
+    const bool idsFit = (double)(cap + (size_t)kWfStripes * chunkMax) * (numLights > 0 ? numLights : 1) < 4.0e9;
+    int wst = RM_ERR_DEVICE;
+    auto denied = ds.wfDenied.find(stream);
+    const size_t wfBytes = wavefront_bytes(cap, numLights);
+    if (!idsFit) set_error("frame too large for the wavefront pipeline's 32-bit ray ids");
+    else if (denied != ds.wfDenied.end() && wfBytes >= denied->second) set_error("wavefront workspace was refused on this stream before");
+    else if ((wst = wavefront_workspace(cap, numLights, stream, &wfWs)) != RM_OK) ds.wfDenied[stream] = wfBytes;
+    if (wst != RM_OK) {
+      if (pathReq == 5 && idsFit) return wst;  // an explicit request reports the workspace failure; a frame the ids cannot cover "does not apply"
+      wavefront = false;
+    }
+  }
   // Waves (8×8 tiles, side by side) per workgroup.  A workgroup's registers and LDS come free only when its LAST wave
   // ends, and march lengths differ a lot between neighbouring tiles, so small workgroups keep more waves resident: one wave
   // per workgroup for every class (measured at the register budgets above: the 4K bulb frame 2.31 / 2.34 / 2.58 ms at
@@ -975,31 +1065,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     }
     if ((st = stamp(4)) != RM_OK) return st;
   } else if (wavefront) {
-    if (ds.numCUs == 0) {
-      hipDeviceProp_t prop;
-      HIP_OK(hipGetDeviceProperties(&prop, dev));
-      ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    // tuning knobs for A/B runs (defaults are the measured best)
-    static const int wavesPerSimd = std::getenv("RM_WF_WAVES_PER_SIMD") ? std::atoi(std::getenv("RM_WF_WAVES_PER_SIMD")) : 0;
-    static const int flushThr = std::getenv("RM_WF_FLUSH") ? std::atoi(std::getenv("RM_WF_FLUSH")) : 16;
-    // persistent waves: as many as are resident at once (4 SIMDs per CU x the kernel's register budget)
-    auto waves = [&](int kind) { return ds.numCUs * 4 * (wavesPerSimd > 0 && wavesPerSimd < wfMarchWaves(kind) ? wavesPerSimd : wfMarchWaves(kind)); };
-    const int marchWaves = waves(2) > waves(0) ? waves(2) : waves(0);
-    static const int envSlotChunk = std::getenv("RM_WF_SLOT_CHUNK") ? std::atoi(std::getenv("RM_WF_SLOT_CHUNK")) : 0;
-    static const int envRayChunk = std::getenv("RM_WF_RAY_CHUNK") ? std::atoi(std::getenv("RM_WF_RAY_CHUNK")) : 0;
-    static const int envPixelChunk = std::getenv("RM_WF_PIXEL_CHUNK") ? std::atoi(std::getenv("RM_WF_PIXEL_CHUNK")) : 0;
-    const uint32_t slotChunk = envSlotChunk >= 64 ? (uint32_t)envSlotChunk : kWfSlotChunk;  // >= 64: one trip's hits fit one fresh chunk
-    static const int envMaxChunk = std::getenv("RM_WF_MAX_CHUNK") ? std::atoi(std::getenv("RM_WF_MAX_CHUNK")) : 0;
-    const uint32_t maxChunk = envMaxChunk > 0 ? (uint32_t)envMaxChunk : 0u;  // 0: fixed chunks (guided chunks measured slower)
-    const uint32_t rayChunk = envRayChunk > 0 ? (uint32_t)envRayChunk : wfRayChunk(1), pixelChunk = envPixelChunk > 0 ? (uint32_t)envPixelChunk : wfRayChunk(0);
-    // hit-slot capacity: every ray may hit, plus one partly used chunk of slots per persistent wave
-    const size_t cap = (size_t)nRows * W + (size_t)slotChunk * marchWaves;
-    WfWs ws;
-    if ((st = wavefront_workspace(cap, numLights, stream, &ws)) != RM_OK) return st;
+    const WfWs &ws = wfWs;
     HIP_OK(hipMemsetAsync(ws.counters, 0, WF_STRIDE * (kWfMaxBounces + 2) * sizeof(uint32_t), stream));
-    const dim3 pgrid(waves(0)), mgrid(waves(2)), mblock(64), dense(ds.numCUs * 16);
-    const int thr = flushThr > 0 && flushThr <= 64 ? flushThr : 16;
+    const dim3 pgrid(wfPrimaryWaves), mgrid(wfShadowWaves), mblock(64), dense(ds.numCUs * 16);
+    const int thr = envFlush > 0 && envFlush <= 64 ? envFlush : 16;
     if ((st = stamp(0)) != RM_OK) return st;
     for (int gen = 0; gen <= wfBounces; gen++) {
       if (wfSkip) {
@@ -1379,6 +1448,25 @@ int rm_debug_last_path(void) {
 int rm_set_kernel_path(int path) {
   if (path < 0 || path > 5) { set_error("kernel path must be 0..5"); return RM_ERR_INVALID_ARGUMENT; }
   g_kernelPath.store(path);
+  return RM_OK;
+}
+int rm_set_workspace_limit(unsigned long long bytes) {
+  g_wsLimit.store(bytes == ~0ull ? ~0ull - 1 : bytes);
+  for (DeviceState &ds : g_dev) {  // what was refused under the old limit may be asked for again
+    std::lock_guard<std::mutex> lock(ds.mu);
+    ds.wfDenied.clear();
+  }
+  return RM_OK;
+}
+int rm_release_workspaces(unsigned long long *freedBytes) {
+  DeviceState *ds;
+  if (int st = current_device_state(&ds)) return st;
+  std::lock_guard<std::mutex> lock(ds->mu);  // no launch is being enqueued on this device meanwhile
+  size_t freed = 0;
+  if (int st = release_workspaces(&freed)) return st;
+  ds->tileOrder.clear();  // the feedback costs lived in the buffers just freed
+  ds->wfDenied.clear();
+  if (freedBytes) *freedBytes = freed;
   return RM_OK;
 }
 

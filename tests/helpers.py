@@ -271,3 +271,72 @@ def oracle_post(frag, bright, post):
     st = oracle().rmo_post_process(fptr(frag), fptr(b) if b is not None else None, fptr(out), W, H, C.byref(post))
     assert st == 0, f"oracle post status {st}"
     return out
+
+
+# ------------------------------------------------------------------ wide random tables for the table walk's exact shortcuts
+PRIMITIVES = [abi.RM_CUBE, abi.RM_CONE, abi.RM_CYLINDER, abi.RM_SPHERE, abi.RM_OCTAHEDRON, abi.RM_TORUS, abi.RM_CAPSULE,
+              abi.RM_DEATHSTAR, abi.RM_RECTANGLE]
+
+
+def rotation(axis, angle):
+    """Rotation by `angle` about an arbitrary axis (Rodrigues), 4×4."""
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    M = np.eye(4)
+    M[:3, :3] = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    return M
+
+
+def random_tablewalk_objects(rng, max_objects=30, materials=True):
+    """A random all-primitive table drawn WIDE — what the pass-over test, the runner-up tracking and the ball ∩ box culls of the
+    table walk (rm_device.hip.h sdSceneImpl / march, rm_kernels.hip scene_cull_ball) must survive without changing a bit:
+    arbitrary-axis rotations, shear, anisotropy 0.2–5, a scaleFactor that is deliberately NOT the smallest scale (the ABI accepts
+    any: the distance values are then not 1-Lipschitz, which the launcher's `lip` must account for), objects inside objects,
+    coincident copies (ties: the lower index wins), tables of up to 30.  Returns a list of RmObject."""
+    f = rng.uniform
+    n = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 20, 25, max_objects]))
+    n = min(n, max_objects)
+    spread = 2.2 if n <= 8 else 4.0
+    objs, models = [], []
+
+    def material():
+        if not materials:
+            return {}
+        return dict(ambient=tuple(f(0, .3, 3)), diffuse=tuple(f(.2, 1, 3)), specular=tuple(f(0, 1, 3)),
+                    shininess=float(rng.choice([0, 1, 7.5, 25, 100])), reflective=tuple(f(0, .8, 3)) if f() < 0.4 else (0, 0, 0),
+                    transparent=tuple(f(0, .8, 3)) if f() < 0.3 else (0, 0, 0), ior=float(f(1.05, 1.6)))
+
+    while len(objs) < n:
+        ty = int(rng.choice(PRIMITIVES))
+        kind = f()
+        if objs and kind < 0.12:      # a coincident copy of an earlier object (same shape or another one, other material)
+            M, sc = models[int(rng.integers(0, len(models)))]
+            if f() < 0.5:
+                ty = objs[-1].type
+        elif objs and kind < 0.27:    # nested: inside an earlier object, smaller, same centre or slightly off
+            P, psc = models[int(rng.integers(0, len(models)))]
+            k = float(f(0.2, 0.7))
+            M = P @ translate(*(f(-0.1, 0.1, 3))) @ rotation(rng.normal(size=3), f(-3, 3)) @ scale(k, k, k)
+            sc = psc * k
+        else:
+            base = float(f(0.5, 1.8)) if n <= 8 else float(f(0.4, 1.0))
+            an = np.ones(3) if f() < 0.4 else np.exp(f(np.log(0.2), np.log(5.0), 3)) ** 0.5  # pairwise ratio up to 5 (25 at the extremes)
+            if f() < 0.15:
+                an = np.exp(f(np.log(0.2), np.log(5.0), 3))
+            sx, sy, sz = base * an
+            S = scale(sx, sy, sz)
+            sh = np.eye(4)
+            if f() < 0.3:             # shear
+                i, j = rng.choice(3, 2, replace=False)
+                sh[i, j] = float(f(-0.8, 0.8))
+                if f() < 0.3:
+                    sh[j, (i + 1) % 3 if (i + 1) % 3 != j else (i + 2) % 3] = float(f(-0.5, 0.5))
+            M = translate(f(-spread, spread), f(-1.0, 1.4), f(-2.8, 1.0)) @ rotation(rng.normal(size=3), f(-3.2, 3.2)) @ sh @ S
+            sc = min(sx, sy, sz)
+        sf = sc
+        if f() < 0.25:                # a scaleFactor the loader would not have produced
+            sf = sc * float(rng.choice([0.3, 0.5, 0.8, 1.3, 2.0, 3.0]))
+        objs.append(make_object(ty, model=M, scale_factor=float(sf), **material()))
+        models.append((M, sc))
+    return objs

@@ -129,3 +129,28 @@ def test_distance_values_are_lipschitz_and_bounded_below_by_the_object_ball():
         assert (distances(o, 1, g, pts) >= lb * (1 - 1e-5) - 1e-6).all(), f"type {ty}"
     o = (abi.RmObject * 2)(h.make_object(abi.RM_SPHERE), h.make_object(abi.RM_MANDELBULB))
     assert bounds(o, 2, g)["lip"] == np.inf  # a fractal in the table: no seed
+
+
+def test_bounds_hold_on_wide_random_tables():
+    """The same two properties on tables drawn WIDE (helpers.random_tablewalk_objects: arbitrary-axis rotations, shear,
+    anisotropy up to 25, scaleFactors that are not the smallest scale, nested and coincident objects, up to 30 objects) — the
+    distribution of the GPU soak test test_random_tablewalk_scenes_bit_exact: nothing outside ball ∩ box comes within the hit
+    threshold, and sdScene changes by at most `lip` per unit of world length (lip is then NOT 1)."""
+    rng = np.random.default_rng(20261011)
+    g = h.make_globals()
+    lips = []
+    for i in range(80):
+        lst = h.random_tablewalk_objects(rng, materials=False)
+        objs, n = (abi.RmObject * len(lst))(*lst), len(lst)
+        b = bounds(objs, n, g)
+        assert b["ok"] and np.isfinite(b["lip"]) and b["lip"] > 0
+        lips.append(b["lip"])
+        d = distances(objs, n, g, outside_points(rng, b, 3000))
+        assert np.isfinite(d).all() and d.min() > 0.0039, f"table {i}: a distance value {d.min()} outside the bounds"
+        p = rng.uniform(-7, 7, (8000, 3))
+        step = rng.normal(size=(8000, 3)) * (10.0 ** rng.uniform(-3, 0.5, (8000, 1)))
+        a, c = distances(objs, n, g, p), distances(objs, n, g, p + step)
+        dist = np.linalg.norm((p + step).astype(np.float32).astype(np.float64) - p.astype(np.float32).astype(np.float64), axis=1)
+        excess = np.abs(c.astype(np.float64) - a) - (b["lip"] * dist * 1.0001 + 2e-5 * max(1.0, b["lip"]))
+        assert (excess <= 0).all(), f"table {i}: sdScene is not {b['lip']}-Lipschitz (excess {excess.max():.3e})"
+    assert max(lips) > 1.5 and min(lips) < 1.01  # both regimes were drawn

@@ -1172,6 +1172,89 @@ def test_random_primitive_scenes_bit_exact(renderer):
                 lib().rm_set_kernel_path(0)
 
 
+def _random_tablewalk_case(rng, W, H):
+    """A WIDE random all-primitive scene (helpers.random_tablewalk_objects: arbitrary-axis rotations, shear, anisotropy 0.2–5,
+    scaleFactors that are not the smallest scale, nested and coincident objects, tables of up to 30), sometimes over a floor slab
+    or inside an enclosing box, one to ten lights of the three plain kinds, every shading option, cameras outside, inside an
+    object, or on an object's surface."""
+    f = rng.uniform
+    objs = h.random_tablewalk_objects(rng, max_objects=28)
+    if f() < 0.4:  # a floor: long grazing shadow rays
+        objs.append(h.make_object(abi.RM_CUBE, model=h.translate(0, -1.8, -1) @ h.scale(11, 0.2, 11), scale_factor=0.2,
+                                  diffuse=(.7, .7, .7), ambient=(.1, .1, .1), reflective=(.3, .3, .3) if f() < 0.3 else (0, 0, 0)))
+    if f() < 0.15:  # everything (camera too) inside one big cube: every ray hits, negative distances never occur but no ray leaves
+        objs.append(h.make_object(abi.RM_CUBE, model=h.scale(24, 24, 24), scale_factor=24, diffuse=(.4, .5, .4), ambient=(.1, .1, .1)))
+    lights = []
+    for _ in range(int(rng.choice([1, 2, 2, 3, 3, 3, 4, 5, 7, 10]))):
+        kind = int(rng.integers(0, 3))
+        col = tuple(f(.2, 1.2, 3))
+        if kind == abi.RM_LIGHT_DIRECTIONAL:
+            lights.append(h.make_light(kind, col, direction=(f(-1, 1), f(-1, 0.6), f(-1, 1))))
+        elif kind == abi.RM_LIGHT_POINT:
+            lights.append(h.make_light(kind, col, pos=(f(-4, 4), f(-1, 5), f(-3, 5)), func=(f(.5, 1), f(0, .1), f(0, .02))))
+        else:
+            lights.append(h.make_light(kind, col, direction=(f(-.3, .3), -1, f(-.6, 0)), pos=(f(-2, 2), f(3, 5), f(0, 3)),
+                                       func=(f(.5, 1), f(0, .1), 0), angle=float(f(.4, .9)), penumbra=float(f(.05, .3))))
+    feats = int(rng.choice([abi.RM_FEAT_WHITE_BACKGROUND, abi.RM_FEAT_DARK_BACKGROUND, 0]))
+    if f() < 0.5:
+        feats |= abi.RM_FEAT_PERLIN_BUMP
+    s = abi.default_settings(features=feats, enableSoftShadow=int(f() < 0.5), enableAmbientOcclusion=int(f() < 0.4),
+                             enableReflection=int(f() < 0.4), enableRefraction=int(f() < 0.3),
+                             maxSteps=int(rng.choice([16, 64, 256, 256])), numReflection=int(rng.choice([1, 2, 3])))
+    g = h.make_globals(ka=f(.2, .8), kd=f(.3, 1), ks=f(.2, 1), kt=f(.2, 1))
+    where = f()
+    if where < 0.2:  # the camera inside an object (its near plane, where rays start, may still be outside a small one)
+        o = objs[int(rng.integers(0, len(objs)))]
+        M = np.linalg.inv(np.array(list(o.invModel), dtype=np.float64).reshape(4, 4).T)
+        pos = tuple((M @ np.array([*f(-0.15, 0.15, 3), 1.0]))[:3])
+        look = tuple(f(-1, 1, 3) + np.array([0, 0, -0.3]))
+    elif where < 0.3:  # on (about) the bounding ball of an object, looking along it
+        o = objs[int(rng.integers(0, len(objs)))]
+        M = np.linalg.inv(np.array(list(o.invModel), dtype=np.float64).reshape(4, 4).T)
+        d = rng.normal(size=3)
+        pos = tuple((M @ np.array([*(d / np.linalg.norm(d) * 0.6), 1.0]))[:3])
+        look = tuple(np.cross(d, rng.normal(size=3)))
+    else:
+        pos, look = (f(-1, 1), f(0.5, 2.5), f(4.5, 6.5)), (f(-.15, .15), f(-.45, -.05), -1)
+    if np.linalg.norm(look) < 1e-3 or abs(np.dot(look, (0, 1, 0))) > 0.98 * np.linalg.norm(look):
+        look = (0.1, -0.2, -1)
+    cam = h.make_camera(pos, look, (0, 1, 0), float(f(35, 70)), W, H)
+    return (cam, (abi.RmObject * len(objs))(*objs), len(objs), (abi.RmLight * len(lights))(*lights), len(lights), g), s
+
+
+def test_random_tablewalk_scenes_bit_exact(renderer):
+    """The exactness evidence of the table walk's shortcuts — pass-over test, runner-up tracking / single-object fast path, ball ∩
+    box march bounds (rm_device.hip.h sdSceneImpl / march; their slack constants 1.00003, 1e-4, nextMinBound) — on scenes drawn
+    WIDE: 128 seeded cases by default; RM_FUZZ_CASES=1000 with three RM_FUZZ_SEEDs is the soak
+    (scripts/gpu_fuzz_soak.sh, summary in profiles/).  Every bit of fragColor and BrightColor equals the oracle's; every
+    fourth refraction-free scene also runs through the wavefront pipeline's instantiations of the same tests."""
+    from raymarcher_amd import lib
+    W, H = 56, 40
+    seed = int(os.environ.get("RM_FUZZ_SEED", "20261012"))
+    rng = np.random.default_rng(seed)
+    cases = int(os.environ.get("RM_FUZZ_CASES", "128"))
+    stats = {"objects": 0, "max_objects": 0, "wavefront": 0}
+    for i in range(cases):
+        scene, s = _random_tablewalk_case(rng, W, H)
+        ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+        out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+        assert_bit_equal(out.cpu().numpy(), ref, f"seed {seed} wide table-walk scene {i} ({scene[2]} objects)")
+        assert_bit_equal(br.cpu().numpy(), ref_b, f"seed {seed} wide table-walk scene {i} bright")
+        stats["objects"] += scene[2]
+        stats["max_objects"] = max(stats["max_objects"], scene[2])
+        if not s.enableRefraction and i % 4 == 0:
+            try:
+                lib().rm_set_kernel_path(5)
+                wf = renderer.render(tables_of(scene), s, W, H)
+                assert lib().rm_debug_last_path() == 5 and _ieq(wf, out), f"seed {seed} scene {i}: wavefront differs"
+                stats["wavefront"] += 1
+            finally:
+                lib().rm_set_kernel_path(0)
+    print(f"FUZZ_SUMMARY seed={seed} cases={cases} mismatched_words=0 mean_objects={stats['objects'] / max(cases, 1):.1f} "
+          f"max_objects={stats['max_objects']} wavefront_cases={stats['wavefront']}")
+    assert stats["max_objects"] >= 20 or cases < 32
+
+
 def _random_bulb_case(rng, W, H):
     """A random scene of the single-Mandelbulb class (its own kernel instantiation: bounding-ball culls of two radii,
     v_min orbit trap, per-lane shadow-ray queue): model transform incl. anisotropic scales and tiny objects, Julia seeds

@@ -184,3 +184,42 @@ def test_wavefront_config5_bands_8k(renderer):
     for r0 in (1000, 2164):
         ref = h.oracle_render(tg._scene_tuple(t), s, W, H, r0, r0 + 4, threads=16)
         tg.assert_bit_equal(wf[r0:r0 + 4].cpu().numpy(), ref, f"8K rows {r0}..{r0 + 4}")
+
+
+def test_wavefront_workspace_refused_falls_back_to_the_pixel_kernel(renderer):
+    """The auto-selected pipeline needs ≈175 B of grow-only scratch per pixel (per device and stream).  When that buffer may
+    not be had — rm_set_workspace_limit here; a failing hipMalloc takes the same branch — a launch that chose the pipeline by
+    itself renders with rm::render_kernel instead (identical bits, no workspace); only an explicit rm_set_kernel_path(5)
+    reports the failure, and HIP's error state stays clean either way (rm_kernels.hip launch_render / stream_workspace)."""
+    import ctypes as C
+    import torch
+    from raymarcher_amd import Scene, lib
+    from raymarcher_amd._lib import RaymarcherError
+    L = lib()
+    W, H = 2560, 1664  # 4.26 M pixels: above the pipeline's 2^22-pixel threshold
+    t = Scene(path=os.path.join(tg.SCENES, "simple", "unit_mengersponge.json")).tables(W, H)
+    s = abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1)
+    need = 150 * W * H  # a lower bound of what the pipeline asks for
+    freed = C.c_ulonglong(0)
+    assert L.rm_release_workspaces(C.byref(freed)) == 0  # whatever earlier tests left on this device
+    try:
+        assert L.rm_set_workspace_limit(64 << 20) == 0
+        capped, ran = render_path(renderer, 0, t, s, W, H)
+        assert ran == 1, "a refused workspace must fall back to the one-lane-per-pixel kernel"
+        again, ran2 = render_path(renderer, 0, t, s, W, H)  # the refusal is remembered: no second attempt, same frame
+        assert ran2 == 1 and tg._ieq(again, capped)
+        with pytest.raises(RaymarcherError):  # an explicit request reports instead of silently switching
+            render_path(renderer, 5, t, s, W, H)
+        torch.cuda.synchronize()  # no sticky HIP error: torch's own calls on this device still succeed
+        small, ran3 = render_path(renderer, 5, t, s, 96, 64)  # a frame whose workspace fits the limit still takes the pipeline
+        assert ran3 == 5
+    finally:
+        assert L.rm_set_workspace_limit(0) == 0
+    wf, ran4 = render_path(renderer, 0, t, s, W, H)  # limit lifted: the refusal is forgotten, the pipeline runs
+    assert ran4 == 5 and tg._ieq(wf, capped)
+    for r0 in (400, 830):
+        ref = h.oracle_render(tg._scene_tuple(t), s, W, H, r0, r0 + 4, threads=16)
+        tg.assert_bit_equal(capped[r0:r0 + 4].cpu().numpy(), ref, f"capped frame rows {r0}..{r0 + 4}")
+    assert L.rm_release_workspaces(C.byref(freed)) == 0 and freed.value >= need
+    after, ran5 = render_path(renderer, 0, t, s, W, H)  # buffers come back on demand
+    assert ran5 == 5 and tg._ieq(after, wf)

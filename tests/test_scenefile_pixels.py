@@ -71,11 +71,12 @@ CASES["sweepfull_reflections_basic_ub1"] = ("edge", 0.998, 0.999)
 # textured floor; simple/unit_plane.json, the third such scene, SwiftShader did not finish compiling)
 CASES["sweep_depth_of_field"] = ("edge", 0.998, 1.0)  # ten objects, one of them textured
 CASES["sweep_shadow_test"] = ("smooth", 1.0, 1.0)      # two images on two objects: texture units 0 and 1
-# simple/unit_plane.json (round 3; 48×27): the area light seen edge-on from most of the floor — 8.4 % of the pixels are 0/0 in
-# binary32 (true value ≈ 1e-5, which the reference on SwiftShader and the arbiter return); every other pixel within 6e-6
-CASES["sweep_unit_plane"] = ("ltc", 0.999, 0.09)
-CASES["sweep_bloom"] = ("ltc", 0.98, 0.0)
-CASES["sweep_arealight"] = ("ltc", 0.88, 0.0)
+# simple/unit_plane.json (round 3; 48×27): the area light seen edge-on from most of the floor — on 8.4 % of the pixels the form
+# factor's direction is 0/0 in binary32 (UB11, DESIGN.md §4: z = 0, the term is 0; the reference on SwiftShader and the arbiter
+# return ≈ 1e-5 there): every pixel within 9e-6 of the reference frame.  ("ltc": every pixel finite and within 1e-3 of the arbiter)
+CASES["sweep_unit_plane"] = ("ltc", 1.0, 1.0)
+CASES["sweep_bloom"] = ("ltc", 0.98, 1.0)
+CASES["sweep_arealight"] = ("ltc", 0.88, 0.98)
 # round 3: the reference's defined refraction scene (four glass spheres, reflection + refraction on), its HDR scene (three
 # textured cubes of seven under three point lights), the five-image scene of textures_tests (one image a GIF) and the sky-box
 # scene (cubemap/beach.json: the reference's JPEG faces through the product's JPEG reader)
@@ -120,22 +121,22 @@ def check(name, frame, z, scene_ref, s, textures, **res):
     if klass == "ltc":
         # The reference uploads the LTC matrices into an 8-bit unorm texture (entries outside [0,1] are clamped), which makes
         # the specular transform singular at grazing angles: the clipped polygon collapses to a segment whose signed areas
-        # cancel EXACTLY in binary32 and the form factor is 0/0.  Those pixels (1-2 %) are NaN in the oracle and on the GPU,
-        # rounding residue elsewhere; they are compared as "NaN on both" by the GPU test and left out here.
-        nan = np.isnan(frame).any(-1)
-        assert nan.mean() <= (min_bytes if min_bytes > 0 else 0.02) and np.isfinite(frame[..., 3]).all()  # "ltc": third field = NaN allowance
+        # cancel EXACTLY in binary32, the form factor's direction is 0/0 (frag:403-409) — UB11 of DESIGN.md §4 gives it z = 0, so
+        # the term is len·scale = 0 (the arbiter and the reference on SwiftShader return ≈1e-5 there).  Every pixel is finite
+        # and within 1e-3 of the arbiter.
+        assert np.isfinite(frame).all(), f"{name}: {np.isnan(frame).any(-1).sum()} non-finite pixels"
         f64 = h.arbiter_render(scene_ref, s, W, H, textures=textures, **res)
         d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
-        assert (d32[~nan] <= 1e-3).all(), f"{name}: the oracle is not within 1e-3 of the arbiter ({np.nanmax(d32):.2e})"
+        assert (d32 <= 1e-3).all(), f"{name}: the oracle is not within 1e-3 of the arbiter ({d32.max():.2e})"
         # SwiftShader blends the LTC texels with 8-bit weights: it is the one that is off
         d = np.abs(frame - ref).max(-1)
-        assert (d[~nan] <= 1e-3).mean() >= min_close and (d[~nan] <= 1e-2).mean() >= 0.99
-        assert (d32[~nan] <= dss[~nan] + 1e-3).all()
+        assert (d <= 1e-3).mean() >= min_close and (d <= 1e-2).mean() >= 0.99
+        assert (d32 <= dss + 1e-3).all()
         assert (frame[..., 3] == ref[..., 3]).all()
-        return (np.clip(np.nan_to_num(frame[::-1]), 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
-    if klass == "chaotic":  # NaN where the escape-time "distance" is 0·inf (80 pixels; SwiftShader's min/max drop them)
-        assert np.isfinite(frame[..., 3]).all()
-        frame = np.nan_to_num(frame, nan=0.0)
+        png = (np.clip(frame[::-1], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+        lv = np.abs(png.astype(int) - z["png8"].astype(int)).max(-1)
+        assert (lv <= 1).mean() >= min_bytes, f"{name}: {(lv > 1).sum()} px more than one 8-bit level off"
+        return png
     d = np.abs(frame - ref).max(-1)
     assert np.isfinite(frame).all()
     assert (d <= 1e-3).mean() >= min_close, f"{name}: {(d > 1e-3).sum()} of {d.size} px beyond 1e-3 of the reference frame (max {d.max():.2e})"
@@ -144,7 +145,8 @@ def check(name, frame, z, scene_ref, s, textures, **res):
     lv = np.abs(png.astype(int) - z["png8"].astype(int)).max(-1)
     assert (lv <= 1).mean() >= min_bytes, f"{name}: {(lv > 1).sum()} px more than one 8-bit level off"
     if klass not in ("smooth", "env"):
-        f64 = np.nan_to_num(h.arbiter_render(scene_ref, s, W, H, textures=textures, **res), nan=0.0)
+        f64 = h.arbiter_render(scene_ref, s, W, H, textures=textures, **res)
+        assert np.isfinite(f64).all()
         d32, dss = np.abs(frame - f64).max(-1), np.abs(ref - f64).max(-1)
         if klass == "chaotic":  # as close to the arbiter as SwiftShader is, and the same picture on average
             assert (d32 <= 1e-3).mean() >= (dss <= 1e-3).mean() - 0.03
@@ -185,8 +187,7 @@ def test_scenefile_to_pixels_on_the_gpu(renderer, name):
     dev = renderer.render(t, s, W, H)
     frame = dev.cpu().numpy()
     png = check(name, frame, z, scene_ref, s, t.textures, **resources(t))
-    if not np.isnan(frame).any():
-        assert (renderer.to_rgba8(dev).cpu().numpy() == png).all()  # the kernel's 8-bit conversion = clamp, ×255, round, flip
+    assert (renderer.to_rgba8(dev).cpu().numpy() == png).all()  # the kernel's 8-bit conversion = clamp, ×255, round, flip
     ref = h.oracle_render((t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_), s, W, H, textures=t.textures,
                           **resources(t))
-    assert ((frame.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(frame) & np.isnan(ref))).all()  # NaN payloads: "both NaN"
+    assert (frame.view(np.uint32) == ref.view(np.uint32)).all()
