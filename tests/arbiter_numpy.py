@@ -1,0 +1,236 @@
+"""An INDEPENDENT arbiter for the headline pixel: the whole C3 fragment — vertex varyings, setScene, raymarch, sdScene with one
+Mandelbulb, getNormal, pnoise / bumpNormal, softshadow, getPhong with directional lights, the orbit-trap colouring of render and
+main's composite — written again from the SHADER TEXT (resources/raymarch.vert, resources/raymarch.frag of the reference;
+`frag:N` below) in vectorised NumPy float64.
+
+Why it exists (missing #2): the binary64 arbiter of oracle/rm_oracle_f64.c is the oracle's own C source compiled with
+`#define float double` — a formula transcribed wrongly into rm_oracle.c would be wrong in both and pass.  This file shares no
+source with the oracle: its own control flow (whole frames of rays advance together, finished rays drop out of the index set),
+NumPy's arccos / arctan2 / sin / cos / power / log / sqrt, no rm_math contract.  It is test infrastructure only.
+
+One sub-expression is evaluated in binary32 ON PURPOSE, as in the C arbiter: the hash → lattice-gradient map
+of the classic Perlin noise (frag:1626-1644).  Its selector gz = 0.5 − |gx| − |gy| is an EXACT tie in real arithmetic for 7 of
+the 49 hash classes, so which of two unrelated gradients `step(gz, 0)` picks is DEFINED by binary32 rounding in the shader (every
+binary32 implementation with IEEE division agrees; a binary64 evaluation of that line picks other gradients for no meaningful
+reason).  Those lines run on np.float32 arrays with NumPy's IEEE operations; everything around them is float64.
+
+Scope: exactly what a frame of scenefiles/simple/unit_mandelbulb.json executes with the reference's default settings
+(WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, reflection, refraction, sky box off): one MANDELBULB object, DIRECTIONAL
+lights.  Anything else raises."""
+import numpy as np
+
+SURFACE_DIST = 1e-3          # frag:32
+FRACTALS_BAILOUT = 2.0       # frag:30
+BUMP_SCALE, BUMP_INTENSITY = 10.0, 2.0  # frag:128-129
+RM_MANDELBULB, RM_LIGHT_DIRECTIONAL = 10, 1  # scenedata.h:18-33 / 10-15 ≡ frag:53-75
+RM_FEAT_PERLIN_BUMP, RM_FEAT_WHITE_BACKGROUND = 128, 8  # include/raymarcher_amd.h: the shader's #defines as feature bits
+
+
+def _dot(a, b):
+    return (a * b).sum(-1)
+
+
+def _normalize(v):
+    return v / np.sqrt(_dot(v, v))[..., None]
+
+
+def _mix(a, b, t):
+    return a * (1.0 - t) + b * t
+
+
+# ---------------------------------------------------------------------------------------------- frag:775-803
+def sd_mandelbulb(pos, power, iters, julia=(0.0, 0.0)):
+    """sdMandelBulb: returns (distance estimate, resColor = (m, trap.y, trap.z, trap.w)).  A point that has bailed out stops
+    updating (the shader's `break`)."""
+    w = np.array(pos, dtype=np.float64)
+    c = w.copy()
+    if np.hypot(*julia) != 0.0:  # frag:782-784
+        c = np.broadcast_to(np.array([julia[0], julia[1], 0.0]), w.shape).copy()
+    m = _dot(w, w)
+    trap = np.concatenate([np.abs(w), m[:, None]], -1)
+    dz = np.ones(len(w))
+    live = np.ones(len(w), dtype=bool)
+    with np.errstate(all="ignore"):
+        for _ in range(iters):
+            dz_n = power * np.power(m, (power - 1.0) / 2.0) * dz + 1.0
+            r = np.sqrt(_dot(w, w))
+            b = power * np.arccos(w[:, 1] / r)
+            a = power * np.arctan2(w[:, 0], w[:, 2])
+            w_n = c + np.power(r, power)[:, None] * np.stack([np.sin(b) * np.sin(a), np.cos(b), np.sin(b) * np.cos(a)], -1)
+            trap_n = np.minimum(trap, np.concatenate([np.abs(w_n), m[:, None]], -1))
+            m_n = _dot(w_n, w_n)
+            dz = np.where(live, dz_n, dz)
+            w = np.where(live[:, None], w_n, w)
+            trap = np.where(live[:, None], trap_n, trap)
+            m = np.where(live, m_n, m)
+            live = live & ~(m > FRACTALS_BAILOUT)
+            if not live.any():
+                break
+        d = 0.25 * np.log(m) * np.sqrt(m) / dz
+    return d, np.concatenate([m[:, None], trap[:, 1:]], -1)
+
+
+# ---------------------------------------------------------------------------------------------- frag:1586-1676
+def _permute(x):  # frag:1602-1604; exact integers below 2^24 in either precision
+    return np.mod((x * 34.0 + 1.0) * x, 289.0)
+
+
+def _lattice_gradients32(ixy):
+    """frag:1626-1634 (and 1636-1644) on np.float32 arrays: the hash → gradient map whose tie-break binary32 defines."""
+    f = np.float32
+    ixy = ixy.astype(f)
+    gx = ixy / f(7.0)
+    t = np.floor(gx) / f(7.0)
+    gy = (t - np.floor(t)) - f(0.5)
+    gx = gx - np.floor(gx)
+    gz = f(0.5) - np.abs(gx) - np.abs(gy)
+    sz = (gz <= f(0.0)).astype(f)                       # step(gz, 0)
+    gx = gx - sz * ((gx >= f(0.0)).astype(f) - f(0.5))  # step(0, gx)
+    gy = gy - sz * ((gy >= f(0.0)).astype(f) - f(0.5))
+    return gx.astype(np.float64), gy.astype(np.float64), gz.astype(np.float64)
+
+
+def pnoise(p):
+    """Classic Perlin noise, 3-D (frag:1610-1676)."""
+    p = np.asarray(p, dtype=np.float64)
+    Pi0 = np.floor(p)
+    Pi1 = np.mod(Pi0 + 1.0, 256.0)
+    Pi0 = np.mod(Pi0, 256.0)
+    Pf0 = p - np.floor(p)
+    Pf1 = Pf0 - 1.0
+    n = {}
+    for cz in (0, 1):
+        iz = (Pi1 if cz else Pi0)[:, 2]
+        for cy in (0, 1):
+            iy = (Pi1 if cy else Pi0)[:, 1]
+            for cx in (0, 1):
+                ix = (Pi1 if cx else Pi0)[:, 0]
+                gx, gy, gz = _lattice_gradients32(_permute(_permute(_permute(ix) + iy) + iz))
+                g = np.stack([gx, gy, gz], -1)
+                g = g * (1.79284291400159 - 0.85373472095314 * _dot(g, g))[:, None]  # taylorInvSqrt, frag:1606-1608
+                off = np.stack([(Pf1 if cx else Pf0)[:, 0], (Pf1 if cy else Pf0)[:, 1], (Pf1 if cz else Pf0)[:, 2]], -1)
+                n[(cx, cy, cz)] = _dot(g, off)
+    t = Pf0
+    fade = t * t * t * (t * (t * 6.0 - 15.0) + 10.0)  # frag:1587-1589
+    nz = {(cx, cy): _mix(n[(cx, cy, 0)], n[(cx, cy, 1)], fade[:, 2]) for cx in (0, 1) for cy in (0, 1)}
+    ny = {cx: _mix(nz[(cx, 0)], nz[(cx, 1)], fade[:, 1]) for cx in (0, 1)}
+    return 2.2 * _mix(ny[0], ny[1], fade[:, 0])
+
+
+def bump_normal(normal, pos, scale=BUMP_SCALE, intensity=BUMP_INTENSITY):  # frag:1679-1691
+    q = pos * scale
+    n0 = pnoise(q)
+    grad = np.stack([pnoise(q + np.array([0.1, 0.0, 0.0])) - n0, pnoise(q + np.array([0.0, 0.1, 0.0])) - n0,
+                     pnoise(q + np.array([0.0, 0.0, 0.1])) - n0], -1)
+    return _normalize(normal + grad * intensity)
+
+
+# ---------------------------------------------------------------------------------------------- the frame
+class Bulb:
+    """What sdScene (frag:1406-1430) does with a table of one Mandelbulb: object-space point, estimate × scaleFactor."""
+
+    def __init__(self, inv_model, scale_factor, power, iters, julia):
+        self.M, self.sf, self.power, self.iters, self.julia = np.asarray(inv_model, np.float64), float(scale_factor), float(power), int(iters), julia
+
+    def __call__(self, p):
+        po = p @ self.M[:3, :3].T + self.M[:3, 3]  # vec3(invModelMatrix · vec4(p, 1)), frag:1417
+        d, res = sd_mandelbulb(po, self.power, self.iters, self.julia)
+        return d * self.sf, res
+
+
+def raymarch(sd, ro, rd, end, max_steps, shadow=False):
+    """frag:1453-1484 (shadow=False, side = +1) and the march of frag:1703-1725 (shadow=True: t += |d|, start at mint = 0).
+    Returns (hit, depth as raymarch reports it: rayDepth − minD, trap of the last evaluation)."""
+    n = len(ro)
+    t = np.zeros(n)
+    d = np.full(n, 1000000.0)
+    trap = np.zeros((n, 4))
+    idx = np.arange(n)
+    for _ in range(max_steps):
+        if len(idx) == 0:
+            break
+        dd, tr = sd(ro[idx] + rd[idx] * t[idx, None])
+        d[idx], trap[idx] = dd, tr
+        stop = (np.abs(dd) < SURFACE_DIST) | (t[idx] > end)
+        go = ~stop
+        t[idx[go]] += np.abs(dd[go]) if shadow else dd[go]
+        idx = idx[go]
+    hit = np.abs(d) < SURFACE_DIST
+    return hit, t - d, trap
+
+
+def get_normal(sd, p):  # frag:1436-1444
+    e = np.array([1.0, -1.0, 0.0]) * 0.5773 * 0.0005
+    x, y = e[0], e[1]
+    taps = [np.array([x, y, y]), np.array([y, y, x]), np.array([y, x, y]), np.array([x, x, x])]  # e.xyy, e.yyx, e.yxy, e.xxx
+    acc = np.zeros_like(p)
+    for k in taps:
+        acc = acc + k * sd(p + k)[0][:, None]
+    return _normalize(acc)
+
+
+def get_phong(sd, N, obj, lights, g, p, rd, far, max_steps):
+    """frag:1842-1933 for an untextured object and DIRECTIONAL lights, soft shadows and ambient occlusion off."""
+    ka, kd, ks = g
+    total = np.broadcast_to(obj["cAmbient"] * ka, p.shape).copy()  # ao = 1
+    V = _normalize(-rd)
+    for li in lights:
+        L = np.broadcast_to(_normalize(-li["dir"]), p.shape)
+        occluded, _, _ = raymarch(sd, p + N * SURFACE_DIST * 5.0, L, far, max_steps, shadow=True)  # frag:1908
+        ndl = _dot(N, L)
+        lit = ~occluded & ~(ndl <= 0.005)  # frag:1909-1912
+        col = (kd * obj["cDiffuse"]) * np.clip(ndl, 0.0, 1.0)[:, None] * li["color"]  # getDiffuse, texLoc == −1: frag:1749-1752
+        R = (-L) - 2.0 * _dot(N, -L)[:, None] * N  # reflect(−L, N)
+        rdv = np.clip(_dot(R, V), 0.0, 1.0)
+        spec = ks * rdv if obj["shininess"] == 0 else ks * np.power(rdv, obj["shininess"])  # frag:1787-1792
+        col = col + spec[:, None] * obj["cSpecular"] * li["color"]
+        total = total + np.where(lit[:, None], col, 0.0)  # fAtt = aFall = 1 for a directional light
+    return total
+
+
+def render_frame(tables, settings, W, H):
+    """fragColor of every pixel, (H, W, 4) float64, row 0 = bottom (gl_FragCoord convention)."""
+    assert tables.num_objects == 1 and tables.objects[0].type == RM_MANDELBULB and tables.objects[0].texLoc == -1
+    assert not (settings.enableSoftShadow or settings.enableAmbientOcclusion or settings.enableReflection or settings.enableRefraction
+                or settings.enableSkyBox) and not tables.globals_.isTwoD
+    o = tables.objects[0]
+    obj = {"cAmbient": np.array(list(o.cAmbient), np.float64), "cDiffuse": np.array(list(o.cDiffuse), np.float64),
+           "cSpecular": np.array(list(o.cSpecular), np.float64), "shininess": float(o.shininess)}
+    assert not o.isEmissive
+    lights = []
+    for i in range(tables.num_lights):
+        li = tables.lights[i]
+        assert li.type == RM_LIGHT_DIRECTIONAL
+        lights.append({"dir": np.array(list(li.dir), np.float64), "color": np.array(list(li.color), np.float64)})
+    gl = tables.globals_
+    sd = Bulb(np.array(list(o.invModel), np.float64).reshape(4, 4).T, o.scaleFactor, gl.power, settings.fractalIters,
+              (gl.juliaSeed[0], gl.juliaSeed[1]))
+    inv_pv = np.array(list(tables.camera.invProjView), np.float64).reshape(4, 4).T  # column-major storage
+    far = float(tables.camera.initialFar)
+    # raymarch.vert:13-25: nearClip / farClip are affine in the quad position, so their interpolated value at a pixel centre
+    # IS the matrix product at that position (in real arithmetic; DESIGN.md §2.3 is about binary32)
+    ys, xs = np.mgrid[0:H, 0:W]
+    ndc = np.stack([(xs.ravel() + 0.5) / W * 2.0 - 1.0, (ys.ravel() + 0.5) / H * 2.0 - 1.0], -1)
+    near = np.concatenate([ndc, np.full((len(ndc), 1), -1.0), np.ones((len(ndc), 1))], -1) @ inv_pv.T
+    farc = np.concatenate([ndc, np.ones((len(ndc), 1)), np.ones((len(ndc), 1))], -1) @ inv_pv.T
+    ro = near[:, :3] / near[:, 3:]                      # setScene, frag:2388-2392
+    rd = _normalize(farc[:, :3] / farc[:, 3:] - ro)
+    assert settings.features & RM_FEAT_WHITE_BACKGROUND
+    bg = np.array([1.0, 1.0, 1.0])                      # WHITE_BACKGROUND, frag:2414-2416
+    out = np.empty((len(ndc), 4))
+    out[:, :3], out[:, 3] = bg, 1.0                     # render's miss: vec4(bgCol, 1), frag:2323-2329
+    hit, depth, trap = raymarch(sd, ro, rd, far, settings.maxSteps)
+    if hit.any():
+        p = ro[hit] + rd[hit] * depth[hit, None]        # frag:2333
+        pn = get_normal(sd, p)
+        if settings.features & RM_FEAT_PERLIN_BUMP:     # #define PERLIN_BUMP (frag:15, 2334-2336)
+            pn = bump_normal(pn, p)
+        tr = trap[hit]
+        col = np.full((len(p), 3), 0.2)                 # frag:2354-2361
+        col = _mix(col, np.array([0.10, 0.20, 0.30]), np.clip(tr[:, 1], 0.0, 1.0)[:, None])
+        col = _mix(col, np.array([0.02, 0.10, 0.30]), np.clip(tr[:, 2] * tr[:, 2], 0.0, 1.0)[:, None])
+        col = _mix(col, np.array([0.30, 0.10, 0.02]), np.clip(np.power(tr[:, 3], 6.0), 0.0, 1.0)[:, None])
+        col = col * 0.5
+        col = col * (get_phong(sd, pn, obj, lights, (gl.ka, gl.kd, gl.ks), p, rd[hit], far, settings.maxSteps) * 8.0)
+        out[hit, :3] = col                              # main: phong + refl + refr with both zero, frag:2478, 2570-2572
+    return out.reshape(H, W, 4), hit.reshape(H, W)

@@ -203,7 +203,7 @@ def test_wavefront_workspace_refused_falls_back_to_the_pixel_kernel(renderer):
     freed = C.c_ulonglong(0)
     assert L.rm_release_workspaces(C.byref(freed)) == 0  # whatever earlier tests left on this device
     try:
-        assert L.rm_set_workspace_limit(64 << 20) == 0
+        assert L.rm_set_workspace_limit(512 << 20) == 0  # the frame needs 1.1 GB; a small frame's 0.36 GB (one slot chunk per persistent wave) fits
         capped, ran = render_path(renderer, 0, t, s, W, H)
         assert ran == 1, "a refused workspace must fall back to the one-lane-per-pixel kernel"
         again, ran2 = render_path(renderer, 0, t, s, W, H)  # the refusal is remembered: no second attempt, same frame

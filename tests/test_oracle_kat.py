@@ -343,30 +343,12 @@ def test_bulb_algebraic_power8_is_the_same_function():
 
 
 # ---------------------------------------------------------------- an INDEPENDENT binary64 evaluation of the Mandelbulb estimator
-def _bulb_de_float64(pos, power, iters, bailout=2.0):
-    """frag:775-803 transcribed from the SHADER TEXT into NumPy float64 — not the oracle's source with wider types: its own
-    vectorised control flow (a point that has bailed out stops updating), NumPy's arccos / arctan2 / sin / cos / power."""
-    w = np.array(pos, dtype=np.float64)
-    c = w.copy()
-    m = (w * w).sum(-1)
-    trap = np.concatenate([np.abs(w), m[:, None]], -1)
-    dz = np.ones(len(w))
-    live = np.ones(len(w), dtype=bool)
-    with np.errstate(all="ignore"):
-        for _ in range(iters):
-            dz_n = power * np.power(m, (power - 1.0) / 2.0) * dz + 1.0
-            r = np.sqrt((w * w).sum(-1))
-            b = power * np.arccos(w[:, 1] / r)
-            a = power * np.arctan2(w[:, 0], w[:, 2])
-            w_n = c + np.power(r, power)[:, None] * np.stack([np.sin(b) * np.sin(a), np.cos(b), np.sin(b) * np.cos(a)], -1)
-            trap_n = np.minimum(trap, np.concatenate([np.abs(w_n), m[:, None]], -1))
-            m_n = (w_n * w_n).sum(-1)
-            dz = np.where(live, dz_n, dz)
-            w = np.where(live[:, None], w_n, w)
-            trap = np.where(live[:, None], trap_n, trap)
-            m = np.where(live, m_n, m)
-            live = live & ~(m > bailout)
-        return 0.25 * np.log(m) * np.sqrt(m) / dz, m, trap[:, 1:]
+def _bulb_de_float64(pos, power, iters):
+    """frag:775-803 transcribed from the SHADER TEXT into NumPy float64 (tests/arbiter_numpy.py, which carries the whole headline
+    pixel the same way): not the oracle's source with wider types."""
+    import arbiter_numpy as an
+    d, res = an.sd_mandelbulb(pos, power, iters)
+    return d, res[:, 0], res[:, 1:]
 
 
 @pytest.mark.parametrize("fixture,iters", [("probe_sd_bulb_p8_12iters.npz", 12), ("probe_sd_bulb_p8.npz", 20)])
