@@ -491,9 +491,6 @@ def main():
         flops_frame, parts, model = flop_model(tables, settings, cnt)
         flops_exec = flop_model(tables, settings, cnt_exec, executed=True)[0] if cnt_exec is not None else None
         kernel_names = {1: "rm::render_kernel<BULB,COUNT=0,ENV,TEX> (one lane per pixel, 8x8 tile per wave)",
-                        2: "pipeline A: bulb_primary+surface+shadow+shade kernels (state machines + lane refill)",
-                        3: "pipeline B: bulbB_primary+surface+shadow+shade kernels (compacted lists, plain loops)",
-                        4: "pipeline C: pipeline B with step-budgeted march passes and re-compaction",
                         5: "wavefront pipeline: per ray generation rm::wf_march_kernel<0|1> (persistent waves, lanes = rays, refilled), "
                            "wf_surface_kernel, wf_march_kernel<2> (shadow rays), wf_light_kernel"}
         # with tile-order feedback a launch is two sort kernels (stage 0, ~0.02 ms) + the render kernel (stage 1): the roofline is

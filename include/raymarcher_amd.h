@@ -325,20 +325,18 @@ int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects,
 int rm_set_timing(int on);
 int rm_get_timing(double *avgKernelMs, int *launches);
 /* Same, split by stage.  One-lane-per-pixel kernel with tile-order feedback active (rm_set_tile_order): stage 0 = the two
- * ordering launches, stage 1 = the render kernel; without it (first frame, small frames, layers / samplers): stage 0 = the
- * render kernel.  Bulb pipelines (kernel paths 2-4): primary march, surface / normals, shadow marches, shading = stages
- * 0..3.  Wavefront pipeline (path 5): stage 0 = all of its kernels. */
+ * ordering launches, stage 1 = the render kernel; without it (first frame, small frames): stage 0 = the render kernel.
+ * Wavefront pipeline (path 5): stage 0 = all of its kernels. */
 int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches);
 /* Which schedule renders a frame: 0 = the measured-fastest one of the scene's class (default), 1 = one lane per pixel
- * (rm::render_kernel).  Single-Mandelbulb class only: 2 = four-kernel pipeline with per-lane state machines and
- * ballot-based lane refill, 3 = four-kernel pipeline with plain loops on compacted hit / shadow-ray lists, 4 = as 3 with
- * the march stages cut into step-budgeted passes (survivors re-compacted between launches).  Table-walk classes
- * (primitives, Menger sponge, Sierpinski; no samplers, procedural layers, refraction, Mandelbulb or 2-D Mandelbrot in the
- * scene): 5 = the wavefront pipeline of rm_wavefront.hip.h — per generation of rays (primary, then each reflection
- * bounce of frag:2491-2524) a persistent march kernel whose lanes are rays refilled from a queue as they end, a dense
- * surface kernel, the same march kernel over the shadow rays, a dense light / bounce kernel.  A request that does not
- * apply to the scene (2-4 outside the bulb class, 5 inside it or on a frame its 32-bit ray ids cannot cover) runs 1.  All
- * paths produce identical bits; the switch exists for A/B measurement and tests. */
+ * (rm::render_kernel, every class), 5 = the wavefront pipeline of rm_wavefront.hip.h for the table-walk classes (primitives,
+ * Menger sponge, Sierpinski; no samplers, procedural layers, refraction, Mandelbulb or 2-D Mandelbrot in the scene) — per
+ * generation of rays (primary, then each reflection bounce of frag:2491-2524) a persistent march kernel whose lanes are rays
+ * refilled from a queue as they end, a dense surface kernel, the same march kernel over the shadow rays, a dense light /
+ * bounce kernel.  A request that does not apply to the scene (5 with a Mandelbulb, samplers, layers or refraction, or on a
+ * frame its 32-bit ray ids cannot cover) runs 1.  Both produce identical bits; the switch exists for A/B measurement and
+ * tests.  (Paths 2-4, three multi-kernel pipelines of the single-Mandelbulb class, were measured slower than path 1 on every
+ * frame incl. frames without tile-order history — profiles/r04_b_bulb_paths.md — and removed in round 4; the numbers are refused.) */
 int rm_set_kernel_path(int path);
 /* Scratch memory the library owns.  Everything the schedules need beyond the caller's frame lives in grow-only buffers per
  * (device, stream): 8 B per tile for the tile-order feedback, the post passes' ping-pong images, and — by far the largest —

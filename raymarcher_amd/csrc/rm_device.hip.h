@@ -111,6 +111,15 @@ struct SceneBlock {
   float mengerAni, mengerOff;
 };
 
+// Which frame row a launch's local row r is: a plain row range (numShards = 1) or the row tiles of one shard of a multi-GPU
+// frame (tiles of tileRows rows dealt round-robin, include/raymarcher_amd.h rm_render_tiles).
+struct RowMap {
+  int rowBegin, tileRows, shard, numShards;
+  __host__ __device__ int frameRow(int r) const {
+    return rowBegin + ((r / tileRows) * numShards + shard) * tileRows + (r % tileRows);
+  }
+};
+
 struct SceneMin { int idx; float d; V4 trap; };
 struct MarchRes { int obj; float d; V4 trap; };
 struct Hit { V3 rd, p, n; int obj; };

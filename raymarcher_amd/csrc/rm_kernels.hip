@@ -16,7 +16,6 @@
 #include <tuple>
 #include <vector>
 
-#include "rm_bulb_pipeline.hip.h"
 #include "rm_device.hip.h"
 #include "rm_wavefront.hip.h"
 #include "rm_internal.h"
@@ -45,7 +44,7 @@ int require_device_pointers(std::initializer_list<std::pair<const char *, const 
 #define RM_TILE_W 8   // pixels per wave tile, horizontally (RM_TILE_W × RM_TILE_H = 64)
 #endif
 constexpr int kTileW = RM_TILE_W, kTileH = 64 / RM_TILE_W;
-constexpr int kBlockW = 4 * kTileW, kBlockH = kTileH;
+constexpr int kBlockH = kTileH;
 
 // COUNT: 0 production, 1 reference-work counters, 2 executed-work counters (rm_device.hip.h), 3 production code plus clock
 // stamps: every wave adds its (s_memtime, s_memrealtime) spans to counters[3], counters[4] — shader cycles and 100 MHz
@@ -78,8 +77,8 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   constexpr int CM = (COUNT == 3) ? 0 : COUNT;  // counting mode of the device code
   unsigned long long t0 = 0, r0 = 0;
   if (COUNT == 3) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-  // LDS copy of the object table for per-lane (divergent) material lookups.
-  __shared__ RmObject s_objs[RM_MAX_OBJECTS];
+  // LDS copy of the object table for per-lane (divergent) material lookups; the single-bulb class reads one entry.
+  __shared__ RmObject s_objs[BULB ? 1 : RM_MAX_OBJECTS];
   {
     const int nd = sb->numObjects * (int)(sizeof(RmObject) / 4);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sb->objs);
@@ -299,7 +298,6 @@ __global__ void deinterleave_kernel(const float4 *__restrict__ in, float4 *__res
 // streams of one device may overlap on the GPU, so they must not share ping-pong buffers or hit lists.
 namespace {
 constexpr int kSlotsInit = 8, kSlotsMax = 64;
-constexpr int kAutoBulbPath = 1;  // what rm_set_kernel_path(0) picks for the single-Mandelbulb class (measured best)
 struct Slot {
   SceneBlock *host = nullptr;  // pinned
   SceneBlock *dev = nullptr;
@@ -307,7 +305,7 @@ struct Slot {
   bool used = false;
 };
 struct TileOrderState { int tileCount = 0, W = 0, nRows = 0, nw = 0; void *mem = nullptr; };
-struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (single kernel) or 5 (pipeline K1..K4 boundaries)
+struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (one stage) or 3 (tile-order sort + render kernel)
 struct DeviceState {
   std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
   std::vector<Slot> slots;       // ring of scene-table slots; grows (to kSlotsMax) instead of waiting for a busy slot
@@ -326,7 +324,7 @@ std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_O
 constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
 std::atomic<bool> g_timing{false};
-std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one-lane-per-pixel, 2 pipeline A (state machine), 3 pipeline B (plain loops)
+std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one lane per pixel, 5 wavefront pipeline
 
 #define HIP_OK(expr)                                                                              \
   do {                                                                                            \
@@ -461,44 +459,6 @@ int release_workspaces(size_t *freedOut) {
   return RM_OK;
 }
 namespace {
-
-// Carve the pipeline workspace for `pixels` pixels and `nl` lights out of the device allocation.
-int bulb_workspace(size_t pixels, int nl, hipStream_t stream, BulbWs *ws, BulbWsB *wsB, BulbWsC *wsC, bool withQueues) {
-  auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
-  const size_t nlq = (size_t)(nl > 0 ? nl : 1);
-  const size_t oCnt = 0, oPix = align(256), oRec = oPix + align(pixels * 4), oP = oRec + align(pixels * 16),
-               oN = oP + align(pixels * 16), oSh = oN + align(pixels * 16), oRay = oSh + align(pixels * nlq * 8),
-               oQ = oRay + align(pixels * nlq * 4),
-               qBytes = withQueues ? 2 * (3 * align(pixels * 4) + 4 * align(pixels * nlq * 4)) : 0, total = oQ + qBytes;
-  void *mem = nullptr;
-  if (int st = stream_workspace(kWsBulbPipeline, stream, total, &mem)) return st;
-  char *b = static_cast<char *>(mem);
-  ws->counters = reinterpret_cast<uint32_t *>(b + oCnt);
-  ws->hitPix = reinterpret_cast<int *>(b + oPix);
-  ws->hitRec = reinterpret_cast<float4 *>(b + oRec);
-  ws->surfP = reinterpret_cast<float4 *>(b + oP);
-  ws->surfN = reinterpret_cast<float4 *>(b + oN);
-  ws->shadow = reinterpret_cast<int2 *>(b + oSh);
-  wsB->counters = ws->counters; wsB->hitPix = ws->hitPix; wsB->hitRec = ws->hitRec; wsB->surfP = ws->surfP;
-  wsB->surfN = ws->surfN; wsB->shadow = ws->shadow;
-  wsB->rayHit = reinterpret_cast<uint32_t *>(b + oRay);
-  wsB->cap = (uint32_t)pixels;
-  wsC->b = *wsB;
-  if (withQueues) {
-    char *q = b + oQ;
-    auto take = [&](size_t bytes) { char *r = q; q += align(bytes); return r; };
-    for (int k = 0; k < 2; k++) {
-      wsC->pPix[k] = reinterpret_cast<int *>(take(pixels * 4));
-      wsC->pT[k] = reinterpret_cast<float *>(take(pixels * 4));
-      wsC->pSteps[k] = reinterpret_cast<int *>(take(pixels * 4));
-      wsC->sRay[k] = reinterpret_cast<uint32_t *>(take(pixels * nlq * 4));
-      wsC->sT[k] = reinterpret_cast<float *>(take(pixels * nlq * 4));
-      wsC->sPen[k] = reinterpret_cast<float *>(take(pixels * nlq * 4));
-      wsC->sSteps[k] = reinterpret_cast<int *>(take(pixels * nlq * 4));
-    }
-  }
-  return RM_OK;
-}
 
 // Carve the wavefront pipeline's records for `cap` hit slots and `nl` lights out of the stream's workspace.
 constexpr int kWfBuffers = 13;
@@ -793,6 +753,26 @@ void ray_planes(SceneBlock *h) {
   }
 }
 
+// What an evaluation reads of an object (SceneBlock::evalRec), incl. the bound of the table walk's pass-over test, from h->objs.
+void scene_eval_records(SceneBlock *h) {
+  for (int i = 0; i < h->numObjects; i++) {
+    const RmObject &o = h->objs[i];
+    EvalRecord &e = h->evalRec[i];
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 3; r++) e.m[c * 3 + r] = o.invModel[c * 4 + r];
+    e.scaleFactor = o.scaleFactor;
+    e.type = o.type;
+    // the skip test's bound (rm_device.hip.h, sdScene<…, SKIP>): radius of the unit shape's bounding ball, with a margin
+    static const float kBound[] = {0.8662f, 0.7073f, 0.7073f, 0.5001f, 0.5001f, 0.6252f, 0.6002f, 0.5001f, 0.7073f};  // cube … rectangle
+    const float sf = o.scaleFactor;
+    const bool ok = std::isfinite(sf) && sf > 1e-6f && sf < 1e6f;
+    e.invScale = ok ? 1.0f / sf : 0.0f;
+    // the primitives only: a fractal's evaluation also writes the orbit trap that sdScene returns — the trap of the LAST
+    // evaluated fractal in table order, nearest or not — so passing over one would change it
+    e.boundR = (ok && o.type >= RM_CUBE && o.type <= RM_RECTANGLE) ? kBound[o.type] : INFINITY;
+  }
+}
+
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, hipStream_t stream, DeviceState &ds, Slot **slotOut,
                 const RmResources &res, const int32_t *tileOrder = nullptr, uint32_t *tileCost = nullptr,
@@ -803,23 +783,8 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   SceneBlock *h = slot->host;
   h->cam = *cam; h->g = *g; h->s = *s;
   h->numObjects = numObjects; h->numLights = numLights;
-  for (int i = 0; i < numObjects; i++) {
-    h->objs[i] = objs[i];
-    EvalRecord &e = h->evalRec[i];
-    for (int c = 0; c < 4; c++)
-      for (int r = 0; r < 3; r++) e.m[c * 3 + r] = objs[i].invModel[c * 4 + r];
-    e.scaleFactor = objs[i].scaleFactor;
-    e.type = objs[i].type;
-    {  // the skip test's bound (rm_device.hip.h, sdScene<…, SKIP>): radius of the unit shape's bounding ball, with a margin
-      static const float kBound[] = {0.8662f, 0.7073f, 0.7073f, 0.5001f, 0.5001f, 0.6252f, 0.6002f, 0.5001f, 0.7073f};  // cube … rectangle
-      const float sf = objs[i].scaleFactor;
-      const bool ok = std::isfinite(sf) && sf > 1e-6f && sf < 1e6f;
-      e.invScale = ok ? 1.0f / sf : 0.0f;
-      // the primitives only: a fractal's evaluation also writes the orbit trap that sdScene returns — the trap of the LAST
-      // evaluated fractal in table order, nearest or not — so passing over one would change it
-      e.boundR = (ok && objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE) ? kBound[objs[i].type] : INFINITY;
-    }
-  }
+  for (int i = 0; i < numObjects; i++) h->objs[i] = objs[i];
+  scene_eval_records(h);
   for (int i = 0; i < numLights; i++) h->lights[i] = lights[i];
   h->numTextures = res.numTextures;
   for (int i = 0; i < res.numTextures; i++) h->tex[i] = res.textures[i];
@@ -883,24 +848,18 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   if (dev < 0 || dev >= 64) { set_error("device index out of range"); return RM_ERR_DEVICE; }
   DeviceState &ds = g_dev[dev];
   std::lock_guard<std::mutex> lock(ds.mu);  // this device only; nothing below blocks on the GPU unless `count` asks for numbers back
-  dim3 grid((W + kBlockW - 1) / kBlockW, (nRows + kBlockH - 1) / kBlockH), block(256);
+  const dim3 block(256);
   const bool bulb = (numObjects == 1 && objs[0].type == RM_MANDELBULB);
   auto nonzero3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
-  // The wavefront pipeline covers the single-Mandelbulb class without secondary rays; everything else (and the
-  // counted variant) runs the one-lane-per-pixel kernel.  Both produce the same bits.
+  // Two schedules of the same per-ray arithmetic, identical bits: rm::render_kernel (one lane per pixel; every class, and the
+  // counted variants) and, for table-walk classes with bounces, the wavefront pipeline.
   static const int envPath = std::getenv("RM_KERNEL_PATH") ? std::atoi(std::getenv("RM_KERNEL_PATH")) : 0;
   const int pathReq = g_kernelPath.load() ? g_kernelPath.load() : envPath;  // 0 = the measured-fastest schedule of the scene's class
-  int path = pathReq;
-  if (path == 0) path = kAutoBulbPath;
-  if (path == 5) path = 1;  // the wavefront pipeline does not cover the bulb class: a request that does not apply runs path 1
   const bool envFeatures = (s->features & (RM_FEAT_TERRAIN | RM_FEAT_CLOUD | RM_FEAT_SKY_BACKGROUND | RM_FEAT_NIGHTSKY_BACKGROUND | RM_FEAT_SEA)) != 0;
   // anything that reads a sampler or takes the area-light branches: object textures, sky box, emissive rectangles, area lights
   bool textured = s->enableSkyBox != 0;
   for (int i = 0; i < numObjects; i++) textured = textured || objs[i].texLoc != -1 || objs[i].isEmissive;
   for (int i = 0; i < numLights; i++) textured = textured || lights[i].type == RM_LIGHT_AREA;
-  const bool pipeline = bulb && !count && path != 1 && !envFeatures && !textured && !g->isTwoD && s->maxSteps >= 1 && s->fractalIters >= 1 &&
-                        !(s->enableReflection && nonzero3(objs[0].cReflective)) &&
-                        !(s->enableRefraction && nonzero3(objs[0].cTransparent));
   // The wavefront pipeline (rm_wavefront.hip.h) covers the table-walk classes whose evaluations cost the same on every
   // lane: no Mandelbulb / 2-D Mandelbrot in the table, no samplers or procedural layers, no refraction.
   bool wfOk = !bulb && !count && !envFeatures && !textured && !g->isTwoD && s->maxSteps >= 1 && s->numReflection <= kWfMaxBounces;
@@ -970,7 +929,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   const int tileCount = (int)(rgrid.x * rgrid.y);
   // every class of the one-lane-per-pixel kernel (round 3: the layer and sampler kernels too — area light + point light 1080p
   // 0.80 -> 0.59 ms, textured floor / sky box at 4K 2.5 -> 2.3 ms, terrain + cloud horizon view 4.31 -> 4.04 ms, sea unchanged)
-  const bool ordered = orderMode > 0 && !pipeline && !wavefront && !g->isTwoD && count == 0 &&
+  const bool ordered = orderMode > 0 && !wavefront && !g->isTwoD && count == 0 &&
                        tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
   uint32_t *oCost = nullptr, *oHist = nullptr;
   int32_t *oOrder = nullptr;
@@ -1012,59 +971,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     return RM_OK;
   };
   float4 *o = reinterpret_cast<float4 *>(d_rgba), *b = reinterpret_cast<float4 *>(d_bright);
-  if (pipeline) {
-    if (ds.numCUs == 0) {
-      hipDeviceProp_t prop;
-      HIP_OK(hipGetDeviceProperties(&prop, dev));
-      ds.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    BulbWs ws;
-    BulbWsB wsB;
-    BulbWsC wsC;
-    // hit-list capacity: every pixel may hit, plus one partly used 64-slot chunk per persistent wave
-    const size_t slots = (size_t)nRows * W + (size_t)kSlotChunk * ds.numCUs * 8 * 4;
-    st = bulb_workspace(slots, numLights, stream, &ws, &wsB, &wsC, path == 4);
-    if (st != RM_OK) return st;
-    HIP_OK(hipMemsetAsync(ws.counters, 0, 256, stream));
-    // tuning knobs for A/B runs (defaults are the measured best)
-    static const int blocksPerCU = std::getenv("RM_PIPE_BLOCKS_PER_CU") ? std::atoi(std::getenv("RM_PIPE_BLOCKS_PER_CU")) : 8;
-    static const int flushThr = std::getenv("RM_PIPE_FLUSH") ? std::atoi(std::getenv("RM_PIPE_FLUSH")) : kDefaultFlushThreshold;
-    const dim3 persistent(ds.numCUs * (blocksPerCU > 0 ? blocksPerCU : 8)), dense(ds.numCUs * 16);
-    if ((st = stamp(0)) != RM_OK) return st;
-    if (path == 2) {
-      hipLaunchKernelGGL(bulb_primary_kernel, persistent, block, 0, stream, slot->dev, map, W, H, nRows, o, b, ws, flushThr);
-      if ((st = stamp(1)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulb_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, ws);
-      if ((st = stamp(2)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulb_shadow_kernel, persistent, block, 0, stream, slot->dev, ws, flushThr);
-      if ((st = stamp(3)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulb_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, ws);
-    } else if (path == 4) {
-      // step budgets per pass; the last pass always runs to the end of the march
-      static const int kBudgets[] = {16, 16, 32, 64, 1 << 30};
-      const int nPass = (int)(sizeof(kBudgets) / sizeof(kBudgets[0]));
-      hipLaunchKernelGGL((bulbC_primary_kernel<true>), grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsC, 0, kBudgets[0]);
-      for (int p = 1; p < nPass; p++)
-        hipLaunchKernelGGL((bulbC_primary_kernel<false>), persistent, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsC, p, kBudgets[p]);
-      if ((st = stamp(1)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulbB_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, wsB);
-      if ((st = stamp(2)) != RM_OK) return st;
-      hipLaunchKernelGGL((bulbC_shadow_kernel<true>), dense, block, 0, stream, slot->dev, wsC, 0, kBudgets[0]);
-      for (int p = 1; p < nPass; p++)
-        hipLaunchKernelGGL((bulbC_shadow_kernel<false>), persistent, block, 0, stream, slot->dev, wsC, p, kBudgets[p]);
-      if ((st = stamp(3)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulbB_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, wsB);
-    } else {
-      hipLaunchKernelGGL(bulbB_primary_kernel, grid, block, 0, stream, slot->dev, map, W, H, nRows, o, b, wsB);
-      if ((st = stamp(1)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulbB_surface_kernel, dense, block, 0, stream, slot->dev, map, W, H, wsB);
-      if ((st = stamp(2)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulbB_shadow_kernel, dense, block, 0, stream, slot->dev, wsB);
-      if ((st = stamp(3)) != RM_OK) return st;
-      hipLaunchKernelGGL(bulbB_shade_kernel, dense, block, 0, stream, slot->dev, map, W, H, o, b, wsB);
-    }
-    if ((st = stamp(4)) != RM_OK) return st;
-  } else if (wavefront) {
+  if (wavefront) {
     const WfWs &ws = wfWs;
     HIP_OK(hipMemsetAsync(ws.counters, 0, WF_STRIDE * (kWfMaxBounces + 2) * sizeof(uint32_t), stream));
     const dim3 pgrid(wfPrimaryWaves), mgrid(wfShadowWaves), mblock(64), dense(ds.numCUs * 16);
@@ -1118,7 +1025,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if ((st = stamp((ordered && haveCost) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
-  ds.lastPath = pipeline ? path : (wavefront ? 5 : 1);
+  ds.lastPath = wavefront ? 5 : 1;
   if (timing) { ds.timed.push_back(tl); timedGuard.kept = true; }
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
@@ -1446,7 +1353,7 @@ int rm_debug_last_path(void) {
   return ds->lastPath;
 }
 int rm_set_kernel_path(int path) {
-  if (path < 0 || path > 5) { set_error("kernel path must be 0..5"); return RM_ERR_INVALID_ARGUMENT; }
+  if (path != 0 && path != 1 && path != 5) { set_error("kernel path must be 0, 1 or 5 (2-4, the bulb pipelines, were removed in round 4)"); return RM_ERR_INVALID_ARGUMENT; }
   g_kernelPath.store(path);
   return RM_OK;
 }

@@ -20,13 +20,48 @@
 //                           next ray, otherwise the pixel is complete and stored.
 //
 // Records live in a per-(device, stream) workspace in HBM.  Cursors are reserved per wave in chunks (one device atomic per
-// 512 rays / 64 hit slots); unused slots of a wave's last chunk are holes (src < 0) that the dense kernels skip.
+// 256 rays / pixels / hit slots, RM_WF_*_CHUNK below); unused slots of a wave's last chunk are holes (src < 0) that the dense
+// kernels skip.
 // Not covered (the launcher keeps those on rm::render_kernel): procedural layers, samplers (textures, sky box, area
 // lights), refraction, scenes with a Mandelbulb or the 2-D Mandelbrot (data-dependent evaluation cost), counting modes.
 #pragma once
-#include "rm_bulb_pipeline.hip.h"
+#include "rm_device.hip.h"
 
 namespace rm {
+
+// ---- wave / block helpers of the queues ----------------------------------------------------------------------------------
+// Reserve `n` units from a device counter, once per wave (lane 0 issues the atomic, the base is broadcast).
+RM_DEV uint32_t waveReserve(uint32_t *counter, uint32_t n) {
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, n);
+  return (uint32_t)__shfl((int)base, 0);
+}
+RM_DEV unsigned long long laneMaskLt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+enum { ST_NEED = 0, ST_MARCH = 1, ST_HIT = 2, ST_MISS = 3, ST_DONE = 4 };  // a lane of a persistent march wave
+// Pixel handed out by the tile-major cursor: 64 consecutive indices = one 8×8 tile (neighbouring lanes start on neighbouring rays).
+RM_DEV bool decodePixel(uint32_t idx, int tilesX, int W, int nRows, int &x, int &r) {
+  uint32_t tile = idx >> 6, l = idx & 63u;
+  x = (int)(tile % (uint32_t)tilesX) * 8 + (int)(l & 7u);
+  r = (int)(tile / (uint32_t)tilesX) * 8 + (int)(l >> 3);
+  return x < W && r < nRows;
+}
+// Block-aggregated append (256-thread blocks): returns this lane's slot (valid only where `want`), one atomic per block.
+RM_DEV uint32_t blockAppend(bool want, uint32_t *counter, uint32_t *ldsScratch /* >= 5 words */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(want);
+  if (lane == 0) ldsScratch[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = ldsScratch[0] + ldsScratch[1] + ldsScratch[2] + ldsScratch[3];
+    ldsScratch[4] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = ldsScratch[4];
+  for (int w = 0; w < wave; w++) base += ldsScratch[w];
+  const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();  // scratch may be reused by the next call
+  return slot;
+}
 
 constexpr int kWfMaxBounces = 7;
 constexpr uint32_t kWfShadowHit = 0x7fc00001u;  // shadow result of a ray that hit: a NaN (no penumbra factor is one)
@@ -91,9 +126,10 @@ RM_DEV void wfLightRay(const RmLight &li, V3 p, float far, V3 &L, float &maxT) {
 #define RM_WF_PRIMARY_WAVES 6
 #endif
 constexpr int wfMarchWaves(int kind) { return kind == 2 ? RM_WF_MARCH_WAVES : RM_WF_PRIMARY_WAVES; }
-// Cursor granularity.  One device counter sustains ≈88 atomics per µs (measured, rm_bulb_pipeline.hip.h): with 64-slot hit
-// chunks the 20 M primary hits of the 8K Menger frame were 311 k atomics ≈ 3.5 ms of a 5.0 ms kernel (the bounce kernels
-// likewise), so hit slots are reserved 1024 at a time (a wave's unused remainder becomes holes) and rays 512 / 1024.
+// Cursor granularity.  One device counter sustains ≈88 atomics per µs (measured in round 1): with 64-slot hit chunks the 20 M
+// primary hits of the 8K Menger frame were 311 k atomics ≈ 3.5 ms of a 5.0 ms kernel (the bounce kernels likewise), so hit
+// slots, rays and pixels are reserved 256 at a time (a wave's unused remainder becomes holes; 64 was atomic-bound, 1024 and
+// guided chunks measured slower: profiles/r03_b_wavefront.md).
 #ifndef RM_WF_SLOT_CHUNK
 #define RM_WF_SLOT_CHUNK 256
 #endif

@@ -2,6 +2,8 @@
 # calibrate SQ_INSTS_VALU against a kernel whose instruction count is known (scripts/microbench/valu_rate2)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+# built here from its source (the binary is not tracked), with the product's flags
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o $R/scripts/microbench/valu_rate2 $R/scripts/microbench/valu_rate2.hip
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_vr2 -- $R/scripts/microbench/valu_rate2 > $R/gpurun_out/pmc_vr2.log 2>&1
 python3 - <<PY
 import csv, glob

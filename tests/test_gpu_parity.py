@@ -376,10 +376,9 @@ def test_mandelbrot_2d_and_julia(renderer):
     assert_bit_equal(renderer.render(tables_of(tuple(scene)), s, W, H).cpu().numpy(), ref, "julia bulb power 6")
 
 
-def test_bulb_schedules_are_bit_identical(renderer):
-    """One lane per pixel (path 1), the state-machine pipeline (2) and the plain-loop pipeline (3) are three
-    schedules of the same arithmetic: identical bits, including with a transformed bulb, a point + spot light,
-    AO and soft shadows."""
+def test_bulb_class_with_every_light_kind_and_kernel_path_requests(renderer):
+    """A transformed bulb under a directional, a point and a spot light, with AO and soft shadows: the oracle's bits whichever
+    schedule is requested — 1, 0 (auto) or 5 (does not apply to the bulb class: runs 1); the removed paths 2-4 are refused."""
     from raymarcher_amd import lib
     W, H = 150, 83
     cam = h.make_camera((0.5, 0.8, 4.0), (-0.5, -0.8, -4.0), (0, 1, 0), 35.0, W, H)
@@ -396,14 +395,17 @@ def test_bulb_schedules_are_bit_identical(renderer):
                  {"features": abi.RM_FEAT_DARK_BACKGROUND, "fractalIters": 1}):
         s = abi.default_settings(**over)
         ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
-        for path in (1, 2, 3, 4, 0):
+        for path in (1, 5, 0):
             try:
-                lib().rm_set_kernel_path(path)
+                assert lib().rm_set_kernel_path(path) == 0
                 a, ab = renderer.render(tables_of(scene), s, W, H, bright=True)
+                assert lib().rm_debug_last_path() == 1
             finally:
                 lib().rm_set_kernel_path(0)
             assert_bit_equal(a.cpu().numpy(), ref, f"path {path} vs oracle {over}")
             assert_bit_equal(ab.cpu().numpy(), ref_b, f"path {path} bright vs oracle {over}")
+    for gone in (2, 3, 4, 6, -1):
+        assert lib().rm_set_kernel_path(gone) == abi.RM_ERR_INVALID_ARGUMENT
 
 
 def synthetic_textures():
