@@ -1113,7 +1113,10 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
 // raymarch.vert:13-25 + frag:2383-2427 + frag:2429-2575 for the pixel centre (px, py), py = 0 at the bottom.
 // ENV = false compiles the procedural layers out (the launcher picks the instantiation from the feature bits),
 // so the common kernels do not carry their registers and code.
-template <bool BULB, int COUNT, bool ENV, bool TEX>
+// SEC = false compiles main's secondary rays out (reflection loop, refraction): the launcher picks it when the settings or the
+// materials rule them out for the whole frame, so that what render() hands over for them (hit point, normal, direction) is not
+// carried across the shadow marches — fewer registers spilled around the hot loops, the same pixels.
+template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
                        V4 &bright, Counters &cnt, bool &hitFlag) {
   float ndcx, ndcy;
@@ -1159,7 +1162,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   const V3 cRefl = noObj ? v3(0.0f, 0.0f, 0.0f) : v3(o.cReflective[0], o.cReflective[1], o.cReflective[2]);
   const V3 cRefr = noObj ? v3(0.0f, 0.0f, 0.0f) : v3(o.cTransparent[0], o.cTransparent[1], o.cTransparent[2]);
   const float ior = o.ior;
-  if (sb->s.enableReflection && len(cRefl) != 0.0f) {  // frag:2491-2524
+  if (SEC && sb->s.enableReflection && len(cRefl) != 0.0f) {  // frag:2491-2524
     V3 fil = v3(1.0f, 1.0f, 1.0f);
     const int nb = sb->s.numReflection;
     for (int i = 0; i < nb; i++) {
@@ -1181,7 +1184,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
       if (res.isEnv) break;
     }
   }
-  if (sb->s.enableRefraction && len(cRefr) != 0.0f) {  // frag:2526-2570
+  if (SEC && sb->s.enableRefraction && len(cRefr) != 0.0f) {  // frag:2526-2570
     V3 rdIn = refract(oi.rd, oi.n, 1.0f / ior);
     V3 pEnter = v3(fma(-(oi.n.x * kSurfaceDist), 3.0f, oi.p.x), fma(-(oi.n.y * kSurfaceDist), 3.0f, oi.p.y),
                    fma(-(oi.n.z * kSurfaceDist), 3.0f, oi.p.z));

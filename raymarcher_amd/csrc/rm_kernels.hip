@@ -63,14 +63,22 @@ constexpr int kBlockH = kTileH;
 #ifndef RM_BULB_WAVES
 #define RM_BULB_WAVES 5
 #endif
+// the instantiations without main's secondary rays (SEC = false: no reflection / refraction anywhere in the frame) need far fewer
+// registers — the bulb kernel 90 without a single spill — and take their own budgets (profiles/r04_d_secondary_rays.md)
+#ifndef RM_BULB_NOSEC_WAVES
+#define RM_BULB_NOSEC_WAVES 6
+#endif
+#ifndef RM_GENERIC_NOSEC_WAVES
+#define RM_GENERIC_NOSEC_WAVES 6
+#endif
 #ifndef RM_ENV_WAVES
 #define RM_ENV_WAVES 6
 #endif
 #ifndef RM_TEX_WAVES
 #define RM_TEX_WAVES 6
 #endif
-template <bool BULB, int COUNT, bool ENV, bool TEX>
-__global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? RM_BULB_WAVES : RM_GENERIC_WAVES)))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true>
+__global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? (SEC ? RM_BULB_WAVES : RM_BULB_NOSEC_WAVES) : (SEC ? RM_GENERIC_WAVES : RM_GENERIC_NOSEC_WAVES))))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
                                                       unsigned long long *__restrict__ counters) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (B
   V4 col, br;
   Counters cnt{0, 0, 0, 0, 0, 0};
   bool hit;
-  shadePixel<BULB, CM, ENV, TEX>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, CM, ENV, TEX, SEC>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -870,6 +878,11 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     anyReflective = anyReflective || nonzero3(objs[i].cReflective);
   }
   const int wfBounces = (s->enableReflection && anyReflective) ? s->numReflection : 0;
+  // whether main's secondary rays (frag:2491-2570) can fire for any pixel of this frame: a reflective object with reflection on and
+  // at least one bounce, or a transparent one with refraction on — otherwise the plain instantiations compile them out (SEC = false)
+  bool anyTransparent = false;
+  for (int i = 0; i < numObjects; i++) anyTransparent = anyTransparent || nonzero3(objs[i].cTransparent);
+  const bool secondary = (s->enableReflection && anyReflective && s->numReflection > 0) || (s->enableRefraction && anyTransparent);
   const bool wfSkip = skip_applies(objs, numObjects);
   bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W)));
   // The wavefront pipeline's knobs and records, settled BEFORE anything below depends on `wavefront`: if its workspace
@@ -1007,21 +1020,25 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
 #define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
       // counting instantiations of the layer / sampler kernels: the reference's work only (they have no shortcuts to count apart)
-      if (envFeatures && textured) { if (count) RM_LAUNCH(false, 1, true, true); else RM_LAUNCH(false, 0, true, true); }
-      else if (envFeatures) { if (count) RM_LAUNCH(false, 1, true, false); else RM_LAUNCH(false, 0, true, false); }
-      else { if (count) RM_LAUNCH(false, 1, false, true); else RM_LAUNCH(false, 0, false, true); }
+#define RM_LAUNCH_NOSEC(B, E, T) hipLaunchKernelGGL((render_kernel<B, 0, E, T, false>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
+      if (envFeatures && textured) { if (count) RM_LAUNCH(false, 1, true, true); else if (secondary) RM_LAUNCH(false, 0, true, true); else RM_LAUNCH_NOSEC(false, true, true); }
+      else if (envFeatures) { if (count) RM_LAUNCH(false, 1, true, false); else if (secondary) RM_LAUNCH(false, 0, true, false); else RM_LAUNCH_NOSEC(false, true, false); }
+      else { if (count) RM_LAUNCH(false, 1, false, true); else if (secondary) RM_LAUNCH(false, 0, false, true); else RM_LAUNCH_NOSEC(false, false, true); }
     } else if (bulb) {
       if (count == 1) RM_LAUNCH(true, 1, false, false);
       else if (count == 2) RM_LAUNCH(true, 2, false, false);
       else if (count == 3) RM_LAUNCH(true, 3, false, false);
-      else RM_LAUNCH(true, 0, false, false);
+      else if (secondary) RM_LAUNCH(true, 0, false, false);
+      else RM_LAUNCH_NOSEC(true, false, false);
     } else {
       if (count == 1) RM_LAUNCH(false, 1, false, false);
       else if (count == 2) RM_LAUNCH(false, 2, false, false);
       else if (count == 3) RM_LAUNCH(false, 3, false, false);
-      else RM_LAUNCH(false, 0, false, false);
+      else if (secondary) RM_LAUNCH(false, 0, false, false);
+      else RM_LAUNCH_NOSEC(false, false, false);
     }
 #undef RM_LAUNCH
+#undef RM_LAUNCH_NOSEC
     if ((st = stamp((ordered && haveCost) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
