@@ -71,6 +71,12 @@ constexpr int kBlockH = kTileH;
 #ifndef RM_GENERIC_NOSEC_WAVES
 #define RM_GENERIC_NOSEC_WAVES 6
 #endif
+#ifndef RM_ENV_NOSEC_WAVES
+#define RM_ENV_NOSEC_WAVES 6
+#endif
+#ifndef RM_TEX_NOSEC_WAVES
+#define RM_TEX_NOSEC_WAVES 6
+#endif
 #ifndef RM_ENV_WAVES
 #define RM_ENV_WAVES 6
 #endif
@@ -78,7 +84,7 @@ constexpr int kBlockH = kTileH;
 #define RM_TEX_WAVES 6
 #endif
 template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true>
-__global__ __launch_bounds__(256, (TEX ? RM_TEX_WAVES : (ENV ? RM_ENV_WAVES : (BULB ? (SEC ? RM_BULB_WAVES : RM_BULB_NOSEC_WAVES) : (SEC ? RM_GENERIC_WAVES : RM_GENERIC_NOSEC_WAVES))))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
+__global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVES) : (ENV ? (SEC ? RM_ENV_WAVES : RM_ENV_NOSEC_WAVES) : (BULB ? (SEC ? RM_BULB_WAVES : RM_BULB_NOSEC_WAVES) : (SEC ? RM_GENERIC_WAVES : RM_GENERIC_NOSEC_WAVES))))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
                                                       unsigned long long *__restrict__ counters) {
