@@ -37,7 +37,12 @@ SFU_PER_ITER, SFU_PER_EVAL = 12, 3  # special-function ops inside the two figure
 # The table-walk classes, counted from the shader text the same way.  One unit primitive of sdMatch (frag:832-894,
 # 991-1019, 1262-1293): sphere length − r; box abs, −, max, length, max max min, +; …
 SDF_FLOP = {0: 19, 1: 28, 2: 17, 3: 7, 4: 30, 5: 10, 6: 10, 7: 34, 8: 19}  # cube cone cylinder sphere octahedron torus capsule deathstar rectangle
-MENGER_BASE, MENGER_PER_LEVEL = 19 + 40, 69  # sdBox + the ani / off prologue (smoothstep, cos, sin); one level of frag:1057-1069 incl. the rotation mix
+# sdMengerSponge (frag:1049-1071).  AS WRITTEN every evaluation also computes ani = smoothstep(−0.2, 0.2, −cos(0.5·iTime)) and
+# off = 1.5·sin(0.01·iTime) (40 flop of launch-uniform arithmetic) and every level the rotation mix p ← mix(p, ma·(p + off), ani)
+# (27 flop), which at iTime = 0 (ani = 0) is the identity.  No implementation executes either per lane, so the ALGORITHMIC model
+# (roofline.frac) leaves the uniform prologue out and, at ani = 0, the mix; the shader-as-written price is reported beside it
+# (roofline.shader_as_written), as round 3's `frac` was.
+MENGER_BOX, MENGER_UNIFORM_PROLOGUE, MENGER_PER_LEVEL, MENGER_ROTATION_MIX = 19, 40, 42, 27
 SIERPINSKI_FLOP = 14 * 18 + 7                 # 14 fold-scale iterations (frag:819-824), length, constant scale
 FLOP_PER_OBJECT = 18 + 1 + 2                  # invModel·(p,1) (9 fma), ·scaleFactor, nearest-object compare / select (frag:1417-1423)
 FLOP_PER_STEP = 10                            # ro + rd·t, hit test, t += d (frag:1459-1470 / 1708-1714)
@@ -48,11 +53,12 @@ FLOP_PER_FBMD8 = 8 * (164 + 75) + 4 * 21 + 30  # fbmd_8 = 8 x (noised 164 + octa
 
 # HBM bytes per launch measured with rocprofv3 PMC counters (WRITE_SIZE, FETCH_SIZE in separate passes; the GPU box's
 # counters cannot be collected from inside this run): see the named profile.  None = not measured yet.
-TRAFFIC_MEASURED = {}
-_traffic_file = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
-if os.path.exists(_traffic_file):
-    with open(_traffic_file) as _f:
-        TRAFFIC_MEASURED = json.load(_f)
+TRAFFIC_MEASURED, PMC_MEASURED = {}, {}
+for _name, _into in (("r04_hbm_traffic.json", TRAFFIC_MEASURED), ("r04_pmc.json", PMC_MEASURED)):
+    _file = os.path.join(ROOT, "profiles", _name)
+    if os.path.exists(_file):
+        with open(_file) as _f:
+            _into.update(json.load(_f))
 
 
 def host_cores():
@@ -126,11 +132,12 @@ def build_config(name, algebraic=False):
     return t, s, W, H, d
 
 
-def flop_model(t, s, cnt, executed=False):
+def flop_model(t, s, cnt, executed=False, as_written=False):
     """Algorithmic flops of a frame from its deterministic counters and the scene table (the reference's formulation,
-    independent of how the kernels evaluate it).  executed=True prices what the kernels really evaluate where that differs
-    from the shader text: the Menger sponge without its per-evaluation uniform prologue (computed once per launch) and,
-    at iTime = 0 (ani = 0), without the per-level rotation mix.  Returns (flop, breakdown dict, model dict)."""
+    independent of how the kernels evaluate it).  as_written=True also charges what the shader text computes per lane but no
+    implementation would (the Menger sponge's launch-uniform prologue; its rotation mix where it is the identity).  executed=True
+    takes the executed-work counters (culls, objects passed over) at the same unit prices.
+    Returns (flop, breakdown dict, model dict)."""
     from raymarcher_amd import abi
     bulb_only = t.num_objects == 1 and t.objects[0].type == abi.RM_MANDELBULB
     per_eval = FLOP_PER_STEP
@@ -139,9 +146,10 @@ def flop_model(t, s, cnt, executed=False):
         if ty == abi.RM_MANDELBULB:
             sdf = FLOP_PER_EVAL_BULB - FLOP_PER_OBJECT - FLOP_PER_STEP  # prologue + distance estimate (its iterations are counted apart)
         elif ty == abi.RM_MENGERSPONGE:
-            sdf = MENGER_BASE + MENGER_PER_LEVEL * s.mengerLevels
-            if executed:
-                sdf = 19 + (MENGER_PER_LEVEL - (27 if t.globals_.iTime == 0.0 else 0)) * s.mengerLevels
+            still = t.globals_.iTime == 0.0  # ani = smoothstep(−0.2, 0.2, −cos 0) = 0: the rotation mix is the identity
+            sdf = MENGER_BOX + (MENGER_PER_LEVEL + (0 if still else MENGER_ROTATION_MIX)) * s.mengerLevels
+            if as_written:
+                sdf = MENGER_BOX + MENGER_UNIFORM_PROLOGUE + (MENGER_PER_LEVEL + MENGER_ROTATION_MIX) * s.mengerLevels
         elif ty == abi.RM_SIERPINSKI:
             sdf = SIERPINSKI_FLOP
         else:
@@ -490,6 +498,7 @@ def main():
         mpix = W * H * args.steps / dt / 1e6
         flops_frame, parts, model = flop_model(tables, settings, cnt)
         flops_exec = flop_model(tables, settings, cnt_exec, executed=True)[0] if cnt_exec is not None else None
+        flops_written = flop_model(tables, settings, cnt, as_written=True)[0]
         kernel_names = {1: "rm::render_kernel<BULB,COUNT=0,ENV,TEX> (one lane per pixel, 8x8 tile per wave)",
                         5: "wavefront pipeline: per ray generation rm::wf_march_kernel<0|1> (persistent waves, lanes = rays, refilled), "
                            "wf_surface_kernel, wf_march_kernel<2> (shadow rays), wf_light_kernel"}
@@ -524,6 +533,18 @@ def main():
                                 "sceneEvals": cnt_exec.sceneEvals, "bulbIters": cnt_exec.bulbIters, "shapeEvals": cnt_exec.shapeEvals,
                                 "shapes_per_evaluation": round(cnt_exec.shapeEvals / max(cnt_exec.sceneEvals, 1), 3),
                                 "flop_per_launch": flops_exec / world}
+        if flops_written != flops_frame:
+            w = flops_written / world / secs / 1e12 if secs > 0 else 0.0
+            roof["shader_as_written"] = {"achieved": round(w, 3), "frac": round(w / PEAK_FP32_TFLOPS, 4), "flop_per_launch": flops_written / world,
+                                         "what": "the same units priced with what the shader text computes per lane but no implementation would: the "
+                                                 "Menger sponge's launch-uniform prologue (40 flop per evaluation) and, at iTime = 0, its identity "
+                                                 "rotation mix (27 flop per level); round 3 reported this as `frac`"}
+        pm = PMC_MEASURED.get(cfg)
+        if pm:
+            # a utilisation figure that needs no flop model: wave-level VALU instructions x live lanes over the issue slots of the
+            # profiled launch (rocprofv3 PMC passes over this command; profiled clocks run a few percent lower)
+            roof["valu_issue"] = {"frac": pm["valu_issue_frac"], "lanes_live": pm["lanes_live"], "cycles_per_valu_instr_per_simd": pm["cycles_per_valu"],
+                                  "resident_waves_per_simd": pm["resident_waves"], "source": pm["source"]}
         if cfg == "c3":
             roof["slots"] = {"algorithmic_frac": round(slots_model(cnt) / world / secs / PEAK_LANE_SLOTS, 4) if secs > 0 else 0.0,
                              "executed_frac": round(slots_model(cnt_exec) / world / secs / PEAK_LANE_SLOTS, 4) if secs > 0 else 0.0,

@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes over every bench configuration on the final round-3 build (production kernels; per launch averages)
+# PMC passes over every bench configuration (production kernels; per launch averages).  PMC_JSON=<file>: also write, per
+# configuration, the frame's aggregate (all production kernels of a frame together) as JSON for bench.py's roofline.valu_issue.
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -22,6 +23,8 @@ def production(n):
     if "wf_" in n: return True
     m = re.search(r"render_kernel<(\w+), (\d+)", n)
     return bool(m) and m.group(2) == "0"
+import json, os
+agg={}
 print("| configuration | kernel | launches | ms | SQ_INSTS_VALU | lanes live | cycles per VALU instr per SIMD | resident waves / SIMD | s_waitcnt share (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | issue-stall share (SQ_WAIT_INST_ANY) | SALU / VALU |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 for cfg in ["c1","c2","c3","c4","c5"]:
@@ -41,5 +44,16 @@ for cfg in ["c1","c2","c3","c4","c5"]:
         iv=a.get("SQ_INSTS_VALU",0)
         if iv < 1e5: continue
         cyc=ms*1e-3*2.39e9*1024
+        g=agg.setdefault(cfg,{"slots":0.0,"lane_instr":0.0,"instr":0.0,"cyc":0.0,"wave_cyc":0.0})
+        nl=len(durs[k])/3.0  # launches per pass
+        g["instr"]+=iv*nl; g["lane_instr"]+=a.get("SQ_THREAD_CYCLES_VALU",0)*nl; g["cyc"]+=cyc*nl; g["wave_cyc"]+=4*a.get("SQ_WAVE_CYCLES",0)*nl
         print(f"| {cfg} | `{k}` | {len(durs[k])//3} | {ms:.3f} | {iv:.3g} | {a.get('SQ_THREAD_CYCLES_VALU',0)/(64*iv):.0%} | {cyc/iv:.2f} | {4*a.get('SQ_WAVE_CYCLES',0)/cyc:.2f} | {a.get('SQ_WAIT_ANY',0)/max(a.get('SQ_WAVE_CYCLES',1),1):.0%} | {a.get('SQ_WAIT_INST_ANY',0)/max(a.get('SQ_WAVE_CYCLES',1),1):.0%} | {a.get('SQ_INSTS_SALU',0)/iv:.2f} |")
+out={}
+for cfg,g in agg.items():
+    if g["instr"]<=0: continue
+    # issue slots: one wave64 VALU instruction per 2 cycles per SIMD at full rate (SIMD-32), every lane live
+    out[cfg]={"valu_issue_frac": round(2.0*g["lane_instr"]/64.0/g["cyc"],4), "lanes_live": round(g["lane_instr"]/(64.0*g["instr"]),3),
+              "cycles_per_valu": round(g["cyc"]/g["instr"],2), "resident_waves": round(g["wave_cyc"]/g["cyc"],2)}
+if os.environ.get("PMC_JSON"):
+    json.dump(out, open(os.environ["PMC_JSON"],"w"), indent=1)
 PY

@@ -36,9 +36,13 @@ def test_flop_model_arithmetic():
     flop, parts, model = bench.flop_model(t, s, c)
     assert model["flop_per_evaluation"] == 41 and model["flop_per_iteration"] == 79 and model["flop_per_shaded_point"] == 1800
     assert flop == 640027016 * 79 + 330035979 * 41 + 2717394 * 1800 and abs(flop / 1e9 - 68.98) < 0.01
-    # table-walk classes: per evaluation 10 + per object 21 + its SDF; Menger: box + prologue + 69 per level
+    # table-walk classes: per evaluation 10 + per object 21 + its SDF.  Menger at iTime = 0: box + 42 per level (the launch-uniform
+    # prologue and the identity rotation mix are priced only in the shader-as-written side figure: 40 + 27 per level more)
     t, s, W, H, _ = bench.build_config("c5")
-    assert bench.flop_model(t, s, abi.RmCounters(1, 0, 0, 0, 0, 0))[0] == 10 + 21 + (19 + 40) + 69 * 5
+    assert bench.flop_model(t, s, abi.RmCounters(1, 0, 0, 0, 0, 0))[0] == 10 + 21 + 19 + 42 * 5
+    assert bench.flop_model(t, s, abi.RmCounters(1, 0, 0, 0, 0, 0), as_written=True)[0] == 10 + 21 + (19 + 40) + 69 * 5
+    t.globals_.iTime = 2.5  # an animated sponge does execute the mix
+    assert bench.flop_model(t, s, abi.RmCounters(1, 0, 0, 0, 0, 0))[0] == 10 + 21 + 19 + 69 * 5
     t, s, W, H, _ = bench.build_config("c2")  # cylinder, cone, sphere, two cubes (any order)
     assert bench.flop_model(t, s, abi.RmCounters(1, 0, 0, 0, 0, 0))[0] == 10 + 5 * 21 + 17 + 28 + 7 + 19 + 19
     assert bench.flop_model(t, s, abi.RmCounters(0, 0, 0, 1, 0, 0))[0] == 50 + 3 * 50 + 4 * 400
