@@ -19,7 +19,7 @@ def production(name):
 
 
 def primary(name):
-    return "wf_march_kernel<0>" in name or re.search(r"render_kernel<\w+, 0", name) is not None
+    return "wf_march_kernel<0" in name or re.search(r"render_kernel<\w+, 0", name) is not None
 
 
 def main():
