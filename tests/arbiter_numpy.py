@@ -14,15 +14,15 @@ the 49 hash classes, so which of two unrelated gradients `step(gz, 0)` picks is 
 binary32 implementation with IEEE division agrees; a binary64 evaluation of that line picks other gradients for no meaningful
 reason).  Those lines run on np.float32 arrays with NumPy's IEEE operations; everything around them is float64.
 
-Scope: exactly what a frame of scenefiles/simple/unit_mandelbulb.json executes with the reference's default settings
-(WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, reflection, refraction, sky box off): one MANDELBULB object, DIRECTIONAL
-lights.  Anything else raises."""
+Scope: exactly what a frame of scenefiles/simple/unit_mandelbulb.json (C3) or unit_mengersponge.json (C5: sdMengerSponge,
+frag:1049-1071, its palette and main's reflection loop, frag:2491-2524) executes with the reference's default #defines
+(WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, refraction, sky box off): one object, DIRECTIONAL lights.  Anything else raises."""
 import numpy as np
 
 SURFACE_DIST = 1e-3          # frag:32
 FRACTALS_BAILOUT = 2.0       # frag:30
 BUMP_SCALE, BUMP_INTENSITY = 10.0, 2.0  # frag:128-129
-RM_MANDELBULB, RM_LIGHT_DIRECTIONAL = 10, 1  # scenedata.h:18-33 / 10-15 ≡ frag:53-75
+RM_MANDELBULB, RM_MENGERSPONGE, RM_LIGHT_DIRECTIONAL = 10, 11, 1  # scenedata.h:18-33 / 10-15 ≡ frag:53-75
 RM_FEAT_PERLIN_BUMP, RM_FEAT_WHITE_BACKGROUND = 128, 8  # include/raymarcher_amd.h: the shader's #defines as feature bits
 
 
@@ -188,14 +188,75 @@ def get_phong(sd, N, obj, lights, g, p, rd, far, max_steps):
     return total
 
 
+class Menger:
+    """sdScene with a table of one Menger sponge (frag:1406-1430, 1049-1071).  `levels` is the loop bound of frag:1056 (4 in the
+    shader, a build knob of the product); resColor = (d, min(0.2·da·db·dc), (1 + m)/4, 0) of the last level that raised d."""
+
+    def __init__(self, inv_model, scale_factor, levels, itime):
+        self.M, self.sf, self.levels, self.itime = np.asarray(inv_model, np.float64), float(scale_factor), int(levels), float(itime)
+
+    def __call__(self, p):
+        p = p @ self.M[:3, :3].T + self.M[:3, 3]
+        q = np.abs(p) - 1.0                                        # sdBox(p, vec3(1)), frag:843-846
+        d = np.sqrt(_dot(np.maximum(q, 0.0), np.maximum(q, 0.0))) + np.minimum(np.max(q, axis=-1), 0.0)
+        res = np.stack([d, np.ones_like(d), np.zeros_like(d), np.zeros_like(d)], -1)
+        x = -np.cos(0.5 * self.itime)                              # smoothstep(−0.2, 0.2, −cos(0.5·iTime)), frag:1052
+        t = np.clip((x + 0.2) / 0.4, 0.0, 1.0)
+        ani = t * t * (3.0 - 2.0 * t)
+        off = 1.5 * np.sin(0.01 * self.itime)
+        ma = np.array([[0.60, 0.00, -0.80], [0.00, 1.00, 0.00], [0.80, 0.00, 0.60]])  # columns (.6,0,.8), (0,1,0), (−.8,0,.6): frag:124-126
+        s = 1.0
+        for m in range(self.levels):
+            p = _mix(p, (p + off) @ ma.T, ani)                     # frag:1057
+            a = np.mod(p * s, 2.0) - 1.0
+            s *= 3.0
+            r = np.abs(1.0 - 3.0 * np.abs(a))
+            da, db, dc = np.maximum(r[:, 0], r[:, 1]), np.maximum(r[:, 1], r[:, 2]), np.maximum(r[:, 2], r[:, 0])
+            c = (np.minimum(da, np.minimum(db, dc)) - 1.0) / s
+            up = c > d
+            d = np.where(up, c, d)
+            res = np.where(up[:, None], np.stack([d, np.minimum(res[:, 1], 0.2 * da * db * dc), np.full_like(d, (1.0 + m) / 4.0),
+                                                   np.zeros_like(d)], -1), res)
+        return d * self.sf, res
+
+
+def render_rays(sd, kind, obj, lights, g, ro, rd, far, settings, bg):
+    """render() (frag:2318-2375) for a batch of rays: (rgb, isEnv, hit point, shading normal).  Point and normal are only
+    meaningful where isEnv is False (the `out IntersectionInfo` of a hit)."""
+    n = len(ro)
+    rgb = np.broadcast_to(bg, (n, 3)).copy()                # a miss: vec4(bgCol, 1), frag:2323-2329
+    hit, depth, trap = raymarch(sd, ro, rd, far, settings.maxSteps)
+    P, N = np.zeros((n, 3)), np.zeros((n, 3))
+    if hit.any():
+        p = ro[hit] + rd[hit] * depth[hit, None]             # frag:2333
+        pn = get_normal(sd, p)
+        if settings.features & RM_FEAT_PERLIN_BUMP:          # #define PERLIN_BUMP (frag:15, 2334-2336)
+            pn = bump_normal(pn, p)
+        ph = get_phong(sd, pn, obj, lights, (g.ka, g.kd, g.ks), p, rd[hit], far, settings.maxSteps)
+        tr = trap[hit]
+        if kind == "bulb":                                   # frag:2354-2361
+            col = np.full((len(p), 3), 0.2)
+            col = _mix(col, np.array([0.10, 0.20, 0.30]), np.clip(tr[:, 1], 0.0, 1.0)[:, None])
+            col = _mix(col, np.array([0.02, 0.10, 0.30]), np.clip(tr[:, 2] * tr[:, 2], 0.0, 1.0)[:, None])
+            col = _mix(col, np.array([0.30, 0.10, 0.02]), np.clip(np.power(tr[:, 3], 6.0), 0.0, 1.0)[:, None])
+            col = col * 0.5
+            col = col * (ph * 8.0)
+        else:                                                # MENGERSPONGE, frag:2362-2365
+            col = (0.5 + 0.5 * np.cos(np.array([0.0, 1.0, 2.0]) + 2.0 * tr[:, 2:3])) * ph
+        rgb[hit], P[hit], N[hit] = col, p, pn
+    return rgb, ~hit, P, N
+
+
 def render_frame(tables, settings, W, H):
-    """fragColor of every pixel, (H, W, 4) float64, row 0 = bottom (gl_FragCoord convention)."""
-    assert tables.num_objects == 1 and tables.objects[0].type == RM_MANDELBULB and tables.objects[0].texLoc == -1
-    assert not (settings.enableSoftShadow or settings.enableAmbientOcclusion or settings.enableReflection or settings.enableRefraction
-                or settings.enableSkyBox) and not tables.globals_.isTwoD
+    """fragColor of every pixel, (H, W, 4) float64, row 0 = bottom (gl_FragCoord convention): a table of one Mandelbulb or one
+    Menger sponge under directional lights; main's reflection loop (frag:2491-2524) when it is enabled."""
+    assert tables.num_objects == 1 and tables.objects[0].type in (RM_MANDELBULB, RM_MENGERSPONGE) and tables.objects[0].texLoc == -1
+    assert not (settings.enableSoftShadow or settings.enableAmbientOcclusion or settings.enableRefraction or settings.enableSkyBox)
+    assert not tables.globals_.isTwoD and settings.features & RM_FEAT_WHITE_BACKGROUND
     o = tables.objects[0]
     obj = {"cAmbient": np.array(list(o.cAmbient), np.float64), "cDiffuse": np.array(list(o.cDiffuse), np.float64),
            "cSpecular": np.array(list(o.cSpecular), np.float64), "shininess": float(o.shininess)}
+    c_refl = np.array(list(o.cReflective), np.float64)
     assert not o.isEmissive
     lights = []
     for i in range(tables.num_lights):
@@ -203,8 +264,11 @@ def render_frame(tables, settings, W, H):
         assert li.type == RM_LIGHT_DIRECTIONAL
         lights.append({"dir": np.array(list(li.dir), np.float64), "color": np.array(list(li.color), np.float64)})
     gl = tables.globals_
-    sd = Bulb(np.array(list(o.invModel), np.float64).reshape(4, 4).T, o.scaleFactor, gl.power, settings.fractalIters,
-              (gl.juliaSeed[0], gl.juliaSeed[1]))
+    inv_model = np.array(list(o.invModel), np.float64).reshape(4, 4).T
+    if o.type == RM_MANDELBULB:
+        kind, sd = "bulb", Bulb(inv_model, o.scaleFactor, gl.power, settings.fractalIters, (gl.juliaSeed[0], gl.juliaSeed[1]))
+    else:
+        kind, sd = "menger", Menger(inv_model, o.scaleFactor, settings.mengerLevels, gl.iTime)
     inv_pv = np.array(list(tables.camera.invProjView), np.float64).reshape(4, 4).T  # column-major storage
     far = float(tables.camera.initialFar)
     # raymarch.vert:13-25: nearClip / farClip are affine in the quad position, so their interpolated value at a pixel centre
@@ -215,22 +279,23 @@ def render_frame(tables, settings, W, H):
     farc = np.concatenate([ndc, np.ones((len(ndc), 1)), np.ones((len(ndc), 1))], -1) @ inv_pv.T
     ro = near[:, :3] / near[:, 3:]                      # setScene, frag:2388-2392
     rd = _normalize(farc[:, :3] / farc[:, 3:] - ro)
-    assert settings.features & RM_FEAT_WHITE_BACKGROUND
     bg = np.array([1.0, 1.0, 1.0])                      # WHITE_BACKGROUND, frag:2414-2416
-    out = np.empty((len(ndc), 4))
-    out[:, :3], out[:, 3] = bg, 1.0                     # render's miss: vec4(bgCol, 1), frag:2323-2329
-    hit, depth, trap = raymarch(sd, ro, rd, far, settings.maxSteps)
-    if hit.any():
-        p = ro[hit] + rd[hit] * depth[hit, None]        # frag:2333
-        pn = get_normal(sd, p)
-        if settings.features & RM_FEAT_PERLIN_BUMP:     # #define PERLIN_BUMP (frag:15, 2334-2336)
-            pn = bump_normal(pn, p)
-        tr = trap[hit]
-        col = np.full((len(p), 3), 0.2)                 # frag:2354-2361
-        col = _mix(col, np.array([0.10, 0.20, 0.30]), np.clip(tr[:, 1], 0.0, 1.0)[:, None])
-        col = _mix(col, np.array([0.02, 0.10, 0.30]), np.clip(tr[:, 2] * tr[:, 2], 0.0, 1.0)[:, None])
-        col = _mix(col, np.array([0.30, 0.10, 0.02]), np.clip(np.power(tr[:, 3], 6.0), 0.0, 1.0)[:, None])
-        col = col * 0.5
-        col = col * (get_phong(sd, pn, obj, lights, (gl.ka, gl.kd, gl.ks), p, rd[hit], far, settings.maxSteps) * 8.0)
-        out[hit, :3] = col                              # main: phong + refl + refr with both zero, frag:2478, 2570-2572
-    return out.reshape(H, W, 4), hit.reshape(H, W)
+    out = np.ones((len(ndc), 4))
+    rgb, is_env, P, N = render_rays(sd, kind, obj, lights, gl, ro, rd, far, settings, bg)  # frag:2443
+    out[:, :3] = rgb                                    # a miss returns here (frag:2459-2465); a hit: phong = ri.fragColor
+    if settings.enableReflection and np.sqrt(_dot(c_refl, c_refl)) != 0.0:  # frag:2491-2524
+        idx = np.nonzero(~is_env)[0]
+        p, n, d = P[idx], N[idx], rd[idx]
+        fil = np.ones(3)
+        for _ in range(settings.numReflection):
+            if len(idx) == 0:
+                break
+            r = d - 2.0 * _dot(n, d)[:, None] * n       # reflect(info.rd, info.n)
+            sro = p + r * SURFACE_DIST * 3.0
+            fil = fil * c_refl                          # the FIRST hit's material throughout (frag:2500-2501), one object here
+            rgb, env, P2, N2 = render_rays(sd, kind, obj, lights, gl, sro, r, far, settings, bg)
+            out[idx, :3] += gl.ks * fil * rgb           # refl += vec4(ks·fil·res.rgb, 1)
+            out[idx, 3] += 1.0
+            go = ~env                                   # `if (res.isEnv) break;`
+            idx, p, n, d = idx[go], P2[go], N2[go], r[go]
+    return out.reshape(H, W, 4), (~is_env).reshape(H, W)
