@@ -313,13 +313,16 @@ RM_DEV float sdSierpinski(V3 p) {
 // compiler's own v_max_f32 with |·| source modifiers / v_min3_f32 give the contract's bits (same comparator as the v_min_f32 /
 // v_max_f32 pair of rm_math, no NaN-quieting prologue needed) — and, unlike the inline-asm spellings, carry no hazard s_nops.
 // TRAP = false (shadow marches, normal and AO taps) drops the orbit-trap bookkeeping (res is then unspecified).
-template <bool TRAP>
-RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
+// LEVELS > 0 / STILL = true: the level count and ani == 0 as COMPILE-TIME facts — the levels are then one basic block with no
+// scalar branch between them (their candidates c are independent of one another; only the final compare / select chain is
+// serial), which is worth more than the branches look: see sdMengerSponge below.  LEVELS = 0: both read at run time.
+template <bool TRAP, int LEVELS, bool STILL>
+RM_DEV float mengerImpl(const SceneBlock *sb, V3 p, V4 &res) {
   float d = sdBox(p, 1.0f, 1.0f, 1.0f);
   float ty = 1.0f, tz = 0.0f;
   const float ani = sb->mengerAni, off = sb->mengerOff;  // scene_prep_kernel (rm_kernels.hip): the prologue's uniforms
-  const int levels = sb->s.mengerLevels;
-  const bool still = ani == 0.0f;  // wave-uniform (scalar loads)
+  const int levels = LEVELS > 0 ? LEVELS : sb->s.mengerLevels;
+  const bool still = STILL || ani == 0.0f;  // wave-uniform (scalar loads)
   // one level (frag:1057-1069); hs = 0.5·s = 0.5·3^m and the divisor 3^(m+1) as compile-time constants (DIVC > 0)
   auto level = [&](int m, float divc, float hs, float sNext) __attribute__((always_inline)) {
     if (!still) {
@@ -361,6 +364,17 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
   }
   res = v4(d, ty, tz, 0.0f);
   return d;
+}
+// The two level counts that occur (the shader's 4, BASELINE config 5's 5) at iTime = 0 get their own straight-line instantiation,
+// chosen by a wave-uniform test; everything else takes the generic one.  Same bits.
+template <bool TRAP>
+RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
+  const int levels = sb->s.mengerLevels;
+  if (sb->mengerAni == 0.0f) {
+    if (levels == 5) return mengerImpl<TRAP, 5, true>(sb, p, res);
+    if (levels == 4) return mengerImpl<TRAP, 4, true>(sb, p, res);
+  }
+  return mengerImpl<TRAP, 0, false>(sb, p, res);
 }
 
 // ---- scene union (frag:1406-1430) ---------------------------------------------------------------------
