@@ -330,6 +330,54 @@ def reflect_refract_scene(W, H):
     return cam, objs, 4, lights, 2, h.make_globals(kt=0.8)
 
 
+def test_kernels_without_secondary_rays_pick_up_exactly_where_they_may(renderer):
+    """The launcher compiles main's reflection loop and refraction out (render_kernel<…, SEC = false>) when they cannot fire for
+    any pixel: reflection off, or on with zero bounces, or no reflective material; refraction off or no transparent material.
+    Every combination around that decision — for the table walk, the bulb class, the sampler kernel and the layer kernel — is the
+    oracle's frame bit for bit, and frames that differ only in a switch that cannot matter are identical to each other."""
+    W, H = 80, 48
+    cam, objs, no, lights, nl, g = reflect_refract_scene(W, H)
+
+    def variant(reflective, transparent):
+        o = (abi.RmObject * no)(*[abi.RmObject.from_buffer_copy(bytes(objs[i])) for i in range(no)])
+        for i in range(no):
+            for k in range(3):
+                if not reflective:
+                    o[i].cReflective[k] = 0.0
+                if not transparent:
+                    o[i].cTransparent[k] = 0.0
+        return (cam, o, no, lights, nl, g)
+
+    frames = {}
+    for mat in ((1, 1), (1, 0), (0, 1), (0, 0)):
+        scene = variant(*mat)
+        for refl, nb, refr in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 1, 1), (1, 2, 1), (1, 0, 1)):
+            s = abi.default_settings(enableReflection=refl, numReflection=nb, enableRefraction=refr)
+            ref, ref_b = h.oracle_render(scene, s, W, H, bright=True)
+            out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
+            assert_bit_equal(out.cpu().numpy(), ref, f"materials {mat}, reflection {refl} x{nb}, refraction {refr}")
+            assert_bit_equal(br.cpu().numpy(), ref_b, f"materials {mat}, reflection {refl} x{nb}, refraction {refr} bright")
+            frames[(mat, refl, nb, refr)] = out
+    # switches that cannot matter: reflection on with zero bounces or without a reflective material adds 0 to rgb (alpha aside)
+    assert _ieq(frames[((0, 0), 0, 1, 0)][..., :3].contiguous(), frames[((0, 0), 1, 2, 1)][..., :3].contiguous())
+    assert _ieq(frames[((1, 0), 0, 1, 0)][..., :3].contiguous(), frames[((1, 0), 1, 0, 0)][..., :3].contiguous())
+    # the other kernel classes: a bulb (reflective material, reflection off / on), a textured scene, the procedural layers
+    bulb = h.scene_mandelbulb(W, H)
+    for k in range(3):
+        bulb[1][0].cReflective[k] = 0.5
+    for s in (abi.default_settings(fractalIters=8), abi.default_settings(fractalIters=8, enableReflection=1),
+              abi.default_settings(fractalIters=8, enableReflection=1, numReflection=0)):
+        assert_bit_equal(renderer.render(tables_of(bulb), s, W, H).cpu().numpy(), h.oracle_render(bulb, s, W, H), "bulb class")
+    for name in ("skybox_reflect", "sea_sky"):
+        scene, s, res = resource_case(name, W, H)
+        for refl in (0, 1):
+            s.enableReflection, s.enableRefraction = refl, refl
+            t = tables_of(scene)
+            for k, v in res.items():
+                setattr(t, k, v)
+            assert_bit_equal(renderer.render(t, s, W, H).cpu().numpy(), h.oracle_render(scene, s, W, H, **res), f"{name} secondary {refl}")
+
+
 @pytest.mark.parametrize("bounces", [1, 2])
 def test_reflection_refraction_bit_exact(renderer, bounces):
     W, H = 96, 64
