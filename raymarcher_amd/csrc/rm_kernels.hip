@@ -841,9 +841,14 @@ bool all_primitives(const RmObject *objs, int numObjects) {
   for (int i = 0; i < numObjects; i++) prim = prim && objs[i].type >= RM_CUBE && objs[i].type <= RM_RECTANGLE;
   return prim;
 }
-bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels) {
+// Size threshold: whole frames and row ranges from 2^22 pixels (one launch after the other on a stream: 4K and up).  Row-TILE
+// shards (rm_render_tiles with numShards > 1) come from multi-GPU hosts, which keep several frames in flight per GPU
+// (dist.FramePipeline, scripts/mgpu_host.cpp): the pipeline's dozen launches per frame then overlap those of its neighbours and
+// it pays from 2^21 pixels — measured on shards of the C5 scene with three frames in flight (profiles/r04_j_c5_shards.md):
+// 4.18 M pixels (1/8 of the 8K frame) 3.41 against 4.34 ms per frame, 2.09 M 2.47 against 2.73, 1.04 M 1.70 against 1.44.
+bool wavefront_pays(const RmObject *objs, int numObjects, int bounces, size_t pixels, bool tileShard) {
   if (all_primitives(objs, numObjects)) return false;
-  return bounces >= (skip_applies(objs, numObjects) ? 2 : 1) && pixels >= (size_t(1) << 22);
+  return bounces >= (skip_applies(objs, numObjects) ? 2 : 1) && pixels >= (size_t(1) << (tileShard ? 21 : 22));
 }
 
 int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -890,7 +895,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   for (int i = 0; i < numObjects; i++) anyTransparent = anyTransparent || nonzero3(objs[i].cTransparent);
   const bool secondary = (s->enableReflection && anyReflective && s->numReflection > 0) || (s->enableRefraction && anyTransparent);
   const bool wfSkip = skip_applies(objs, numObjects);
-  bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W)));
+  bool wavefront = wfOk && (pathReq == 5 || (pathReq == 0 && wavefront_pays(objs, numObjects, wfBounces, (size_t)nRows * W, map.numShards > 1)));
   // The wavefront pipeline's knobs and records, settled BEFORE anything below depends on `wavefront`: if its workspace
   // (≈(160 + 4·numLights) B per hit slot, grow-only per (device, stream): 5.8 GB for an 8K frame) cannot be had, the
   // auto-selected launch falls back to render_kernel — identical bits, no workspace — and only an explicit path-5 request

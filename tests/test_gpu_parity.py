@@ -1017,9 +1017,14 @@ def test_config5_menger_8k_reflection(renderer):
     s = abi.default_settings(mengerLevels=5, numReflection=2, enableReflection=1)
     full = renderer.render(t, s, W, H)
     k = 5
+    assert lib().rm_debug_last_path() == 5
     mine = renderer.render_tiles(t, s, W, H, T, k, N)
+    # a row-TILE shard of 4.1 M pixels takes the wavefront pipeline too (multi-GPU hosts keep frames in flight: threshold 2^21)
+    assert lib().rm_debug_last_path() == 5
     rows = [lib().rm_shard_row_to_frame(H, T, k, N, i) for i in range(mine.shape[0])]
     assert _ieq(mine, full[torch.tensor(rows, device=full.device)])
+    band = renderer.render(t, s, W, H, row_begin=1000, row_end=1000 + mine.shape[0])  # the same pixel count as a plain row range: 2^22 applies
+    assert lib().rm_debug_last_path() == 1 and _ieq(band, full[1000:1000 + mine.shape[0]])
     for r0 in (2160, 3000):
         ref = h.oracle_render(_scene_tuple(t), s, W, H, r0, r0 + 8, threads=16)
         assert_bit_equal(full[r0:r0 + 8].cpu().numpy(), ref, f"8K rows {r0}..{r0 + 8}")
