@@ -23,6 +23,9 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "g"
     traffic, rows = {}, []
     pmc = json.load(open(os.path.join(SRC, "pmc.json"))) if os.path.exists(os.path.join(SRC, "pmc.json")) else {}
+    # a partial re-run (scripts/gpu_r4_final.sh c5) refreshes its configurations only: the others keep what profiles/ holds
+    old_pmc = json.load(open(os.path.join(PRO, "r04_pmc.json"))) if os.path.exists(os.path.join(PRO, "r04_pmc.json")) else {}
+    old_traffic = json.load(open(os.path.join(PRO, "r04_hbm_traffic.json"))) if os.path.exists(os.path.join(PRO, "r04_hbm_traffic.json")) else {}
     for c, (W, H) in SIZES.items():
         b = os.path.join(SRC, f"{c}_bench.json")
         if not os.path.exists(b):
@@ -33,7 +36,12 @@ def main():
                 shutil.copy(s, os.path.join(PRO, f"r04_{tag}_{c}_{suffix}"))
         d = last_json_line(b)
         hj = os.path.join(SRC, f"{c}.json")
-        if os.path.exists(hj):
+        fresh = os.path.exists(hj) and os.path.getmtime(hj) >= os.path.getmtime(b) - 3600
+        if c not in pmc and c in old_pmc:
+            pmc[c] = old_pmc[c]
+        if not fresh and c in old_traffic:
+            traffic[c] = old_traffic[c]
+        elif os.path.exists(hj):
             t = json.load(open(hj))[c]
             if not t.get("frames_profiled"):
                 # scripts/hbm_summary.py did not recognise the primary kernel's name (fixed since: `wf_march_kernel<0, false>`): the
@@ -63,12 +71,22 @@ def main():
                     + f" | {d.get('cpu_baseline', {}).get('value', float('nan')):.2f} | "
                     + ", ".join(f"{k} {v['value']:.0f}" for k, v in d.get("variants", {}).items()) + " |")
     if traffic:
-        json.dump(traffic, open(os.path.join(PRO, "r04_hbm_traffic.json"), "w"), indent=1)
+        json.dump(dict(sorted(traffic.items())), open(os.path.join(PRO, "r04_hbm_traffic.json"), "w"), indent=1)
     if pmc:
-        json.dump(pmc, open(os.path.join(PRO, "r04_pmc.json"), "w"), indent=1)
+        json.dump(dict(sorted(pmc.items())), open(os.path.join(PRO, "r04_pmc.json"), "w"), indent=1)
     t = os.path.join(SRC, "pmc_table.md")
-    if os.path.exists(t):
-        with open(os.path.join(PRO, f"r04_{tag}_configs_pmc.md"), "w") as f:
+    md = os.path.join(PRO, f"r04_{tag}_configs_pmc.md")
+    if os.path.exists(t) and os.path.exists(md):
+        new_rows = [ln for ln in open(t).read().splitlines() if ln.startswith("| c")]
+        cfgs = {ln.split("|")[1].strip() for ln in new_rows}
+        old = open(md).read().splitlines()
+        keep = [ln for ln in old if not (ln.startswith("| c") and ln.split("|")[1].strip() in cfgs)]
+        body = [ln for ln in keep if ln.startswith("| c")] + new_rows
+        head = [ln for ln in keep if not ln.startswith("| c")]
+        with open(md, "w") as f:
+            f.write("\n".join(head).rstrip("\n") + "\n" + "\n".join(sorted(body)) + "\n")
+    elif os.path.exists(t):
+        with open(md, "w") as f:
             f.write("# PMC per kernel of every bench configuration, round-4 final build (`scripts/gpu_r4_final.sh` → `scripts/gpu_pmc_configs3.sh`: "
                     "rocprofv3 --pmc over `bench.py --config cN --steps 3 --warmup 1`, three counter sets in separate passes; production kernels; "
                     "per-launch averages incl. the cold first frame, profiled clocks)\n\nlanes live = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU); "
