@@ -317,6 +317,9 @@ def main():
     ap.add_argument("--gather", choices=["float4", "rgba8"], default="float4",
                     help="N > 1: what travels to rank 0 — the float4 tiles (16 B/pixel; every frame ends as a float4 frame on rank 0) or "
                          "their 8-bit conversion (4 B/pixel; every frame ends as the RGBA8 image saveViewportImage would write)")
+    ap.add_argument("--gather-root", choices=["zero", "rotate"], default="zero",
+                    help="N > 1: where frames end — every frame on rank 0 (default; SURVEY §8e), or frame i on rank i mod N, which spreads "
+                         "the root's receive traffic and de-interleave pass over the ranks (also timed as variants.rotating_root)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (RCCL process group, pipelined gather, de-interleave) even with one rank: "
                          "a rehearsal of the multi-GPU path on a one-GPU box")
@@ -356,21 +359,23 @@ def main():
     # three frames in flight, each on its own stream: the renders of consecutive frames overlap as well (a shard's frame
     # cannot end before its longest ray chain, ≈0.7–0.9 ms, which is 3× the shard's work at N = 8; dist.FramePipeline)
     rgba8 = distributed and args.gather == "rgba8"
-    if rgba8:
-        # the shard's float4 tiles stay on its GPU (one buffer per frame slot); their 8-bit conversion travels
-        tiles32 = [torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device) for _ in range(3)]
-        pipe = FramePipeline(plan, rank, (W, 4), torch.uint8, r.device, depth=3, multi_stream=True,
-                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave_rgba8(g, W, H, TILE_ROWS, world, slot_rows)))
-    else:
-        pipe = FramePipeline(plan, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True,
-                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows))) \
-            if distributed else None
+    tiles32 = [torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device) for _ in range(3)] if rgba8 else None
+
+    def make_pipe(rotate):
+        """frame i is gathered to rank 0 — or, rotate: to rank i mod world (dist.FramePipeline) — and de-interleaved there"""
+        if rgba8:  # the shard's float4 tiles stay on its GPU (one buffer per frame slot); their 8-bit conversion travels
+            return FramePipeline(plan, rank, (W, 4), torch.uint8, r.device, depth=3, multi_stream=True, rotate_root=rotate,
+                                 finish=lambda g: frame_holder.__setitem__("f", r.deinterleave_rgba8(g, W, H, TILE_ROWS, world, slot_rows)))
+        return FramePipeline(plan, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True, rotate_root=rotate,
+                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows)))
+    pipes = {"current": make_pipe(args.gather_root == "rotate") if distributed else None}
     submitted = [0]
 
     def step():
         if not distributed:
             frame_holder["f"] = r.render(tables, settings, W, H, out=mine)
             return
+        pipe = pipes["current"]
         if rgba8:
             buf = tiles32[submitted[0] % 3]
             submitted[0] += 1
@@ -381,7 +386,7 @@ def main():
 
     def fence():
         if distributed:
-            pipe.drain()
+            pipes["current"].drain()
         torch.cuda.synchronize(r.device)
         if distributed:
             dist.barrier()
@@ -412,6 +417,26 @@ def main():
     kernel_ms = float(kmax.item())
 
     variants = {}
+    if distributed and not args.no_variants and args.gather_root == "zero":
+        # the same frames with the gather's root rotating over the ranks (frame i ends on rank i mod N): rank 0 is then no longer
+        # the one rank that receives N − 1 slots and de-interleaves the whole frame every frame; never `value`
+        pipes["current"] = make_pipe(True)
+        for _ in range(min(args.warmup, 3) + world):
+            step()
+        fence()
+        t0r = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dtr = torch.tensor([time.perf_counter() - t0r], dtype=torch.float64, device=r.device)
+        dist.all_reduce(dtr, op=dist.ReduceOp.MAX)
+        same = None
+        if rank == 0 and "f" in frame_holder:  # the last frame rank 0 was the root of
+            same = bool(torch.equal(frame_holder["f"], timed_frame))
+        variants["rotating_root"] = {"value": round(W * H * args.steps / float(dtr.item()) / 1e6, 2), "unit": "Mpixels/s",
+                                     "ms_per_step": round(float(dtr.item()) / args.steps * 1e3, 4), "steps": args.steps,
+                                     "frame_identical_to_headline": same,
+                                     "what": "FramePipeline(rotate_root=True): frame i is gathered to and de-interleaved on rank i mod N"}
     single = not distributed and not args.no_variants
     nv = max(3, min(args.steps, 10))
     if single and schedule == 1 and cfg in ("c2", "c3", "c4", "c5"):
@@ -563,7 +588,8 @@ def main():
             "config": {"workload": desc["workload"], "baseline_config": desc["baseline_config"], "name": cfg,
                        "rows": "whole frame" if not distributed else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; three frames in "
                                "flight per GPU on three streams (renders of consecutive frames overlap, RCCL gather of frame i "
-                               "to rank 0 runs under later renders); every frame de-interleaved on rank 0"
+                               + ("to rank 0 runs under later renders); every frame de-interleaved on rank 0" if args.gather_root == "zero" else
+                                  "to rank i mod N runs under later renders); every frame de-interleaved on its root")
                                + (" as the RGBA8 image (4 B/pixel gathered)" if rgba8 else " as a float4 frame (16 B/pixel gathered)"),
                        "tile_order": ("feedback: each frame records its tiles' shader-cycle costs, the next frame starts heavy tiles first "
                                       "(same pixels, same work; variants.raster_tile_order = no history, variants.orbiting_camera = a "

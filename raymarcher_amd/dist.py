@@ -63,13 +63,19 @@ class FramePipeline:
     (measured: 0.95 ms per shard-frame on one stream, 0.27–0.31 ms with three frames in flight on three streams;
     scripts/shard_probe.py).  The library keeps scratch and the tile-order feedback per stream, so the slots do not interfere."""
 
-    def __init__(self, plan, rank, slot_shape, dtype, device, finish=None, depth=2, multi_stream=False):
+    def __init__(self, plan, rank, slot_shape, dtype, device, finish=None, depth=2, multi_stream=False, rotate_root=False):
+        """rotate_root=False: every frame is gathered to rank 0 (what a host that shows or saves frames from one
+        process wants).  rotate_root=True: frame i is gathered to rank i mod world and `finish` runs there — every frame still
+        ends as ONE complete frame on ONE GPU, but the root's extra work (receiving world − 1 slots over its xGMI links, the
+        de-interleave pass over the whole frame) is spread over the ranks instead of making rank 0 the longest pole of every
+        frame (profiles/r04_i_submit_rate.md: rank 0 bounds the headline's N = 8 scaling at ≈5.9 ×)."""
         import torch
         assert depth >= 2
-        self.plan, self.rank, self.finish, self.depth = plan, rank, finish, depth
+        self.plan, self.rank, self.finish, self.depth, self.rotate = plan, rank, finish, depth, bool(rotate_root)
         self.local = [torch.zeros((plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.gathered = [torch.empty((plan.world * plan.slot_rows,) + tuple(slot_shape), dtype=dtype, device=device)
-                         for _ in range(depth)] if rank == 0 else [None] * depth
+                         for _ in range(depth)] if (rank == 0 or rotate_root) else [None] * depth
+        self.root_of = [0] * depth  # the root of the frame each slot holds
         # the per-rank views of every gather buffer, made once (submit() runs several thousand times a second at N = 8)
         self.outs = [list(g.view(plan.world, plan.slot_rows, *tuple(slot_shape)).unbind(0)) if g is not None else None for g in self.gathered]
         self.work = [None] * depth
@@ -93,19 +99,18 @@ class FramePipeline:
             self.work[b].wait()
             self.work[b] = None
             self.frames_finished += 1
-            if self.rank == 0 and self.finish is not None:
+            if self.rank == self.root_of[b] and self.finish is not None:
                 self.finish(self.gathered[b])
 
     def submit(self, render_into):
         import torch.distributed as dist
         b = self.i % self.depth
         self._join(b)                       # frame i-depth used this slot (normally already joined below)
+        root = (self.i % self.plan.world) if self.rotate else 0
+        self.root_of[b] = root
         with self._on(b):
             render_into(self.local[b])
-            if self.rank == 0:
-                self.work[b] = dist.gather(self.local[b], self.outs[b], dst=0, async_op=True)
-            else:
-                self.work[b] = dist.gather(self.local[b], None, dst=0, async_op=True)
+            self.work[b] = dist.gather(self.local[b], self.outs[b] if self.rank == root else None, dst=root, async_op=True)
         if self.i >= self.depth - 1:        # finish the oldest frame in flight while the newer ones render / travel
             self._join((self.i - (self.depth - 1)) % self.depth)
         self.i += 1

@@ -66,7 +66,8 @@ rows = torch.tensor(plan.frame_rows(rank), dtype=torch.float32)
 frames = []
 DEPTH = int(os.environ.get("RM_TEST_DEPTH", "2"))
 DT = torch.uint8 if os.environ.get("RM_TEST_DTYPE") == "uint8" else torch.float32   # bench.py --gather rgba8 moves bytes
-pipe = FramePipeline(plan, rank, (W, 4), DT, torch.device("cpu"), depth=DEPTH,
+ROTATE = os.environ.get("RM_TEST_ROTATE") == "1"   # frame k is gathered to rank k mod world instead of rank 0
+pipe = FramePipeline(plan, rank, (W, 4), DT, torch.device("cpu"), depth=DEPTH, rotate_root=ROTATE,
                      finish=lambda g: frames.append(deinterleave_host(g, plan).clone()))
 for k in range(K):
     def render_into(slot, k=k):   # pixel value = 1000·frame + frame row: any mix-up of slots, frames or rows shows
@@ -75,11 +76,11 @@ for k in range(K):
     assert pipe.frames_finished == max(k - (DEPTH - 2), 0), (k, pipe.frames_finished)   # frame k-(DEPTH-1) is joined inside submit(k)
 pipe.drain()
 ok = pipe.frames_finished == K
-if rank == 0:
-    ok = ok and len(frames) == K
-    for k, f in enumerate(frames):
-        want = ((1000.0 if DT is torch.float32 else 50.0) * k + torch.arange(H, dtype=torch.float32))[:, None, None].expand(H, W, 4).to(DT)
-        ok = ok and f.dtype == DT and bool((f == want).all())
+mine = [k for k in range(K) if (k % world if ROTATE else 0) == rank]   # the frames this rank is the root of, in order
+ok = ok and len(frames) == len(mine)
+for k, f in zip(mine, frames):
+    want = ((1000.0 if DT is torch.float32 else 50.0) * k + torch.arange(H, dtype=torch.float32))[:, None, None].expand(H, W, 4).to(DT)
+    ok = ok and f.dtype == DT and bool((f == want).all())
 flag = torch.tensor([1 if ok else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.barrier()
@@ -88,14 +89,16 @@ sys.exit(0 if int(flag.item()) == 1 else 3)
 '''
 
 
-@pytest.mark.parametrize("world,depth,dtype", [(2, 2, "float32"), (4, 2, "float32"), (2, 3, "float32"), (3, 4, "float32"), (2, 3, "uint8")])
-def test_frame_pipeline_gloo(world, depth, dtype, tmp_path):
+@pytest.mark.parametrize("world,depth,dtype,rotate", [(2, 2, "float32", 0), (4, 2, "float32", 0), (2, 3, "float32", 0), (3, 4, "float32", 0),
+                                                      (2, 3, "uint8", 0), (3, 3, "float32", 1), (4, 2, "float32", 1), (2, 3, "uint8", 1)])
+def test_frame_pipeline_gloo(world, depth, dtype, rotate, tmp_path):
     """The pipelined gather bench.py uses for N > 1 (`depth` frames in flight: frame i's gather under the renders of the
-    frames after it): every frame arrives complete, in order, through the right slot."""
+    frames after it): every frame arrives complete, in order, through the right slot — on rank 0, or with rotate_root on rank
+    i mod world for frame i."""
     script = tmp_path / "pipe_worker.py"
     script.write_text(PIPE_WORKER.format(root=ROOT))
-    port = 29900 + world + 10 * depth + (os.getpid() % 400)
+    port = 29900 + world + 10 * depth + 50 * rotate + (os.getpid() % 400)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth), RM_TEST_DTYPE=dtype), capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth), RM_TEST_DTYPE=dtype, RM_TEST_ROTATE=str(rotate)), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

@@ -35,7 +35,8 @@ def run_bench(*flags):
     (("--config", "c3", "--steps", "3", "--warmup", "1"), 3840 * 2160),
     (("--config", "c3", "--steps", "3", "--warmup", "1", "--gather", "rgba8"), 3840 * 2160),
     (("--config", "c5", "--steps", "2", "--warmup", "1"), 7680 * 4320),
-], ids=["c3_float4", "c3_rgba8", "c5_float4"])
+    (("--config", "c3", "--steps", "3", "--warmup", "1", "--gather-root", "rotate"), 3840 * 2160),
+], ids=["c3_float4", "c3_rgba8", "c5_float4", "c3_rotating_root"])
 def test_bench_distributed_branch_in_a_child_process(flags, px):
     line = run_bench(*flags)
     assert line["n_gpus"] == 1 and line["steps"] == int(flags[3]) and line["unit"] == "Mpixels/s" and line["scaling"] == "strong"
@@ -49,3 +50,8 @@ def test_bench_distributed_branch_in_a_child_process(flags, px):
     assert "three frames in flight" in line["config"]["rows"]
     assert ("RGBA8" in line["config"]["rows"]) == ("rgba8" in flags)
     assert "cpu_baseline" not in line
+    if "rotate" in flags:
+        assert "on its root" in line["config"]["rows"] and "rotating_root" not in line["variants"]
+    else:  # the rotating-root pipeline is timed beside the headline and delivers the same frame
+        v = line["variants"]["rotating_root"]
+        assert v["value"] > 0 and v["frame_identical_to_headline"] is True
