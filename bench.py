@@ -259,8 +259,9 @@ def timed_frames(r, L, fence, render, n):
 
 def orbit_variant(r, L, fence, t, s, W, H, frames=24, deg=1.0):
     """A moving sequence: the camera orbits the scene by `deg` degrees per frame (the reference's interactive use,
-    src/realtime.cpp:235-281).  The tile-order feedback then works from a slightly different picture; timed with the
-    feedback on and off, and two frames of the sequence are checked bit for bit against renders without any history."""
+    src/realtime.cpp:235-281).  Every frame is a NEW picture, so its tiles are ordered by the geometric classification
+    (tile_geom_kernel: rings of the objects' bounding balls first) combined with the previous frame's stale costs; timed against
+    raster order, and two frames of the sequence are checked bit for bit against renders in raster order."""
     import math
     import torch
     from raymarcher_amd import Scene, abi, scenes
@@ -299,7 +300,8 @@ def orbit_variant(r, L, fence, t, s, W, H, frames=24, deg=1.0):
     return {"value": round(W * H / res["feedback"] / 1e3, 2), "unit": "Mpixels/s", "ms_per_step": round(res["feedback"], 4),
             "ms_per_step_raster_order": round(res["raster"], 4), "frames": frames, "degrees_per_frame": deg,
             "frame_identical_with_and_without_history": same,
-            "what": "camera orbiting the bulb, every frame a new picture: tile order from the PREVIOUS frame's costs against raster order"}
+            "what": "camera orbiting the bulb, every frame a new picture: tiles ordered by the geometric classification of the frame's own "
+                    "scene and camera combined with the previous frame's (stale) costs, against raster order"}
 
 
 def main():
@@ -476,7 +478,7 @@ def main():
                                               "steps": nf, "frames_identical_to_headline": same,
                                               "what": "the same frames submitted round-robin on three HIP streams (three in flight)"}
         if cfg == "c3":
-            variants["orbiting_camera"] = orbit_variant(r, L, fence, tables, settings, W, H)
+            variants["orbiting_camera"] = orbit_variant(r, L, fence, tables, settings, W, H, deg=float(os.environ.get("RM_ORBIT_DEG", "1.0")))
     if single and schedule == 5:
         # the same frame by the one-lane-per-pixel kernel (rm_set_kernel_path(1)); the headline ran the wavefront pipeline
         L.rm_set_kernel_path(1)
@@ -591,9 +593,10 @@ def main():
                                + ("to rank 0 runs under later renders); every frame de-interleaved on rank 0" if args.gather_root == "zero" else
                                   "to rank i mod N runs under later renders); every frame de-interleaved on its root")
                                + (" as the RGBA8 image (4 B/pixel gathered)" if rgba8 else " as a float4 frame (16 B/pixel gathered)"),
-                       "tile_order": ("feedback: each frame records its tiles' shader-cycle costs, the next frame starts heavy tiles first "
-                                      "(same pixels, same work; variants.raster_tile_order = no history, variants.orbiting_camera = a "
-                                      "moving sequence)" if ordered else "not used by this schedule"),
+                       "tile_order": ("feedback: each frame records its tiles' shader-cycle costs and the next frame of the SAME picture starts heavy "
+                                      "tiles first; a new picture (first frame, moved camera) is ordered by a geometric classification instead "
+                                      "(same pixels, same work; variants.raster_tile_order = plain raster order, variants.orbiting_camera = "
+                                      "every frame a new picture)" if ordered else "not used by this schedule"),
                        "parity": "bit-exact vs CPU oracle (rm_math contract); vs the reference shader: unpinned, cross-checked (DESIGN §2)"},
             "roofline": roof,
             "variants": variants,

@@ -354,12 +354,15 @@ int rm_release_workspaces(unsigned long long *freedBytes);
 int rm_debug_last_path(void);
 /* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never
  * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely
- * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): feedback — every
- * frame records each tile's shader-cycle cost, and the next frame of the same size on the same stream starts its tiles
- * heaviest-first by those costs (the first frame, and the first after a change of size, run in raster order); mode 0:
- * always raster order; -1: back to the default / the RM_TILE_ORDER environment variable.  Applies to every launch of the
- * one-lane-per-pixel kernel with at least 2048 tiles (not to the 2-D Mandelbrot path, the bulb pipelines or the wavefront
- * pipeline, whose persistent waves balance themselves). */
+ * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): every frame records each
+ * tile's shader-cycle cost; the next frame of the same size on the same stream starts its tiles heaviest-first by those costs
+ * when it is the SAME picture (scene tables, camera, settings, rows), and otherwise — the first frame, a moved camera, a
+ * changed scene — by a geometric classification of the tiles (centre ray against the objects' bounding balls: silhouette rings
+ * first, interiors next, background last), combined with the stale costs where a frame of that size was rendered before;
+ * scenes with procedural layers or objects without a bound start new pictures in raster order.  mode 0: always raster order;
+ * -1: back to the default / the RM_TILE_ORDER environment variable.  Applies to every launch of the one-lane-per-pixel kernel
+ * with at least 2048 tiles (not to the 2-D Mandelbrot path or the wavefront pipeline, whose persistent waves balance
+ * themselves). */
 int rm_set_tile_order(int mode);
 /* Experiments: force a given launch order (d_order: a device permutation of 0..tileCount-1, or NULL) and / or collect the
  * tiles' costs (d_cost: tileCount device words, accumulated, or NULL) for subsequent launches on the current device. */

@@ -100,6 +100,11 @@ struct SceneBlock {
   float cullLip;  // Lipschitz bound of every object's distance value per unit of world length (+inf with a fractal in the table)
   float cullLo[3], cullHi[3];  // axis-aligned box with the same property (see scene_cull_ball); cullBoxOk = 0: none
   int32_t cullBoxOk;
+  // World-space bounding ball of every object (centre xyz, radius; filled by scene_cull_ball with the balls it derives anyway),
+  // objBallOk = 1 when every object has one: tile_geom_kernel classifies the tiles of a frame WITHOUT cost history by their
+  // centre ray's closest approach to these balls (rm_kernels.hip, "tile order").  Never read by the render kernels.
+  float objBall[RM_MAX_OBJECTS][4];
+  int32_t objBallOk;
   // Launch order of the workgroups (see rm_kernels.hip, "tile order"): workgroup b renders tile tileOrder[b] (a permutation
   // of 0..tileCount-1, heaviest tiles first) or tile b if null; tileCost (or null) accumulates every tile's shader-cycle cost.
   const int32_t *tileOrder;

@@ -224,6 +224,40 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict_
   }
 }
 
+// A frame WITHOUT usable history (the first of its size on a stream, or any frame whose scene or camera differs from the one that
+// recorded the costs): stand-in costs from geometry alone.  One thread per tile: the tile centre's primary ray against every
+// object's world-space bounding ball (SceneBlock::objBall) — closest approach inside [0.6·R, R + the tile's footprint] is a
+// silhouette candidate (the rays that graze an object march longest), inside 0.6·R an interior tile, anything else background;
+// the bucket sort above then starts rings first, interiors next, background last, raster order within a class.  Measured on cold
+// 4K frames (scripts/cold_order_probe.py, profiles/r04_k_geometric_order.md): bulb 2.85 → 2.26 ms (measured costs: 1.99),
+// directional_light_2.json 1.89 → 1.77-1.81, reflections_complex.json 8.70 → 8.39-8.44.  Same pixels.
+__global__ __launch_bounds__(256) void tile_geom_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H, int nRows, int tilesX,
+                                                        int tileW, int n, uint32_t *__restrict__ cost, int combine) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int x = (i % tilesX) * tileW + tileW / 2, r = (i / tilesX) * kBlockH + kBlockH / 2;
+  x = x < W ? x : W - 1;
+  r = r < nRows ? r : nRows - 1;
+  V3 ro, rd;
+  primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
+  // angle of one tile seen from the eye ≈ the distance between neighbouring tile centres' directions
+  V3 ro2, rd2;
+  primaryRay(sb, x < W - tileW ? x + tileW : x - tileW, map.frameRow(r), W, H, ro2, rd2);
+  const float foot = len(sub(rd2, rd));
+  int cls = 0;
+  const int no = sb->numObjects;
+  for (int k = 0; k < no; k++) {
+    const V3 v = v3(sb->objBall[k][0] - ro.x, sb->objBall[k][1] - ro.y, sb->objBall[k][2] - ro.z);
+    const float R = sb->objBall[k][3], tca = dot(v, rd);
+    const float q2 = dot(v, v) - tca * tca, hi = fma(foot, tca, R), lo = 0.6f * R;
+    if (tca > 0.0f && q2 <= hi * hi) cls = (q2 >= lo * lo) ? 2 : (cls > 1 ? cls : 1);
+  }
+  const uint32_t gv = cls == 2 ? (1u << 16) : (cls == 1 ? (1u << 11) : (1u << 4));
+  // combine: a frame of the same size rendered a DIFFERENT picture before (a moving camera) — its measured costs are stale but near;
+  // the heavier of the two estimates decides
+  cost[i] = (combine && cost[i] > gv) ? cost[i] : gv;
+}
+
 __global__ void probe_math_kernel(int fn, const float *x, const float *y, const float *z, float *out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -318,7 +352,11 @@ struct Slot {
   hipEvent_t done = nullptr;
   bool used = false;
 };
-struct TileOrderState { int tileCount = 0, W = 0, nRows = 0, nw = 0; void *mem = nullptr; };
+struct TileOrderState {
+  int tileCount = 0, W = 0, nRows = 0, nw = 0;
+  void *mem = nullptr;
+  unsigned long long sceneKey = 0;  // hash of the scene + camera + row map of the frame that recorded the costs in `mem`
+};
 struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (one stage) or 3 (tile-order sort + render kernel)
 struct DeviceState {
   std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
@@ -622,6 +660,7 @@ double sigma_max3(const double m[3][3]) {
 
 void scene_cull_ball(SceneBlock *h) {
   h->cullOk = 0;
+  h->objBallOk = 0;
   h->cullC[0] = h->cullC[1] = h->cullC[2] = 0.0f;
   h->cullR2 = 0.0f;
   h->cullR2Soft = 0.0f;
@@ -702,6 +741,16 @@ void scene_cull_ball(SceneBlock *h) {
     kappaSoft = ksi < kappaSoft ? ksi : kappaSoft;
     C[0] += cx[i] / n; C[1] += cy[i] / n; C[2] += cz[i] / n;
   }
+  for (int i = 0; i < n; i++) {  // the per-object balls, for the geometric tile order (the bulb's tight radius where it holds)
+    const RmObject &o = h->objs[i];
+    double r = rad[i];
+    if (o.type == RM_MANDELBULB) {
+      const double jx = h->g.juliaSeed[0], jy = h->g.juliaSeed[1];
+      if (o.scaleFactor >= 0.05f && jx * jx + jy * jy <= 1.2996) r = rad[i] * (1.15 / 2.1);
+    }
+    h->objBall[i][0] = (float)cx[i]; h->objBall[i][1] = (float)cy[i]; h->objBall[i][2] = (float)cz[i]; h->objBall[i][3] = (float)r;
+  }
+  h->objBallOk = 1;
   double R = 0.0;
   for (int i = 0; i < n; i++) {
     const double d = std::sqrt((cx[i] - C[0]) * (cx[i] - C[0]) + (cy[i] - C[1]) * (cy[i] - C[1]) + (cz[i] - C[2]) * (cz[i] - C[2])) + rad[i];
@@ -957,7 +1006,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
                        tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
   uint32_t *oCost = nullptr, *oHist = nullptr;
   int32_t *oOrder = nullptr;
-  bool haveCost = false;
+  bool haveCost = false, samePicture = false;
   if (ordered) {
     void *mem = nullptr;
     if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 8 + 256, &mem)) != RM_OK) return st;
@@ -965,16 +1014,37 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     oCost = oHist + 64;
     oOrder = reinterpret_cast<int32_t *>(oCost + tileCount);
     TileOrderState &ts = ds.tileOrder[stream];
-    const TileOrderState now{tileCount, W, nRows, nw, mem};
+    // the picture the recorded costs belong to: everything that decides a pixel (FNV-1a over the caller's tables and the row map)
+    unsigned long long key = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t nb) {
+      const unsigned char *b8 = static_cast<const unsigned char *>(p);
+      for (size_t k = 0; k < nb; k++) key = (key ^ b8[k]) * 1099511628211ull;
+    };
+    mix(cam, sizeof(*cam)); mix(g, sizeof(*g)); mix(s, sizeof(*s)); mix(&map, sizeof(map));
+    mix(objs, sizeof(RmObject) * (size_t)numObjects); mix(lights, sizeof(RmLight) * (size_t)numLights);
+    const TileOrderState now{tileCount, W, nRows, nw, mem, key};
     haveCost = ts.tileCount == now.tileCount && ts.W == W && ts.nRows == nRows && ts.nw == nw && ts.mem == mem;
     if (!haveCost) HIP_OK(hipMemsetAsync(oCost, 0, (size_t)tileCount * 4, stream));
+    samePicture = haveCost && ts.sceneKey == key;
     ts = now;
   }
+  // Which order this frame's tiles start in: the previous frame's measured costs when it was the same picture; otherwise — no
+  // history, or the scene / camera moved — the geometric classification (tile_geom_kernel), where the scene has per-object balls
+  // and no procedural layers (their cost is not where the objects are); otherwise raster order.
+  static const int geomMode = [] { const char *e = std::getenv("RM_TILE_ORDER_GEOMETRIC"); return e ? std::atoi(e) : 2; }();  // 0 off (raster), 1 geometry alone, 2 geometry + stale costs (measured best, default)
+  const bool geomOn = geomMode != 0;
+  const bool byCost = ordered && samePicture;
+  bool byGeom = ordered && !samePicture && geomOn && !envFeatures && numObjects > 0;
   Slot *slot;
   st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res,
-                   ordered ? (haveCost ? oOrder : nullptr) : ds.dbgTileOrder, ordered ? oCost : ds.dbgTileCost,
+                   ordered ? ((byCost || byGeom) ? oOrder : nullptr) : ds.dbgTileOrder, ordered ? oCost : ds.dbgTileCost,
                    ordered ? tileCount : ds.dbgTileCount);
   if (st != RM_OK) return st;
+  if (byGeom && !slot->host->objBallOk) {  // an object without a bounding ball (Sierpinski, 2-D Mandelbrot as an object): raster order
+    byGeom = false;
+    slot->host->tileOrder = nullptr;
+    HIP_OK(hipMemcpyAsync(&slot->dev->tileOrder, &slot->host->tileOrder, sizeof(slot->host->tileOrder), hipMemcpyHostToDevice, stream));
+  }
   unsigned long long *dc = ds.dCounters;
   if (count) {
     HIP_OK(hipMemsetAsync(dc, 0, 10 * sizeof(unsigned long long), stream));
@@ -1021,8 +1091,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
     // procedural layers or textures; the generic kernel with either or both.  Features a launch does not need are
     // compiled out so the common kernels keep their register budget.
-    if (ordered && haveCost) {  // this frame's launch order from the previous frame's tile costs, ahead of the render
+    if (byCost || byGeom) {  // this frame's launch order — from the previous frame's tile costs or from geometry — ahead of the render
       const dim3 sgrid((tileCount + 255) / 256);
+      if (byGeom) hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * kTileW, tileCount, oCost,
+                                     (geomMode == 2 && haveCost) ? 1 : 0);
       HIP_OK(hipMemsetAsync(oHist, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist);
       hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder);
@@ -1050,7 +1122,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     }
 #undef RM_LAUNCH
 #undef RM_LAUNCH_NOSEC
-    if ((st = stamp((ordered && haveCost) ? 2 : 1)) != RM_OK) return st;
+    if ((st = stamp((byCost || byGeom) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
   ds.lastPath = wavefront ? 5 : 1;

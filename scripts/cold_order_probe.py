@@ -49,6 +49,35 @@ def main():
         nbg = tiles.sum(dim=1)
         orders["objects first, background last"] = torch.argsort((nbg == 64).to(torch.int32), stable=True)
         orders["silhouette, objects, background"] = torch.argsort(torch.where(nbg == 64, 2, torch.where(nbg > 0, 0, 1)).to(torch.int32), stable=True)
+        # round 4: the same classification from GEOMETRY alone (what a launcher could compute before the frame exists): the tile
+        # centre's ray against every object's world-space bounding ball — ring (closest approach within [a·R, R + tile footprint]:
+        # silhouette candidates) first, ball interiors next, the rest last
+        import numpy as np
+        inv = np.array(list(t.camera.invProjView), np.float64).reshape(4, 4).T
+        ti = np.arange(n)
+        ndc = np.stack([((ti % tx) * 8 + 4) / W * 2 - 1, ((ti // tx) * 8 + 4) / H * 2 - 1], -1)
+        nr = np.concatenate([ndc, -np.ones((n, 1)), np.ones((n, 1))], -1) @ inv.T
+        fr = np.concatenate([ndc, np.ones((n, 1)), np.ones((n, 1))], -1) @ inv.T
+        ro = nr[:, :3] / nr[:, 3:]
+        rd = fr[:, :3] / fr[:, 3:] - ro
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        foot = np.linalg.norm(fr[1, :3] / fr[1, 3] - fr[0, :3] / fr[0, 3]) / np.linalg.norm(fr[0, :3] / fr[0, 3] - ro[0])  # one tile's angle
+        for a in (0.5, 0.7):
+            cls = np.zeros(n, np.int32)
+            for i in range(t.num_objects):
+                o = t.objects[i]
+                Mi = np.linalg.inv(np.array(list(o.invModel), np.float64).reshape(4, 4).T)
+                c = Mi[:3, 3]
+                smax = np.linalg.svd(Mi[:3, :3], compute_uv=False)[0]
+                R = {10: 1.15, 11: 1.7322}.get(o.type, 0.8662) * smax
+                v = c - ro
+                tca = (v * rd).sum(1)
+                q = np.sqrt(np.maximum((v * v).sum(1) - tca * tca, 0.0))
+                m = foot * np.maximum(tca, 0.0)
+                ring = (tca > 0) & (q >= a * R) & (q <= R + m)
+                inside = (tca > 0) & (q < a * R)
+                cls = np.maximum(cls, np.where(ring, 2, np.where(inside, 1, 0)))
+            orders[f"geometric rings a={a}"] = torch.argsort(torch.from_numpy(-cls).to(r.device), stable=True)
         for oname, o in orders.items():
             oo = None if o is None else o.to(torch.int32).contiguous()
             L.rm_debug_set_tile_order(C.c_void_p(oo.data_ptr()) if oo is not None else None, None, n if oo is not None else 0)
