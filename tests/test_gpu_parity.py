@@ -929,6 +929,61 @@ def test_full_size_properties_4k_bulb(renderer):
     assert 0.25 < hit < 0.40  # ≈0.33 of the pixels hit the bulb
 
 
+def test_tile_order_of_new_and_repeated_pictures_never_changes_a_pixel(renderer):
+    """Frames of at least 2048 tiles start their tiles in an order the launcher derives: measured costs of the previous frame for
+    the SAME picture, a geometric classification (tile_geom_kernel: objects' bounding balls) — combined with stale costs — for a
+    NEW picture (first frame, moved camera, changed scene, another row range or shard), raster order where the scene gives no
+    balls (an object without a bound, procedural layers).  Whatever the order: the frame of rm_set_tile_order(0), bit for bit,
+    and the oracle's."""
+    import torch
+    from raymarcher_amd import lib
+    W, H = 640, 384  # 80 x 48 = 3840 tiles
+    L = lib()
+
+    def frames(seq, **kw):
+        outs = []
+        for scene, s in seq:
+            outs.append(renderer.render(tables_of(scene), s, W, H, **kw).clone())
+        return outs
+
+    prim = all_primitives_scene(W, H)
+    moved = (h.make_camera((0.6, 2.2, 6.5), (-0.1, -0.3, -1), (0, 1, 0), 45.0, W, H),) + prim[1:]
+    bulb = h.scene_mandelbulb(W, H)
+    sier = (prim[0], (abi.RmObject * 2)(h.make_object(abi.RM_SIERPINSKI, model=h.scale(0.8, 0.8, 0.8), scale_factor=0.8, diffuse=(.8, .6, .3)),
+                                        h.make_object(abi.RM_SPHERE, model=h.translate(1.5, 0, 0))), 2) + prim[3:]
+    s0 = abi.default_settings(maxSteps=96)
+    s1 = abi.default_settings(maxSteps=96, enableAmbientOcclusion=1)
+    sb = abi.default_settings(fractalIters=8, maxSteps=96)
+    # new, same, same, moved camera, back, changed settings, another class, an unbounded object (raster fallback), the layers
+    seq = [(prim, s0), (prim, s0), (prim, s0), (moved, s0), (prim, s0), (prim, s1), (bulb, sb), (bulb, sb), (sier, s0), (sier, s0),
+           (env_scene(W, H), abi.default_settings(features=ENV_ALL, maxSteps=64))]
+    try:
+        assert L.rm_set_tile_order(0) == 0
+        want = frames(seq)
+        assert L.rm_set_tile_order(1) == 0
+        got = frames(seq)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert _ieq(a, b), f"frame {k} of the sequence differs from its raster-order render"
+        for k in (0, 3, 6):
+            scene, s = seq[k]
+            assert_bit_equal(got[k].cpu().numpy(), h.oracle_render(scene, s, W, H), f"frame {k} vs oracle")
+        # a tall frame so that a row range and a shard still have >= 2048 tiles: other row maps are other pictures
+        H2 = 1024
+        scene = (h.make_camera((0, 1.2, 6), (0, -0.2, -1), (0, 1, 0), 45.0, W, H2),) + prim[1:]
+        t = tables_of(scene)
+        L.rm_set_tile_order(0)
+        full = renderer.render(t, s0, W, H2).clone()
+        L.rm_set_tile_order(1)
+        for _ in range(2):
+            assert _ieq(renderer.render(t, s0, W, H2), full)
+            assert _ieq(renderer.render(t, s0, W, H2, row_begin=200, row_end=904), full[200:904])
+            mine = renderer.render_tiles(t, s0, W, H2, 8, 1, 2)
+            rows = [L.rm_shard_row_to_frame(H2, 8, 1, 2, i) for i in range(mine.shape[0])]
+            assert _ieq(mine, full[torch.tensor(rows, device=full.device)])
+    finally:
+        L.rm_set_tile_order(-1)
+
+
 # ---------------------------------------------------------------- the other BASELINE.json configurations, at their full sizes
 SCENES = os.path.join(os.path.dirname(__file__), "golden", "scenes")
 
