@@ -6,9 +6,10 @@ set -e -o pipefail
 mkdir -p gpurun_out
 OUT=gpurun_out/fuzz_soak.txt
 : > $OUT
-for SEED in 20261012 7 987654321; do
-  echo "== seed $SEED: test_random_tablewalk_scenes_bit_exact, 1000 cases" | tee -a $OUT
-  RM_FUZZ_CASES=1000 RM_FUZZ_SEED=$SEED timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x \
+CASES=${CASES:-1000}
+for SEED in ${SEEDS:-20261012 7 987654321}; do
+  echo "== seed $SEED: test_random_tablewalk_scenes_bit_exact, $CASES cases" | tee -a $OUT
+  RM_FUZZ_CASES=$CASES RM_FUZZ_SEED=$SEED timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x \
      -k "test_random_tablewalk_scenes_bit_exact" 2>&1 | grep -E "FUZZ_SUMMARY|passed|failed|Error|assert" | tee -a $OUT
 done
 echo "== seed 424242: the older generators (general, all-primitive, bulb class, wavefront class), 400 cases each" | tee -a $OUT
