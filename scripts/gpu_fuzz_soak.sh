@@ -12,6 +12,8 @@ for SEED in ${SEEDS:-20261012 7 987654321}; do
   RM_FUZZ_CASES=$CASES RM_FUZZ_SEED=$SEED timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x \
      -k "test_random_tablewalk_scenes_bit_exact" 2>&1 | grep -E "FUZZ_SUMMARY|passed|failed|Error|assert" | tee -a $OUT
 done
-echo "== seed 424242: the older generators (general, all-primitive, bulb class, wavefront class), 400 cases each" | tee -a $OUT
-RM_FUZZ_CASES=400 RM_FUZZ_SEED=424242 timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py tests/test_gpu_wavefront.py -m gpu -q -x \
-   -k "test_random_scenes_bit_exact or test_random_primitive_scenes_bit_exact or test_random_bulb or test_wavefront_random_scenes_bit_exact" 2>&1 | tail -3 | tee -a $OUT
+for SEED in ${OLD_SEEDS:-424242}; do
+  echo "== seed $SEED: the older generators (general, all-primitive, bulb class, wavefront class), ${OLD_CASES:-400} cases each" | tee -a $OUT
+  RM_FUZZ_CASES=${OLD_CASES:-400} RM_FUZZ_SEED=$SEED timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py tests/test_gpu_wavefront.py -m gpu -q -x \
+     -k "test_random_scenes_bit_exact or test_random_primitive_scenes_bit_exact or test_random_bulb or test_wavefront_random_scenes_bit_exact" 2>&1 | tail -3 | tee -a $OUT
+done
