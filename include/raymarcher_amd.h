@@ -364,6 +364,11 @@ int rm_debug_last_path(void);
  * with at least 2048 tiles (not to the 2-D Mandelbrot path or the wavefront pipeline, whose persistent waves balance
  * themselves). */
 int rm_set_tile_order(int mode);
+/* Shape of the pixel tile a wave renders: 8×8 by default; for table-walk, sampler and layer scenes the launcher measures, per
+ * stream and picture, whether 4 wide × 16 tall tiles are faster (frames 0-1 and 4-5 of a picture run 8×8, frames 2-3 and 6-7 4×16,
+ * the second of each pair timed with HIP events) and keeps the shape with the smaller best time from the ninth frame on.  The shape never changes a pixel.  Tests /
+ * experiments: mode 0 = tune (default), 3 = always 8×8, 2 = always 4×16, -1 = back to the RM_TILE_SHAPE environment variable. */
+int rm_debug_set_tile_shape(int mode);
 /* Experiments: force a given launch order (d_order: a device permutation of 0..tileCount-1, or NULL) and / or collect the
  * tiles' costs (d_cost: tileCount device words, accumulated, or NULL) for subsequent launches on the current device. */
 int rm_debug_set_tile_order(const int32_t *d_order, uint32_t *d_cost, int tileCount);

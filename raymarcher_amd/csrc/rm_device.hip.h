@@ -100,6 +100,9 @@ struct SceneBlock {
   float cullLip;  // Lipschitz bound of every object's distance value per unit of world length (+inf with a fractal in the table)
   float cullLo[3], cullHi[3];  // axis-aligned box with the same property (see scene_cull_ball); cullBoxOk = 0: none
   int32_t cullBoxOk;
+  // Shape of a wave's pixel tile: 2^tileShift pixels wide, 64 >> tileShift tall (3 = 8×8, the default; 2 = 4 wide × 16 tall,
+  // which the launcher's tuner picks for pictures it measures faster that way: rm_kernels.hip, "tile shape").  Same pixels.
+  int32_t tileShift;
   // World-space bounding ball of every object (centre xyz, radius; filled by scene_cull_ball with the balls it derives anyway),
   // objBallOk = 1 when every object has one: tile_geom_kernel classifies the tiles of a frame WITHOUT cost history by their
   // centre ray's closest approach to these balls (rm_kernels.hip, "tile order").  Never read by the render kernels.

@@ -43,8 +43,7 @@ int require_device_pointers(std::initializer_list<std::pair<const char *, const 
 #ifndef RM_TILE_W
 #define RM_TILE_W 8   // pixels per wave tile, horizontally (RM_TILE_W × RM_TILE_H = 64)
 #endif
-constexpr int kTileW = RM_TILE_W, kTileH = 64 / RM_TILE_W;
-constexpr int kBlockH = kTileH;
+static_assert(RM_TILE_W == 4 || RM_TILE_W == 8 || RM_TILE_W == 16, "tile width: 4, 8 or 16 pixels");
 
 // COUNT: 0 production, 1 reference-work counters, 2 executed-work counters (rm_device.hip.h), 3 production code plus clock
 // stamps: every wave adds its (s_memtime, s_memrealtime) spans to counters[3], counters[4] — shader cycles and 100 MHz
@@ -111,8 +110,9 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
   // the wave's start stamp waits in LDS (not in two scalar registers across the whole kernel — the register budget is tight)
   __shared__ unsigned long long s_c0[4];
   if (sb->tileCost && lane == 0) s_c0[wave] = __builtin_amdgcn_s_memtime();
-  const int x = (tbx * (blockDim.x >> 6) + wave) * kTileW + (lane % kTileW);
-  const int r = tby * kBlockH + (lane / kTileW);
+  const int tsh = sb->tileShift, tw = 1 << tsh;  // wave-uniform (scalar): the tile is tw pixels wide, 64 / tw tall
+  const int x = (tbx * (blockDim.x >> 6) + wave) * tw + (lane & (tw - 1));
+  const int r = tby * (64 >> tsh) + (lane >> tsh);
   if (x >= W || r >= nRows) return;
   const int y = map.frameRow(r);
   V4 col, br;
@@ -232,17 +232,18 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict_
 // 4K frames (scripts/cold_order_probe.py, profiles/r04_k_geometric_order.md): bulb 2.85 → 2.26 ms (measured costs: 1.99),
 // directional_light_2.json 1.89 → 1.77-1.81, reflections_complex.json 8.70 → 8.39-8.44.  Same pixels.
 __global__ __launch_bounds__(256) void tile_geom_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H, int nRows, int tilesX,
-                                                        int tileW, int n, uint32_t *__restrict__ cost, int combine) {
+                                                        int tileW, int tileH, int n, uint32_t *__restrict__ cost, int combine) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int x = (i % tilesX) * tileW + tileW / 2, r = (i / tilesX) * kBlockH + kBlockH / 2;
+  int x = (i % tilesX) * tileW + tileW / 2, r = (i / tilesX) * tileH + tileH / 2;
   x = x < W ? x : W - 1;
   r = r < nRows ? r : nRows - 1;
   V3 ro, rd;
   primaryRay(sb, x, map.frameRow(r), W, H, ro, rd);
   // angle of one tile seen from the eye ≈ the distance between neighbouring tile centres' directions
   V3 ro2, rd2;
-  primaryRay(sb, x < W - tileW ? x + tileW : x - tileW, map.frameRow(r), W, H, ro2, rd2);
+  const int span = tileW > tileH ? tileW : tileH;  // the tile's larger side, in pixels
+  primaryRay(sb, x < W - span ? x + span : x - span, map.frameRow(r), W, H, ro2, rd2);
   const float foot = len(sub(rd2, rd));
   int cls = 0;
   const int no = sb->numObjects;
@@ -353,9 +354,28 @@ struct Slot {
   bool used = false;
 };
 struct TileOrderState {
-  int tileCount = 0, W = 0, nRows = 0, nw = 0;
+  int tileCount = 0, W = 0, nRows = 0, nw = 0, tileShift = 3;
   void *mem = nullptr;
   unsigned long long sceneKey = 0;  // hash of the scene + camera + row map of the frame that recorded the costs in `mem`
+};
+// "Tile shape": which of the two tile shapes a picture renders faster with is scene-dependent (upright objects: 4 wide × 16 tall
+// tiles straddle fewer vertical silhouettes, so whole waves agree on the table walk's shortcuts more often — C2 at 1080p 0.866 →
+// 0.792 ms — while reflections_complex.json loses 5 % that way; profiles/r04_m_tile_shape.txt).  So the launcher MEASURES, per
+// stream and picture: frames 0-1 of a picture run 8×8 (frame 1, ordered by frame 0's costs, is timed with HIP events), frames 2-3
+// run 4×16 (frame 3 timed), frames 4-7 repeat that (clocks ramp up over a process's first frames: one round would favour the later
+// candidate), and from then on the shape with the smaller best time is used.  Same pixels whatever the shape.  Single-bulb class: 8×8
+// always (measured: 4×16 +5 %).  RM_TILE_SHAPE / rm_debug_set_tile_shape: 0 tune, 3 always 8×8, 2 always 4×16.
+struct ShapeTune {
+  unsigned long long key = 0;
+  int W = 0, nRows = 0;
+  int frame = 0;    // frames of this picture enqueued so far
+  int chosen = -1;  // the decided tile shift, -1 while measuring
+  hipEvent_t ev[4][2] = {};  // [timed launch k: candidate k & 1 (0 = 8×8, 1 = 4×16), round k >> 1][start, stop]
+  bool timed[4] = {false, false, false, false};
+  void drop() {
+    for (auto &c : ev) for (auto &e : c) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (bool &t : timed) t = false;
+  }
 };
 struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (one stage) or 3 (tile-order sort + render kernel)
 struct DeviceState {
@@ -366,6 +386,7 @@ struct DeviceState {
   std::vector<TimedLaunch> timed;           // rm_set_timing / rm_get_timing, per device
   int numCUs = 0;
   std::map<hipStream_t, TileOrderState> tileOrder;  // what the feedback costs of each stream belong to
+  std::map<hipStream_t, ShapeTune> shapeTune;  // the tile-shape tuner's state per stream
   std::map<hipStream_t, size_t> wfDenied;  // smallest wavefront workspace (bytes) that could not be had on a stream
   const int32_t *dbgTileOrder = nullptr;  // rm_debug_set_tile_order (experiments): overrides the modes below
   uint32_t *dbgTileCost = nullptr;
@@ -376,6 +397,7 @@ std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_O
 constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
 std::atomic<bool> g_timing{false};
+std::atomic<int> g_tileShape{-1};  // rm_debug_set_tile_shape: -1 = the RM_TILE_SHAPE environment variable (default 0 = tune), 0 tune, 3 8×8, 2 4×16
 std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one lane per pixel, 5 wavefront pipeline
 
 #define HIP_OK(expr)                                                                              \
@@ -839,7 +861,7 @@ void scene_eval_records(SceneBlock *h) {
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, hipStream_t stream, DeviceState &ds, Slot **slotOut,
                 const RmResources &res, const int32_t *tileOrder = nullptr, uint32_t *tileCost = nullptr,
-                int tileCount = 0) {  // caller holds ds.mu
+                int tileCount = 0, int tileShift = 3) {  // caller holds ds.mu
   Slot *slot;
   int st = acquire_slot(ds, &slot);
   if (st != RM_OK) return st;
@@ -857,6 +879,7 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   scene_cull_ball(h);
   ray_planes(h);
   h->tileOrder = tileOrder; h->tileCost = tileCost; h->tileCount = tileCount;
+  h->tileShift = tileShift;
   h->mengerAni = 0.0f; h->mengerOff = 0.0f;
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   bool menger = false;
@@ -994,7 +1017,59 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   // compiler's own budgets two waves were best for the bulb, profiles/r02_c_waves_per_block.md).  RM_WAVES_PER_BLOCK overrides.
   static const int wpb = std::getenv("RM_WAVES_PER_BLOCK") ? std::atoi(std::getenv("RM_WAVES_PER_BLOCK")) : 0;
   const int nw = (wpb == 1 || wpb == 2 || wpb == 4) ? wpb : 1;
-  const dim3 rgrid((W + nw * kTileW - 1) / (nw * kTileW), (nRows + kBlockH - 1) / kBlockH), rblock(64 * nw);
+  // the picture this launch renders: everything that decides a pixel (FNV-1a over the caller's tables and the row map) — what the
+  // tile-order feedback and the tile-shape tuner key their measurements by
+  unsigned long long key = 1469598103934665603ull;
+  {
+    auto mix = [&](const void *p, size_t nb) {
+      const unsigned char *b8 = static_cast<const unsigned char *>(p);
+      for (size_t k = 0; k < nb; k++) key = (key ^ b8[k]) * 1099511628211ull;
+    };
+    mix(cam, sizeof(*cam)); mix(g, sizeof(*g)); mix(s, sizeof(*s)); mix(&map, sizeof(map));
+    mix(objs, sizeof(RmObject) * (size_t)numObjects); mix(lights, sizeof(RmLight) * (size_t)numLights);
+  }
+  // Tile shape ("tile shape" above): 8×8 unless the tuner is measuring or has chosen 4×16 for this picture on this stream
+  static const int envShape = std::getenv("RM_TILE_SHAPE") ? std::atoi(std::getenv("RM_TILE_SHAPE")) : 0;
+  const int shapeReq = g_tileShape.load() >= 0 ? g_tileShape.load() : envShape;
+  const bool bigFrame = (size_t)nRows * W >= (size_t)2048 * 64;
+  int tileShift = (RM_TILE_W == 8) ? 3 : (RM_TILE_W == 4 ? 2 : (RM_TILE_W == 16 ? 4 : 3));
+  ShapeTune *tune = nullptr;  // non-null: this launch is one of the tuner's (frames 0-3 of a picture) or follows its choice
+  int tuneTimed = -1;         // 0..3: time this launch as the tuner's candidate (k & 1: 0 = 8×8, 1 = 4×16) of round k >> 1
+  if (shapeReq == 2 || shapeReq == 3) tileShift = shapeReq;
+  else if (RM_TILE_W == 8 && !bulb && !wavefront && !g->isTwoD && count == 0 && bigFrame && !ds.dbgTileOrder && !ds.dbgTileCost) {
+    tune = &ds.shapeTune[stream];
+    if (tune->key != key || tune->W != W || tune->nRows != nRows) {
+      tune->drop();
+      tune->key = key; tune->W = W; tune->nRows = nRows; tune->frame = 0; tune->chosen = -1;
+    }
+    if (tune->chosen < 0 && tune->frame >= 8) {
+      bool ready = true;
+      for (int k = 0; k < 4; k++) ready = ready && tune->timed[k] && hipEventQuery(tune->ev[k][1]) == hipSuccess;
+      if (ready) {
+        float best[2] = {1e30f, 1e30f};
+        bool ok = true;
+        for (int k = 0; k < 4; k++) {
+          float ms = 0.0f;
+          ok = ok && hipEventElapsedTime(&ms, tune->ev[k][0], tune->ev[k][1]) == hipSuccess;
+          best[k & 1] = ms < best[k & 1] ? ms : best[k & 1];
+        }
+        tune->chosen = (ok && best[1] < 0.97f * best[0]) ? 2 : 3;  // 4×16 must win by 3 %
+        tune->drop();
+      }
+    }
+    (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+    if (tune->chosen >= 0) tileShift = tune->chosen;
+    else {
+      // frames 0-1, 4-5: 8×8; 2-3, 6-7: 4×16; from frame 8 until the timings are in (a host that enqueues far ahead of the GPU): 8×8 —
+      // the enqueue path never waits for them
+      const int f = tune->frame;
+      tileShift = (f < 8 && ((f >> 1) & 1)) ? 2 : 3;
+      if (f < 8 && (f & 1)) tuneTimed = ((f >> 1) & 1) | ((f >> 2) << 1);  // candidate | round << 1
+    }
+    tune->frame++;
+  }
+  const int tileW = 1 << tileShift, tileH = 64 >> tileShift;
+  const dim3 rgrid((W + nw * tileW - 1) / (nw * tileW), (nRows + tileH - 1) / tileH), rblock(64 * nw);
   // Tile order ("tile order" above): 0 raster order, 1 feedback — tiles start heaviest-first by the costs the previous frame
   // of this size on this stream recorded.  Small frames are not worth the two extra launches.
   static const int envOrder = std::getenv("RM_TILE_ORDER") ? std::atoi(std::getenv("RM_TILE_ORDER")) : kDefaultTileOrder;
@@ -1014,16 +1089,8 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     oCost = oHist + 64;
     oOrder = reinterpret_cast<int32_t *>(oCost + tileCount);
     TileOrderState &ts = ds.tileOrder[stream];
-    // the picture the recorded costs belong to: everything that decides a pixel (FNV-1a over the caller's tables and the row map)
-    unsigned long long key = 1469598103934665603ull;
-    auto mix = [&](const void *p, size_t nb) {
-      const unsigned char *b8 = static_cast<const unsigned char *>(p);
-      for (size_t k = 0; k < nb; k++) key = (key ^ b8[k]) * 1099511628211ull;
-    };
-    mix(cam, sizeof(*cam)); mix(g, sizeof(*g)); mix(s, sizeof(*s)); mix(&map, sizeof(map));
-    mix(objs, sizeof(RmObject) * (size_t)numObjects); mix(lights, sizeof(RmLight) * (size_t)numLights);
-    const TileOrderState now{tileCount, W, nRows, nw, mem, key};
-    haveCost = ts.tileCount == now.tileCount && ts.W == W && ts.nRows == nRows && ts.nw == nw && ts.mem == mem;
+    const TileOrderState now{tileCount, W, nRows, nw, tileShift, mem, key};
+    haveCost = ts.tileCount == now.tileCount && ts.W == W && ts.nRows == nRows && ts.nw == nw && ts.tileShift == tileShift && ts.mem == mem;
     if (!haveCost) HIP_OK(hipMemsetAsync(oCost, 0, (size_t)tileCount * 4, stream));
     samePicture = haveCost && ts.sceneKey == key;
     ts = now;
@@ -1038,7 +1105,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   Slot *slot;
   st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res,
                    ordered ? ((byCost || byGeom) ? oOrder : nullptr) : ds.dbgTileOrder, ordered ? oCost : ds.dbgTileCost,
-                   ordered ? tileCount : ds.dbgTileCount);
+                   ordered ? tileCount : ds.dbgTileCount, tileShift);
   if (st != RM_OK) return st;
   if (byGeom && !slot->host->objBallOk) {  // an object without a bounding ball (Sierpinski, 2-D Mandelbrot as an object): raster order
     byGeom = false;
@@ -1093,12 +1160,17 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // compiled out so the common kernels keep their register budget.
     if (byCost || byGeom) {  // this frame's launch order — from the previous frame's tile costs or from geometry — ahead of the render
       const dim3 sgrid((tileCount + 255) / 256);
-      if (byGeom) hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * kTileW, tileCount, oCost,
+      if (byGeom) hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * tileW, tileH, tileCount, oCost,
                                      (geomMode == 2 && haveCost) ? 1 : 0);
       HIP_OK(hipMemsetAsync(oHist, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist);
       hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder);
       if ((st = stamp(1)) != RM_OK) return st;  // stage 0 = the ordering launches, stage 1 = the render
+    }
+    if (tuneTimed >= 0 && tune) {  // the tuner's timed launch of this candidate shape: events around the render kernel alone
+      if (hipEventCreate(&tune->ev[tuneTimed][0]) == hipSuccess && hipEventCreate(&tune->ev[tuneTimed][1]) == hipSuccess)
+        HIP_OK(hipEventRecord(tune->ev[tuneTimed][0], stream));
+      else tuneTimed = -1;
     }
 #define RM_LAUNCH(B, C, E, T) hipLaunchKernelGGL((render_kernel<B, C, E, T>), rgrid, rblock, 0, stream, slot->dev, map, W, H, nRows, o, b, dc)
     if (envFeatures || textured) {
@@ -1122,6 +1194,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     }
 #undef RM_LAUNCH
 #undef RM_LAUNCH_NOSEC
+    if (tuneTimed >= 0 && tune) {
+      HIP_OK(hipEventRecord(tune->ev[tuneTimed][1], stream));
+      tune->timed[tuneTimed] = true;
+    }
     if ((st = stamp((byCost || byGeom) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
@@ -1457,6 +1533,11 @@ int rm_set_kernel_path(int path) {
   g_kernelPath.store(path);
   return RM_OK;
 }
+int rm_debug_set_tile_shape(int mode) {
+  if (mode != -1 && mode != 0 && mode != 2 && mode != 3) { set_error("tile shape mode must be -1, 0, 2 or 3"); return RM_ERR_INVALID_ARGUMENT; }
+  g_tileShape.store(mode);
+  return RM_OK;
+}
 int rm_set_workspace_limit(unsigned long long bytes) {
   g_wsLimit.store(bytes == ~0ull ? ~0ull - 1 : bytes);
   for (DeviceState &ds : g_dev) {  // what was refused under the old limit may be asked for again
@@ -1472,6 +1553,8 @@ int rm_release_workspaces(unsigned long long *freedBytes) {
   size_t freed = 0;
   if (int st = release_workspaces(&freed)) return st;
   ds->tileOrder.clear();  // the feedback costs lived in the buffers just freed
+  for (auto &kv : ds->shapeTune) kv.second.drop();
+  ds->shapeTune.clear();
   ds->wfDenied.clear();
   if (freedBytes) *freedBytes = freed;
   return RM_OK;

@@ -984,6 +984,40 @@ def test_tile_order_of_new_and_repeated_pictures_never_changes_a_pixel(renderer)
         L.rm_set_tile_order(-1)
 
 
+def test_tile_shape_tuner_never_changes_a_pixel(renderer):
+    """The launcher measures, per stream and picture, whether 8×8 or 4 wide × 16 tall pixel tiles are faster (frames 0-7 of a
+    picture alternate the two shapes in pairs, then the choice sticks; rm_kernels.hip "tile shape").  Every frame of such a
+    sequence — and the frame with either shape forced, whole, as a row range and as a shard — is the same frame, the oracle's."""
+    import torch
+    from raymarcher_amd import lib
+    L = lib()
+    W, H = 640, 400  # 4000 8×8 tiles, 4000 4×16 tiles
+    scene = all_primitives_scene(W, H)
+    t = tables_of(scene)
+    s = abi.default_settings(maxSteps=96, enableSoftShadow=1)
+    try:
+        assert L.rm_debug_set_tile_shape(3) == 0
+        ref = renderer.render(t, s, W, H).clone()
+        assert_bit_equal(ref.cpu().numpy(), h.oracle_render(scene, s, W, H), "8×8 tiles vs oracle")
+        assert L.rm_debug_set_tile_shape(2) == 0
+        for _ in range(2):
+            assert _ieq(renderer.render(t, s, W, H), ref)
+        assert _ieq(renderer.render(t, s, W, H, row_begin=33, row_end=377), ref[33:377])
+        mine = renderer.render_tiles(t, s, W, H, 8, 1, 3)
+        rows = [L.rm_shard_row_to_frame(H, 8, 1, 3, i) for i in range(mine.shape[0])]
+        assert _ieq(mine, ref[torch.tensor(rows, device=ref.device)])
+        assert L.rm_debug_set_tile_shape(0) == 0
+        for k in range(14):  # the tuner's eight frames, its decision, and frames after it
+            assert _ieq(renderer.render(t, s, W, H), ref), f"frame {k} of the tuned sequence differs"
+        moved = (h.make_camera((0.5, 2.0, 6.5), (-0.1, -0.3, -1), (0, 1, 0), 45.0, W, H),) + scene[1:]
+        want = h.oracle_render(moved, s, W, H)
+        for k in range(3):  # a new picture restarts the measurement
+            assert_bit_equal(renderer.render(tables_of(moved), s, W, H).cpu().numpy(), want, f"moved camera, frame {k}")
+        assert L.rm_debug_set_tile_shape(5) == abi.RM_ERR_INVALID_ARGUMENT
+    finally:
+        L.rm_debug_set_tile_shape(-1)
+
+
 # ---------------------------------------------------------------- the other BASELINE.json configurations, at their full sizes
 SCENES = os.path.join(os.path.dirname(__file__), "golden", "scenes")
 
