@@ -387,6 +387,7 @@ struct DeviceState {
   int numCUs = 0;
   std::map<hipStream_t, TileOrderState> tileOrder;  // what the feedback costs of each stream belong to
   std::map<hipStream_t, ShapeTune> shapeTune;  // the tile-shape tuner's state per stream
+  std::map<std::tuple<unsigned long long, int, int>, int> shapeChoice;  // decisions by (picture, W, rows): other streams adopt them
   std::map<hipStream_t, size_t> wfDenied;  // smallest wavefront workspace (bytes) that could not be had on a stream
   const int32_t *dbgTileOrder = nullptr;  // rm_debug_set_tile_order (experiments): overrides the modes below
   uint32_t *dbgTileCost = nullptr;
@@ -1041,6 +1042,8 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if (tune->key != key || tune->W != W || tune->nRows != nRows) {
       tune->drop();
       tune->key = key; tune->W = W; tune->nRows = nRows; tune->frame = 0; tune->chosen = -1;
+      const auto known = ds.shapeChoice.find(std::make_tuple(key, W, nRows));  // another stream of this device measured this picture
+      if (known != ds.shapeChoice.end()) tune->chosen = known->second;
     }
     if (tune->chosen < 0 && tune->frame >= 8) {
       bool ready = true;
@@ -1055,6 +1058,8 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
         }
         tune->chosen = (ok && best[1] < 0.97f * best[0]) ? 2 : 3;  // 4×16 must win by 3 %
         tune->drop();
+        if (ds.shapeChoice.size() >= 256) ds.shapeChoice.clear();
+        ds.shapeChoice[std::make_tuple(key, W, nRows)] = tune->chosen;
       }
     }
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
@@ -1555,6 +1560,7 @@ int rm_release_workspaces(unsigned long long *freedBytes) {
   ds->tileOrder.clear();  // the feedback costs lived in the buffers just freed
   for (auto &kv : ds->shapeTune) kv.second.drop();
   ds->shapeTune.clear();
+  ds->shapeChoice.clear();
   ds->wfDenied.clear();
   if (freedBytes) *freedBytes = freed;
   return RM_OK;
