@@ -322,6 +322,10 @@ def main():
     ap.add_argument("--gather-root", choices=["zero", "rotate"], default="zero",
                     help="N > 1: where frames end — every frame on rank 0 (default; SURVEY §8e), or frame i on rank i mod N, which spreads "
                          "the root's receive traffic and de-interleave pass over the ranks (also timed as variants.rotating_root)")
+    ap.add_argument("--root-relief", default="auto",
+                    help="N > 1, --gather-root zero: rm_set_root_relief(K) — rank 0, which also receives N − 1 slots and de-interleaves the "
+                         "whole frame every frame, renders (K − 1)/K of a peer's tiles.  auto: 8 from four ranks, 16 for two or three, "
+                         "0 (the plain t mod N deal) for one; or an integer (0 = off)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (RCCL process group, pipelined gather, de-interleave) even with one rank: "
                          "a rehearsal of the multi-GPU path on a one-GPU box")
@@ -352,6 +356,12 @@ def main():
     r = Renderer(local_rank)
     tables, settings, W, H, desc = build_config(cfg, algebraic=(cfg == "c3" and args.bulb_eval == "algebraic"))
     L = lib()
+    # the partition: with every frame ending on rank 0, rank 0 is relieved of some tiles (profiles/r04_i_submit_rate.md: its
+    # de-interleave pass and N − 1 receives make it the longest pole of every frame); a rotating root needs no relief
+    relief = 0
+    if distributed and world > 1 and args.gather_root == "zero":
+        relief = (8 if world >= 4 else 16) if args.root_relief == "auto" else int(args.root_relief)
+    assert L.rm_set_root_relief(relief) == 0
     plan = ShardPlan(H, TILE_ROWS, world)
     my_rows, slot_rows = plan.rows(rank), plan.slot_rows  # shard 0 owns the most rows → equal gather slots
     mine = torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device) if not distributed else None
@@ -363,28 +373,29 @@ def main():
     rgba8 = distributed and args.gather == "rgba8"
     tiles32 = [torch.zeros((slot_rows, W, 4), dtype=torch.float32, device=r.device) for _ in range(3)] if rgba8 else None
 
-    def make_pipe(rotate):
+    def make_pipe(rotate, pl):
         """frame i is gathered to rank 0 — or, rotate: to rank i mod world (dist.FramePipeline) — and de-interleaved there"""
+        sr = pl.slot_rows
         if rgba8:  # the shard's float4 tiles stay on its GPU (one buffer per frame slot); their 8-bit conversion travels
-            return FramePipeline(plan, rank, (W, 4), torch.uint8, r.device, depth=3, multi_stream=True, rotate_root=rotate,
-                                 finish=lambda g: frame_holder.__setitem__("f", r.deinterleave_rgba8(g, W, H, TILE_ROWS, world, slot_rows)))
-        return FramePipeline(plan, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True, rotate_root=rotate,
-                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, slot_rows)))
-    pipes = {"current": make_pipe(args.gather_root == "rotate") if distributed else None}
+            return FramePipeline(pl, rank, (W, 4), torch.uint8, r.device, depth=3, multi_stream=True, rotate_root=rotate,
+                                 finish=lambda g: frame_holder.__setitem__("f", r.deinterleave_rgba8(g, W, H, TILE_ROWS, world, sr)))
+        return FramePipeline(pl, rank, (W, 4), torch.float32, r.device, depth=3, multi_stream=True, rotate_root=rotate,
+                             finish=lambda g: frame_holder.__setitem__("f", r.deinterleave(g, W, H, TILE_ROWS, world, sr)))
+    pipes = {"current": make_pipe(args.gather_root == "rotate", plan) if distributed else None, "rows": my_rows}
     submitted = [0]
 
     def step():
         if not distributed:
             frame_holder["f"] = r.render(tables, settings, W, H, out=mine)
             return
-        pipe = pipes["current"]
+        pipe, rows = pipes["current"], pipes["rows"]
         if rgba8:
             buf = tiles32[submitted[0] % 3]
             submitted[0] += 1
-            pipe.submit(lambda slot: r.tiles_to_rgba8(r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=buf[:my_rows]),
-                                                      out=slot[:my_rows]))
+            pipe.submit(lambda slot: r.tiles_to_rgba8(r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=buf[:rows]),
+                                                      out=slot[:rows]))
             return
-        pipe.submit(lambda slot: r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=slot[:my_rows]))
+        pipe.submit(lambda slot: r.render_tiles(tables, settings, W, H, TILE_ROWS, rank, world, out=slot[:rows]))
 
     def fence():
         if distributed:
@@ -420,9 +431,13 @@ def main():
 
     variants = {}
     if distributed and not args.no_variants and args.gather_root == "zero":
-        # the same frames with the gather's root rotating over the ranks (frame i ends on rank i mod N): rank 0 is then no longer
-        # the one rank that receives N − 1 slots and de-interleaves the whole frame every frame; never `value`
-        pipes["current"] = make_pipe(True)
+        # the same frames with the gather's root rotating over the ranks (frame i ends on rank i mod N; the plain t mod N deal): rank 0
+        # is then no longer the one rank that receives N − 1 slots and de-interleaves the whole frame every frame; never `value`
+        assert L.rm_set_root_relief(0) == 0
+        plan0 = ShardPlan(H, TILE_ROWS, world)
+        if rgba8 and plan0.slot_rows > tiles32[0].shape[0]:
+            tiles32[:] = [torch.zeros((plan0.slot_rows, W, 4), dtype=torch.float32, device=r.device) for _ in range(3)]
+        pipes["current"], pipes["rows"] = make_pipe(True, plan0), plan0.rows(rank)
         for _ in range(min(args.warmup, 3) + world):
             step()
         fence()
@@ -435,10 +450,11 @@ def main():
         same = None
         if rank == 0 and "f" in frame_holder:  # the last frame rank 0 was the root of
             same = bool(torch.equal(frame_holder["f"], timed_frame))
+        assert L.rm_set_root_relief(relief) == 0
         variants["rotating_root"] = {"value": round(W * H * args.steps / float(dtr.item()) / 1e6, 2), "unit": "Mpixels/s",
                                      "ms_per_step": round(float(dtr.item()) / args.steps * 1e3, 4), "steps": args.steps,
                                      "frame_identical_to_headline": same,
-                                     "what": "FramePipeline(rotate_root=True): frame i is gathered to and de-interleaved on rank i mod N"}
+                                     "what": "FramePipeline(rotate_root=True), no root relief: frame i is gathered to and de-interleaved on rank i mod N"}
     single = not distributed and not args.no_variants
     nv = max(3, min(args.steps, 10))
     if single and schedule == 1 and cfg in ("c2", "c3", "c4", "c5"):
@@ -590,7 +606,8 @@ def main():
             "config": {"workload": desc["workload"], "baseline_config": desc["baseline_config"], "name": cfg,
                        "rows": "whole frame" if not distributed else f"{TILE_ROWS}-row tiles round-robin over {world} GPUs; three frames in "
                                "flight per GPU on three streams (renders of consecutive frames overlap, RCCL gather of frame i "
-                               + ("to rank 0 runs under later renders); every frame de-interleaved on rank 0" if args.gather_root == "zero" else
+                               + (f"to rank 0 runs under later renders); every frame de-interleaved on rank 0; root relief {relief} "
+                                  "(rm_set_root_relief: rank 0 renders fewer tiles)" if args.gather_root == "zero" else
                                   "to rank i mod N runs under later renders); every frame de-interleaved on its root")
                                + (" as the RGBA8 image (4 B/pixel gathered)" if rgba8 else " as a float4 frame (16 B/pixel gathered)"),
                        "tile_order": ("feedback: each frame records its tiles' shader-cycle costs and the next frame of the SAME picture starts heavy "

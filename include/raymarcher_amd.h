@@ -235,6 +235,14 @@ int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, c
 int rm_render_tiles_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                         const RmGlobals *g, const RmSettings *s, const RmResources *res, int W, int H, int tileRows,
                         int shard, int numShards, float *d_rgba, float *d_bright, void *stream);
+/* The row-tile partition.  Default (root relief 0): tile t belongs to shard t mod numShards.  rm_set_root_relief(K), K in 2..64:
+ * the deal runs in cycles of numShards·K − 1 tiles — K − 1 full rounds, then one round that leaves shard 0 out — so shard 0, the
+ * gather's root (which also receives numShards − 1 slots and de-interleaves the whole frame every frame), renders (K − 1)/K of a
+ * peer's tiles.  The setting is PROCESS-WIDE and every entry point that deals tiles reads it (rm_render_tiles*, rm_shard_rows,
+ * rm_shard_row_to_frame, rm_deinterleave*, rm_gather_*): every rank of a job sets the same value before rendering.  With relief
+ * the largest shard is shard 1, not shard 0: size gather slots by rm_gather_slot_rows.  0 switches it off. */
+int rm_set_root_relief(int K);
+int rm_get_root_relief(void);
 /* Rows owned by `shard` under the rm_render_tiles partition. */
 int rm_shard_rows(int H, int tileRows, int shard, int numShards);
 /* Frame row of the shard's packed row `localRow` (inverse map used when de-interleaving a gather). */

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rm_set_kernel_path": (C.c_int, [C.c_int]),
     "rm_debug_last_path": (C.c_int, []),
     "rm_debug_set_tile_shape": (C.c_int, [C.c_int]),
+    "rm_set_root_relief": (C.c_int, [C.c_int]),
+    "rm_get_root_relief": (C.c_int, []),
     "rm_set_workspace_limit": (C.c_int, [C.c_ulonglong]),
     "rm_release_workspaces": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "rm_set_tile_order": (C.c_int, [C.c_int]),

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "rm_math.hip.h"
+#include "rm_internal.h"
 
 namespace rm {
 
@@ -123,8 +124,9 @@ struct SceneBlock {
 // frame (tiles of tileRows rows dealt round-robin, include/raymarcher_amd.h rm_render_tiles).
 struct RowMap {
   int rowBegin, tileRows, shard, numShards;
+  int relief;  // the partition's root relief (rm_internal.h: 0 = tile t belongs to shard t mod numShards)
   __host__ __device__ int frameRow(int r) const {
-    return rowBegin + ((r / tileRows) * numShards + shard) * tileRows + (r % tileRows);
+    return rowBegin + tile_of(shard, r / tileRows, numShards, relief) * tileRows + (r % tileRows);
   }
 };
 

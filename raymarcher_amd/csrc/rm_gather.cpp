@@ -148,7 +148,7 @@ extern "C" {
 
 int rm_gather_slot_rows(int H, int tileRows, int numShards) {
   if (H <= 0 || tileRows <= 0 || numShards <= 0) return 0;
-  return shard_rows(H, tileRows, 0, numShards);  // shard 0 owns the most rows: equal slots of that size hold every shard
+  return max_shard_rows(H, tileRows, numShards, root_relief());  // equal slots of the largest shard's size hold every shard
 }
 
 int rm_gather_create_ex(const int *devices, int numDevices, unsigned flags, RmGather **out) {
@@ -192,7 +192,7 @@ int rm_gather_tiles(RmGather *g, const float *const *d_tiles, float *d_gathered,
   const int n = (int)g->devices.size();
   if (root < 0 || root >= n) { set_error("root out of range"); return RM_ERR_INVALID_ARGUMENT; }
   std::vector<size_t> count(n);
-  for (int k = 0; k < n; k++) count[k] = (size_t)shard_rows(H, tileRows, k, n) * W * 4;
+  for (int k = 0; k < n; k++) count[k] = (size_t)shard_rows(H, tileRows, k, n, root_relief()) * W * 4;
   return gather_elems(g, reinterpret_cast<const void *const *>(d_tiles), d_gathered, count, (size_t)rm_gather_slot_rows(H, tileRows, n) * W * 4,
                       sizeof(float), ncclFloat, root, streams);
 }
@@ -203,7 +203,7 @@ int rm_gather_tiles_rgba8(RmGather *g, const uint8_t *const *d_tiles8, uint8_t *
   const int n = (int)g->devices.size();
   if (root < 0 || root >= n) { set_error("root out of range"); return RM_ERR_INVALID_ARGUMENT; }
   std::vector<size_t> count(n);
-  for (int k = 0; k < n; k++) count[k] = (size_t)shard_rows(H, tileRows, k, n) * W * 4;  // bytes: 4 per pixel
+  for (int k = 0; k < n; k++) count[k] = (size_t)shard_rows(H, tileRows, k, n, root_relief()) * W * 4;  // bytes: 4 per pixel
   return gather_elems(g, reinterpret_cast<const void *const *>(d_tiles8), d_gathered8, count, (size_t)rm_gather_slot_rows(H, tileRows, n) * W * 4,
                       1, ncclUint8, root, streams);
 }

@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,8 +21,10 @@
 namespace rm {
 namespace {
 thread_local std::string t_error;
+std::atomic<int> g_rootRelief{0};  // rm_set_root_relief: the partition's root relief, process-wide
 }
 void set_error(const std::string &msg) { t_error = msg; }
+int root_relief() { return g_rootRelief.load(); }
 
 }  // namespace rm
 
@@ -139,13 +142,19 @@ int rm_camera_build(const RmCameraData *cd, int W, int H, float nearPlane, float
 
 int rm_shard_rows(int H, int tileRows, int shard, int numShards) {
   if (H <= 0 || tileRows <= 0 || numShards <= 0 || shard < 0 || shard >= numShards) return -1;
-  return shard_rows(H, tileRows, shard, numShards);
+  return shard_rows(H, tileRows, shard, numShards, root_relief());
 }
 int rm_shard_row_to_frame(int H, int tileRows, int shard, int numShards, int localRow) {
   if (H <= 0 || tileRows <= 0 || numShards <= 0 || shard < 0 || shard >= numShards) return -1;
-  if (localRow < 0 || localRow >= shard_rows(H, tileRows, shard, numShards)) return -1;
-  return ((localRow / tileRows) * numShards + shard) * tileRows + (localRow % tileRows);
+  if (localRow < 0 || localRow >= shard_rows(H, tileRows, shard, numShards, root_relief())) return -1;
+  return tile_of(shard, localRow / tileRows, numShards, root_relief()) * tileRows + (localRow % tileRows);
 }
+int rm_set_root_relief(int K) {
+  if (K != 0 && (K < 2 || K > 64)) { set_error("root relief must be 0 (off) or 2..64"); return RM_ERR_INVALID_ARGUMENT; }
+  g_rootRelief.store(K);
+  return RM_OK;
+}
+int rm_get_root_relief(void) { return g_rootRelief.load(); }
 
 // ---- PNG reader (stands in for QImage::load → RGBA8888 → mirrored(), raymarchscene.cpp:198-209) ------------
 namespace {

@@ -317,27 +317,29 @@ __global__ void tiles_to_rgba8_kernel(const float4 *__restrict__ in, uchar4 *__r
 }
 // gathered RGBA8 slots → frame rows (flip: row 0 of the output is the top of the image, as rm_frame_to_rgba8 writes it)
 __global__ void deinterleave_rgba8_kernel(const uchar4 *__restrict__ in, uchar4 *__restrict__ out, int W, int H, int tileRows,
-                                          int numShards, int strideRows, int flip) {
+                                          int numShards, int strideRows, int flip, int relief) {
   int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;  // y = frame row (0 = bottom)
   if (x >= W) return;
-  int tile = y / tileRows, shard = tile % numShards;
+  int shard, localTile;
+  tile_owner(y / tileRows, numShards, relief, shard, localTile);
   int before = shard * strideRows;
   if (strideRows == 0)
-    for (int s = 0; s < shard; s++) before += shard_rows(H, tileRows, s, numShards);
-  int local = (tile / numShards) * tileRows + (y % tileRows);
+    for (int s = 0; s < shard; s++) before += shard_rows(H, tileRows, s, numShards, relief);
+  int local = localTile * tileRows + (y % tileRows);
   out[(size_t)(flip ? H - 1 - y : y) * W + x] = in[(size_t)(before + local) * W + x];
 }
 // gathered[shard-major packed rows] → frame rows
 __global__ void deinterleave_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int W, int H, int tileRows,
-                                    int numShards, int strideRows) {
+                                    int numShards, int strideRows, int relief) {
   int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;  // y = frame row
   if (x >= W) return;
-  int tile = y / tileRows, shard = tile % numShards;
+  int shard, localTile;
+  tile_owner(y / tileRows, numShards, relief, shard, localTile);
   // rows owned by shards < shard, plus this shard's rows before frame row y
   int before = shard * strideRows;
   if (strideRows == 0)
-    for (int s = 0; s < shard; s++) before += shard_rows(H, tileRows, s, numShards);
-  int local = (tile / numShards) * tileRows + (y % tileRows);
+    for (int s = 0; s < shard; s++) before += shard_rows(H, tileRows, s, numShards, relief);
+  int local = localTile * tileRows + (y % tileRows);
   out[(size_t)y * W + x] = in[(size_t)(before + local) * W + x];
 }
 
@@ -1252,7 +1254,7 @@ int rm_render(const RmCamera *cam, const RmObject *objs, int numObjects, const R
               float *d_bright, void *stream) {
   if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
   int n = rowEnd - rowBegin;
-  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1, 0};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
                        static_cast<hipStream_t>(stream), 0, nullptr);
 }
@@ -1262,7 +1264,7 @@ int rm_render_ex(const RmCamera *cam, const RmObject *objs, int numObjects, cons
                  int rowBegin, int rowEnd, float *d_rgba, float *d_bright, void *stream) {
   if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
   int n = rowEnd - rowBegin;
-  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1, 0};
   RmResources res{};
   res.textures = textures; res.numTextures = numTextures;
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
@@ -1274,7 +1276,7 @@ int rm_render_res(const RmCamera *cam, const RmObject *objs, int numObjects, con
                   float *d_rgba, float *d_bright, void *stream) {
   if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
   int n = rowEnd - rowBegin;
-  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1, 0};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright,
                        static_cast<hipStream_t>(stream), 0, nullptr, res ? *res : kNoResources);
 }
@@ -1285,7 +1287,7 @@ int rm_render_counted_ex(const RmCamera *cam, const RmObject *objs, int numObjec
   if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
   if (mode != RM_COUNT_REFERENCE && mode != RM_COUNT_EXECUTED) { set_error("bad counting mode"); return RM_ERR_INVALID_ARGUMENT; }
   int n = rowEnd - rowBegin;
-  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1, 0};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, mode, out);
 }
 int rm_render_counted_res(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
@@ -1294,7 +1296,7 @@ int rm_render_counted_res(const RmCamera *cam, const RmObject *objs, int numObje
   if (rowBegin < 0 || rowEnd > H || rowBegin > rowEnd) { set_error("rows out of range"); return RM_ERR_INVALID_ARGUMENT; }
   if (mode != RM_COUNT_REFERENCE && mode != RM_COUNT_EXECUTED) { set_error("bad counting mode"); return RM_ERR_INVALID_ARGUMENT; }
   int n = rowEnd - rowBegin;
-  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1};
+  RowMap map{rowBegin, n > 0 ? n : 1, 0, 1, 0};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, n, d_rgba, d_bright, nullptr, mode, out,
                        res ? *res : kNoResources);
 }
@@ -1318,7 +1320,7 @@ int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects,
     set_error("rm_render_clocked covers the single-Mandelbulb class and the plain table walk (no samplers, no procedural layers)");
     return RM_ERR_UNSUPPORTED;
   }
-  RowMap map{0, H > 0 ? H : 1, 0, 1};
+  RowMap map{0, H > 0 ? H : 1, 0, 1, 0};
   return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, H, d_rgba, nullptr, nullptr, 3, nullptr,
                        kNoResources, shaderMHz, d_waveSpans);
 }
@@ -1330,8 +1332,8 @@ int rm_render_tiles(const RmCamera *cam, const RmObject *objs, int numObjects, c
     set_error("bad tile partition");
     return RM_ERR_INVALID_ARGUMENT;
   }
-  RowMap map{0, tileRows, shard, numShards};
-  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards),
+  RowMap map{0, tileRows, shard, numShards, root_relief()};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards, root_relief()),
                        d_rgba, d_bright, static_cast<hipStream_t>(stream), 0, nullptr);
 }
 
@@ -1342,15 +1344,15 @@ int rm_render_tiles_res(const RmCamera *cam, const RmObject *objs, int numObject
     set_error("bad tile partition");
     return RM_ERR_INVALID_ARGUMENT;
   }
-  RowMap map{0, tileRows, shard, numShards};
-  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards),
+  RowMap map{0, tileRows, shard, numShards, root_relief()};
+  return launch_render(cam, objs, numObjects, lights, numLights, g, s, W, H, map, shard_rows(H, tileRows, shard, numShards, root_relief()),
                        d_rgba, d_bright, static_cast<hipStream_t>(stream), 0, nullptr, res ? *res : kNoResources);
 }
 
 int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int tileRows, int numShards,
                     int shardStrideRows, void *stream) {
   if (!d_gathered || !d_frame || W <= 0 || H <= 0 || tileRows <= 0 || numShards <= 0 || numShards > 64 ||
-      (shardStrideRows != 0 && shardStrideRows < shard_rows(H, tileRows, 0, numShards))) {
+      (shardStrideRows != 0 && shardStrideRows < max_shard_rows(H, tileRows, numShards, root_relief()))) {
     set_error("bad deinterleave arguments");
     return RM_ERR_INVALID_ARGUMENT;
   }
@@ -1358,7 +1360,7 @@ int rm_deinterleave(const float *d_gathered, float *d_frame, int W, int H, int t
   dim3 grid((W + 255) / 256, H), block(256);
   hipLaunchKernelGGL(deinterleave_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4 *>(d_gathered), reinterpret_cast<float4 *>(d_frame), W, H, tileRows,
-                     numShards, shardStrideRows);
+                     numShards, shardStrideRows, root_relief());
   HIP_OK(hipGetLastError());
   return RM_OK;
 }
@@ -1377,7 +1379,7 @@ int rm_tiles_to_rgba8(const float *d_tiles, uint8_t *d_tiles8, int W, int rows, 
 int rm_deinterleave_rgba8(const uint8_t *d_gathered8, uint8_t *d_frame8, int W, int H, int tileRows, int numShards,
                           int shardStrideRows, int flip, void *stream) {
   if (!d_gathered8 || !d_frame8 || W <= 0 || H <= 0 || tileRows <= 0 || numShards <= 0 || numShards > 64 ||
-      (shardStrideRows != 0 && shardStrideRows < shard_rows(H, tileRows, 0, numShards))) {
+      (shardStrideRows != 0 && shardStrideRows < max_shard_rows(H, tileRows, numShards, root_relief()))) {
     set_error("bad deinterleave arguments");
     return RM_ERR_INVALID_ARGUMENT;
   }
@@ -1385,7 +1387,7 @@ int rm_deinterleave_rgba8(const uint8_t *d_gathered8, uint8_t *d_frame8, int W, 
   dim3 grid((W + 255) / 256, H), block(256);
   hipLaunchKernelGGL(deinterleave_rgba8_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const uchar4 *>(d_gathered8), reinterpret_cast<uchar4 *>(d_frame8), W, H, tileRows, numShards,
-                     shardStrideRows, flip);
+                     shardStrideRows, flip, root_relief());
   HIP_OK(hipGetLastError());
   return RM_OK;
 }

@@ -22,8 +22,8 @@ class ShardPlan:
 
     @property
     def slot_rows(self):
-        """Rows of one gather slot: shard 0 always owns the most rows, so every slot is sized for it."""
-        return self.rows(0)
+        """Rows of one gather slot: the largest shard's (shard 0, or shard 1 under rm_set_root_relief), so every slot holds any shard."""
+        return max(self.rows(k) for k in range(min(self.world, 2)))
 
     def frame_rows(self, rank):
         """Frame row of each packed row of `rank` (rm_shard_row_to_frame)."""

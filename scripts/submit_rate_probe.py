@@ -24,17 +24,33 @@ def main():
     import bench
     from raymarcher_amd import Renderer
     from raymarcher_amd.dist import FramePipeline, ShardPlan
+    from raymarcher_amd import lib
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    relief = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     N = 8
     r = Renderer(0)
     tables, settings, W, H, _ = bench.build_config(cfg)
+    assert lib().rm_set_root_relief(relief) == 0
     plan = ShardPlan(H, bench.TILE_ROWS, N)
     my_rows, slot_rows = plan.rows(0), plan.slot_rows
 
     def fake_gather(local, outs, dst=0, async_op=False):  # rank 0's own slot travels by a device copy; peers' slots keep old data
-        outs[0].copy_(local, non_blocking=True)
+        if outs is not None:
+            outs[0].copy_(local, non_blocking=True)
         return _Work()
     dist.gather = fake_gather
+    if relief:  # what a PEER has to sustain under the relief partition (rank 1 owns the most rows; no de-interleave, no receives)
+        rows1 = plan.rows(1)
+        pipe1 = FramePipeline(plan, 1, (W, 4), torch.float32, r.device, depth=3, multi_stream=True)
+        sub1 = lambda: pipe1.submit(lambda slot: r.render_tiles(tables, settings, W, H, bench.TILE_ROWS, 1, N, out=slot[:rows1]))
+        for _ in range(30):
+            sub1()
+        pipe1.drain(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            sub1()
+        pipe1.drain(); torch.cuda.synchronize()
+        print(f"{cfg}, root relief {relief}: rank 1's shard ({rows1} of {H} rows) through FramePipeline: wall {(time.perf_counter() - t0) / 300 * 1e3:.3f} ms per frame")
     frame = {}
     pipe = FramePipeline(plan, 0, (W, 4), torch.float32, r.device, depth=3, multi_stream=True,
                          finish=lambda g: frame.__setitem__("f", r.deinterleave(g, W, H, bench.TILE_ROWS, N, slot_rows)))
@@ -52,7 +68,7 @@ def main():
     submit = lambda: pipe.submit(lambda slot: r.render_tiles(tables, settings, W, H, bench.TILE_ROWS, 0, N, out=slot[:my_rows]))
     run(30, submit)
     host, wall = run(300, submit)
-    print(f"{cfg}: 1/{N} shard ({my_rows} of {H} rows) through FramePipeline, three frames in flight: host {host:.3f} ms per submit "
+    print(f"{cfg}, root relief {relief}: rank 0's shard ({my_rows} of {H} rows) through FramePipeline, three frames in flight: host {host:.3f} ms per submit "
           f"({1e3 / host:.0f} submits/s), wall {wall:.3f} ms per frame; budget for 6x at N = {N}: "
           f"{bench_ms(cfg) / 6:.3f} ms")
     # the pure host cost of a submit: the same pipeline over a frame so small that the GPU never holds the host back

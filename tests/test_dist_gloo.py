@@ -19,6 +19,8 @@ from raymarcher_amd.dist import ShardPlan, gather_to_root, deinterleave_host
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 W, H, T = 40, 50, 8            # last tile is partial
+from raymarcher_amd import lib
+lib().rm_set_root_relief(int(os.environ.get("RM_TEST_RELIEF", "0")))   # every rank the same partition
 plan = ShardPlan(H, T, world)
 scene = h.scene_mandelbulb(W, H)
 s = abi.default_settings(fractalIters=12)
@@ -41,14 +43,15 @@ sys.exit(0 if int(flag.item()) == 1 else 3)
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_shard_gather_deinterleave_gloo(world, tmp_path):
+@pytest.mark.parametrize("world,relief", [(2, 0), (3, 0), (3, 2), (2, 3)])
+def test_shard_gather_deinterleave_gloo(world, relief, tmp_path):
+    """… also under rm_set_root_relief (rank 0 owns fewer tiles: the largest slot is rank 1's)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    port = 29400 + world + (os.getpid() % 500)
+    port = 29400 + world + 7 * relief + (os.getpid() % 500)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", RM_TEST_RELIEF=str(relief))
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
 
@@ -61,6 +64,8 @@ from raymarcher_amd.dist import FramePipeline, ShardPlan, deinterleave_host
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 W, H, T, K = 6, 53, 8, 5
+from raymarcher_amd import lib
+lib().rm_set_root_relief(int(os.environ.get("RM_TEST_RELIEF", "0")))
 plan = ShardPlan(H, T, world)
 rows = torch.tensor(plan.frame_rows(rank), dtype=torch.float32)
 frames = []
@@ -90,7 +95,8 @@ sys.exit(0 if int(flag.item()) == 1 else 3)
 
 
 @pytest.mark.parametrize("world,depth,dtype,rotate", [(2, 2, "float32", 0), (4, 2, "float32", 0), (2, 3, "float32", 0), (3, 4, "float32", 0),
-                                                      (2, 3, "uint8", 0), (3, 3, "float32", 1), (4, 2, "float32", 1), (2, 3, "uint8", 1)])
+                                                      (2, 3, "uint8", 0), (3, 3, "float32", 1), (4, 2, "float32", 1), (2, 3, "uint8", 1),
+                                                      (3, 3, "float32", 2)])
 def test_frame_pipeline_gloo(world, depth, dtype, rotate, tmp_path):
     """The pipelined gather bench.py uses for N > 1 (`depth` frames in flight: frame i's gather under the renders of the
     frames after it): every frame arrives complete, in order, through the right slot — on rank 0, or with rotate_root on rank
@@ -100,5 +106,5 @@ def test_frame_pipeline_gloo(world, depth, dtype, rotate, tmp_path):
     port = 29900 + world + 10 * depth + 50 * rotate + (os.getpid() % 400)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth), RM_TEST_DTYPE=dtype, RM_TEST_ROTATE=str(rotate)), capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", RM_TEST_DEPTH=str(depth), RM_TEST_DTYPE=dtype, RM_TEST_ROTATE=str(rotate & 1), RM_TEST_RELIEF="2" if rotate == 2 else "0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

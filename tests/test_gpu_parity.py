@@ -830,6 +830,46 @@ def test_tiles_gather_roundtrip(renderer):
         assert_bit_equal(frame.cpu().numpy(), ref, f"deinterleave {shards}")
 
 
+def test_tiles_gather_roundtrip_with_root_relief(renderer):
+    """rm_set_root_relief(K): shard 0 (the gather's root) owns (K − 1)/K of a peer's tiles.  Every shard's rows are the frame's, the
+    packed concatenation and the slotted gather layout (equal slots of the LARGEST shard — shard 1 now) de-interleave to the frame,
+    as float4 and as RGBA8 (flipped and not)."""
+    import torch
+    from raymarcher_amd import lib
+    L = lib()
+    W, H, T = 48, 210, 8  # 27 tiles, the last one partial
+    scene = h.scene_mandelbulb(W, H)
+    t = tables_of(scene)
+    s = abi.default_settings(fractalIters=10)
+    ref = h.oracle_render(scene, s, W, H)
+    full = renderer.render(t, s, W, H)
+    img = renderer.to_rgba8(full)  # flipped: row 0 = top
+    try:
+        for shards, K in ((2, 2), (3, 4), (4, 8), (8, 8), (8, 2)):
+            assert L.rm_set_root_relief(K) == 0
+            parts = [renderer.render_tiles(t, s, W, H, T, k, shards) for k in range(shards)]
+            assert [p.shape[0] for p in parts] == [L.rm_shard_rows(H, T, k, shards) for k in range(shards)] and sum(p.shape[0] for p in parts) == H
+            assert parts[0].shape[0] <= parts[1].shape[0]  # the root is relieved (a frame shorter than one cycle of the deal may not show it)
+            if K == 2:
+                assert parts[0].shape[0] < parts[1].shape[0]
+            for k, p in enumerate(parts):
+                rows = [L.rm_shard_row_to_frame(H, T, k, shards, r) for r in range(p.shape[0])]
+                assert_bit_equal(p.cpu().numpy(), ref[rows], f"shard {k}/{shards}, relief {K}")
+            assert _ieq(renderer.deinterleave(torch.cat(parts, 0).contiguous(), W, H, T, shards), full)
+            slot = L.rm_gather_slot_rows(H, T, shards)
+            assert slot == max(p.shape[0] for p in parts)
+            gathered = torch.zeros((shards * slot, W, 4), dtype=torch.float32, device=full.device)
+            g8 = torch.zeros((shards * slot, W, 4), dtype=torch.uint8, device=full.device)
+            for k, p in enumerate(parts):
+                gathered[k * slot:k * slot + p.shape[0]] = p
+                g8[k * slot:k * slot + p.shape[0]] = renderer.tiles_to_rgba8(p)
+            assert _ieq(renderer.deinterleave(gathered, W, H, T, shards, slot), full)
+            assert bool((renderer.deinterleave_rgba8(g8, W, H, T, shards, slot, flip=True) == img).all())
+            assert bool((renderer.deinterleave_rgba8(g8, W, H, T, shards, slot, flip=False) == img.flip(0)).all())
+    finally:
+        L.rm_set_root_relief(0)
+
+
 def test_unsupported_and_invalid_inputs(renderer):
     from raymarcher_amd import RaymarcherError
     W, H = 8, 8
