@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict_
 // 4K frames (scripts/cold_order_probe.py, profiles/r04_k_geometric_order.md): bulb 2.85 → 2.26 ms (measured costs: 1.99),
 // directional_light_2.json 1.89 → 1.77-1.81, reflections_complex.json 8.70 → 8.39-8.44.  Same pixels.
 __global__ __launch_bounds__(256) void tile_geom_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H, int nRows, int tilesX,
-                                                        int tileW, int tileH, int n, uint32_t *__restrict__ cost, int combine) {
+                                                        int tileW, int tileH, int n, uint32_t *__restrict__ cost, int combine, int ringLog2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int x = (i % tilesX) * tileW + tileW / 2, r = (i / tilesX) * tileH + tileH / 2;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void tile_geom_kernel(const SceneBlock *__rest
     const float q2 = dot(v, v) - tca * tca, hi = fma(foot, tca, R), lo = 0.6f * R;
     if (tca > 0.0f && q2 <= hi * hi) cls = (q2 >= lo * lo) ? 2 : (cls > 1 ? cls : 1);
   }
-  const uint32_t gv = cls == 2 ? (1u << 16) : (cls == 1 ? (1u << 11) : (1u << 4));
+  const uint32_t gv = cls == 2 ? (1u << ringLog2) : (cls == 1 ? (1u << 11) : (1u << 4));
   // combine: a frame of the same size rendered a DIFFERENT picture before (a moving camera) — its measured costs are stale but near;
   // the heavier of the two estimates decides
   cost[i] = (combine && cost[i] > gv) ? cost[i] : gv;
@@ -1107,6 +1107,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   // and no procedural layers (their cost is not where the objects are); otherwise raster order.
   static const int geomMode = [] { const char *e = std::getenv("RM_TILE_ORDER_GEOMETRIC"); return e ? std::atoi(e) : 2; }();  // 0 off (raster), 1 geometry alone, 2 geometry + stale costs (measured best, default)
   const bool geomOn = geomMode != 0;
+  static const int ringCombined = [] { const char *e = std::getenv("RM_GEOM_RING_LOG2"); const int v = e ? std::atoi(e) : 16; return v < 5 ? 5 : (v > 17 ? 17 : v); }();
   const bool byCost = ordered && samePicture;
   bool byGeom = ordered && !samePicture && geomOn && !envFeatures && numObjects > 0;
   Slot *slot;
@@ -1168,7 +1169,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if (byCost || byGeom) {  // this frame's launch order — from the previous frame's tile costs or from geometry — ahead of the render
       const dim3 sgrid((tileCount + 255) / 256);
       if (byGeom) hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * tileW, tileH, tileCount, oCost,
-                                     (geomMode == 2 && haveCost) ? 1 : 0);
+                                     (geomMode == 2 && haveCost) ? 1 : 0, ((geomMode == 2 && haveCost) ? ringCombined : 16));
       HIP_OK(hipMemsetAsync(oHist, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist);
       hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder);
