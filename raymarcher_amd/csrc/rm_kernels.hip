@@ -1038,7 +1038,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   int tileShift = (RM_TILE_W == 8) ? 3 : (RM_TILE_W == 4 ? 2 : (RM_TILE_W == 16 ? 4 : 3));
   ShapeTune *tune = nullptr;  // non-null: this launch is one of the tuner's (frames 0-3 of a picture) or follows its choice
   int tuneTimed = -1;         // 0..3: time this launch as the tuner's candidate (k & 1: 0 = 8×8, 1 = 4×16) of round k >> 1
-  if (shapeReq == 2 || shapeReq == 3) tileShift = shapeReq;
+  if ((shapeReq == 2 || shapeReq == 3) && count == 0) tileShift = shapeReq;  // the counted / stamped diagnostic builds keep 8×8 (their callers size per-wave arrays by it)
   else if (RM_TILE_W == 8 && !bulb && !wavefront && !g->isTwoD && count == 0 && bigFrame && !ds.dbgTileOrder && !ds.dbgTileCost) {
     tune = &ds.shapeTune[stream];
     if (tune->key != key || tune->W != W || tune->nRows != nRows) {
