@@ -20,7 +20,7 @@
 namespace rm {
 namespace {
 
-struct half4 { __half x, y, z, w; };
+struct alignas(8) half4 { __half x, y, z, w; };  // 8-byte aligned: one 64-bit global / LDS access per texel
 
 __device__ __forceinline__ float q16(float v) { return __half2float(__float2half_rn(v)); }
 __device__ __forceinline__ unsigned char to8(float v) {
@@ -28,13 +28,6 @@ __device__ __forceinline__ unsigned char to8(float v) {
   return (unsigned char)(int)fma(v, 255.0f, 0.5f);
 }
 __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
-
-__global__ void bright_to_half_kernel(const float4 *__restrict__ in, half4 *__restrict__ out, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 c = in[i];
-  out[i] = half4{__float2half_rn(c.x), __float2half_rn(c.y), __float2half_rn(c.z), __float2half_rn(1.0f)};
-}
 
 // blur.frag:9-31, CLAMP_TO_EDGE, taps on texel centres
 __global__ void blur_kernel(const half4 *__restrict__ src, half4 *__restrict__ dst, int W, int H, int horizontal) {
@@ -65,19 +58,39 @@ __global__ void blur_kernel(const half4 *__restrict__ src, half4 *__restrict__ d
 // pixel to 1.4 reads + 1 write.  Rows/columns outside the image replicate the edge (CLAMP_TO_EDGE) by clamping the
 // GLOBAL coordinate when the tile is staged, which is what clamping each tap does.
 constexpr int kBlurTW = 64, kBlurTH = 32, kBlurR = 4;
-__global__ __launch_bounds__(256) void blur_pair_kernel(const half4 *__restrict__ src, half4 *__restrict__ dst, int W, int H) {
+// F32SRC: `srcv` is the float BrightColor plane (pass 1): the staging step rounds it to binary16 as the reference's RGBA16F
+// colour attachment does, so no separate conversion pass (and its 8 B/pixel round trip) is needed.
+template <bool F32SRC>
+__global__ __launch_bounds__(256) void blur_pair_kernel(const void *__restrict__ srcv, half4 *__restrict__ dst, int W, int H) {
   constexpr int SW = kBlurTW + 2 * kBlurR, SH = kBlurTH + 2 * kBlurR;  // staged source: 72 × 40
+  constexpr int kStage = SW * SH, kPer = (kStage + 255) / 256;
   __shared__ half4 s_src[SH][SW];
   __shared__ half4 s_h[SH][kBlurTW];
   const float w[5] = {0.2270270270f, 0.1945945946f, 0.1216216216f, 0.0540540541f, 0.0162162162f};
   const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
-  for (int i = threadIdx.x; i < SW * SH; i += 256) {
-    const int lx = i % SW, ly = i / SW;
-    s_src[ly][lx] = src[(size_t)clampi(y0 - kBlurR + ly, H) * W + clampi(x0 - kBlurR + lx, W)];
+  {  // every load of the thread is issued before the first LDS write waits for one (a load-wait-write loop is latency-bound)
+    using Texel = typename std::conditional<F32SRC, float4, half4>::type;
+    const Texel *src = static_cast<const Texel *>(srcv);
+    Texel t[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int i = threadIdx.x + k * 256, lx = i % SW, ly = i / SW;
+      if (i < kStage) t[k] = src[(size_t)clampi(y0 - kBlurR + ly, H) * W + clampi(x0 - kBlurR + lx, W)];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int i = threadIdx.x + k * 256, lx = i % SW, ly = i / SW;
+      if (i < kStage) {
+        if constexpr (F32SRC) s_src[ly][lx] = half4{__float2half_rn(t[k].x), __float2half_rn(t[k].y), __float2half_rn(t[k].z), __float2half_rn(1.0f)};
+        else s_src[ly][lx] = t[k];
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kBlurTW * SH; i += 256) {  // horizontal pass on every staged row
-    const int lx = i % kBlurTW, ly = i / kBlurTW;
+  static_assert((kBlurTW * SH) % 256 == 0 && (kBlurTW * kBlurTH) % 256 == 0, "whole rounds of the block");
+#pragma unroll 2
+  for (int k0 = 0; k0 < kBlurTW * SH / 256; k0++) {  // horizontal pass on every staged row
+    const int i = threadIdx.x + k0 * 256, lx = i % kBlurTW, ly = i / kBlurTW;
     const half4 c = s_src[ly][lx + kBlurR];
     float r = __half2float(c.x) * w[0], g = __half2float(c.y) * w[0], b = __half2float(c.z) * w[0];
 #pragma unroll
@@ -90,8 +103,9 @@ __global__ __launch_bounds__(256) void blur_pair_kernel(const half4 *__restrict_
     s_h[ly][lx] = half4{__float2half_rn(r), __float2half_rn(g), __float2half_rn(b), __float2half_rn(1.0f)};
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kBlurTW * kBlurTH; i += 256) {  // vertical pass on the tile
-    const int lx = i % kBlurTW, ly = i / kBlurTW;
+#pragma unroll 2
+  for (int k0 = 0; k0 < kBlurTW * kBlurTH / 256; k0++) {  // vertical pass on the tile
+    const int i = threadIdx.x + k0 * 256, lx = i % kBlurTW, ly = i / kBlurTW;
     const int x = x0 + lx, y = y0 + ly;
     if (x >= W || y >= H) continue;
     const half4 c = s_h[ly + kBlurR][lx];
@@ -107,27 +121,54 @@ __global__ __launch_bounds__(256) void blur_pair_kernel(const half4 *__restrict_
   }
 }
 
-// hdr.frag:13-35.  Writes either the float frame (no FXAA afterwards) or the RGBA8 FXAA source.
-__global__ void light_kernel(const float4 *__restrict__ frag, const half4 *__restrict__ bloom, float4 *__restrict__ outF,
-                             uchar4 *__restrict__ out8, int n, int hdr, int useBloom, float exposure) {
+// hdr.frag:13-35 without bloom (with it: light_bloom_kernel).  Writes either the float frame (no FXAA afterwards) or the RGBA8 FXAA
+// source.
+__global__ void light_kernel(const float4 *__restrict__ frag, float4 *__restrict__ outF, uchar4 *__restrict__ out8, int n, int hdr,
+                             float exposure) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 f = frag[i];
-  float c[3] = {q16(f.x), q16(f.y), q16(f.z)};
+  const float c[3] = {q16(f.x), q16(f.y), q16(f.z)};
   float r[3];
-  if (!hdr && !useBloom) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) r[k] = pow_(c[k], 1.0f / 2.2f);
-  } else {
-    if (useBloom) {
-      half4 b = bloom[i];
-      c[0] = c[0] + __half2float(b.x); c[1] = c[1] + __half2float(b.y); c[2] = c[2] + __half2float(b.z);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) r[k] = 1.0f - exp_((-c[k]) * exposure);
-  }
+  for (int k = 0; k < 3; k++) r[k] = hdr ? 1.0f - exp_((-c[k]) * exposure) : pow_(c[k], 1.0f / 2.2f);
   if (out8) out8[i] = make_uchar4(to8(r[0]), to8(r[1]), to8(r[2]), 255);
   else outF[i] = make_float4(r[0], r[1], r[2], 1.0f);
+}
+
+// applyBloom's last pass (pass 9, horizontal) and the hdr.frag composite in one launch: a block owns 256 pixels of one row, stages
+// the 264 source texels in LDS, blurs them — the sum rounded to binary32 and then to binary16, the value the ping-pong target would
+// have held — and composites.  Saves the 8 B/pixel written and re-read between the two and a pass whose nine taps per pixel
+// came through L1.
+__global__ __launch_bounds__(256) void light_bloom_kernel(const float4 *__restrict__ frag, const half4 *__restrict__ src, float4 *__restrict__ outF,
+                                                          uchar4 *__restrict__ out8, int W, int H, float exposure) {
+  __shared__ half4 s_row[256 + 2 * kBlurR];
+  const float w[5] = {0.2270270270f, 0.1945945946f, 0.1216216216f, 0.0540540541f, 0.0162162162f};
+  const int x0 = blockIdx.x * 256, y = blockIdx.y, x = x0 + threadIdx.x;
+  const half4 *row = src + (size_t)y * W;
+  s_row[threadIdx.x] = row[clampi(x0 - kBlurR + (int)threadIdx.x, W)];
+  if (threadIdx.x < 2 * kBlurR) s_row[256 + threadIdx.x] = row[clampi(x0 - kBlurR + 256 + (int)threadIdx.x, W)];
+  float4 f = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (x < W) f = frag[(size_t)y * W + x];
+  __syncthreads();
+  if (x >= W) return;
+  const int lx = threadIdx.x + kBlurR;
+  const half4 c0 = s_row[lx];
+  float r = __half2float(c0.x) * w[0], g = __half2float(c0.y) * w[0], b = __half2float(c0.z) * w[0];
+#pragma unroll
+  for (int k = 1; k < 5; k++) {
+    const half4 p = s_row[lx + k], m = s_row[lx - k];
+    r = fma(__half2float(p.x), w[k], r); g = fma(__half2float(p.y), w[k], g); b = fma(__half2float(p.z), w[k], b);
+    r = fma(__half2float(m.x), w[k], r); g = fma(__half2float(m.y), w[k], g); b = fma(__half2float(m.z), w[k], b);
+  }
+  asm volatile("" : "+v"(r), "+v"(g), "+v"(b));  // binary32 first, then binary16 (see blur_kernel)
+  const float c[3] = {q16(f.x) + q16(r), q16(f.y) + q16(g), q16(f.z) + q16(b)};
+  float o[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) o[k] = 1.0f - exp_((-c[k]) * exposure);
+  const size_t i = (size_t)y * W + x;
+  if (out8) out8[i] = make_uchar4(to8(o[0]), to8(o[1]), to8(o[2]), 255);
+  else outF[i] = make_float4(o[0], o[1], o[2], 1.0f);
 }
 
 __global__ void quant8_kernel(const float4 *__restrict__ frag, uchar4 *__restrict__ out8, int n) {
@@ -271,20 +312,20 @@ extern "C" int rm_post_process(const float *d_frag, const float *d_bright, float
     return RM_OK;
   }
   if (light) {
-    const half4 *bloom = nullptr;
     if (ps->enableBloom) {  // applyBloom: 10 passes H,V,H,…; the composite reads the buffer pass 9 wrote
-      hipLaunchKernelGGL(bright_to_half_kernel, lin, blk, 0, st, reinterpret_cast<const float4 *>(d_bright), pa, (int)n);
       half4 *src = pa, *dst = pb;
       const dim3 tiles((W + kBlurTW - 1) / kBlurTW, (H + kBlurTH - 1) / kBlurTH);
-      for (int i = 0; i < 4; i++) {  // passes 1-8 as four horizontal+vertical pairs through LDS
-        hipLaunchKernelGGL(blur_pair_kernel, tiles, blk, 0, st, src, dst, W, H);
+      // passes 1-8 as four horizontal+vertical pairs through LDS; the first reads the float BrightColor plane directly
+      hipLaunchKernelGGL(blur_pair_kernel<true>, tiles, blk, 0, st, static_cast<const void *>(d_bright), src, W, H);
+      for (int i = 1; i < 4; i++) {
+        hipLaunchKernelGGL(blur_pair_kernel<false>, tiles, blk, 0, st, static_cast<const void *>(src), dst, W, H);
         half4 *t = src; src = dst; dst = t;
       }
-      hipLaunchKernelGGL(blur_kernel, grid2, blk, 0, st, src, dst, W, H, 1);  // pass 9 (horizontal), the one composited
-      bloom = dst;
+      // pass 9 (horizontal), the one composited, inside the composite
+      hipLaunchKernelGGL(light_bloom_kernel, grid2, blk, 0, st, frag, src, out, ps->enableFXAA ? stage8 : nullptr, W, H, ps->exposure);
+    } else {
+      hipLaunchKernelGGL(light_kernel, lin, blk, 0, st, frag, out, ps->enableFXAA ? stage8 : nullptr, (int)n, ps->enableHDR, ps->exposure);
     }
-    hipLaunchKernelGGL(light_kernel, lin, blk, 0, st, frag, bloom, out, ps->enableFXAA ? stage8 : nullptr, (int)n,
-                       ps->enableHDR, ps->enableBloom, ps->exposure);
   } else {
     hipLaunchKernelGGL(quant8_kernel, lin, blk, 0, st, frag, stage8, (int)n);
   }

@@ -579,6 +579,25 @@ def test_post_passes_bit_exact(renderer, name):
     assert (img == exp).all()
 
 
+@pytest.mark.parametrize("W,H", [(700, 45), (257, 33), (64, 32), (1, 1), (3, 70)])
+def test_post_passes_bit_exact_on_wide_synthetic_frames(renderer, W, H):
+    """Several 64×32 blur tiles and 256-pixel row blocks with ragged right / bottom edges (and frames smaller than one apron): the
+    fused first pass (float BrightColor staged as binary16) and the fused last pass (horizontal blur inside the composite) against
+    the oracle's ten-pass loop (realtimerender.cpp:92-108), on random frames with sparse bright pixels."""
+    import torch
+    rng = np.random.default_rng(W * 1000 + H)
+    frag = rng.random((H, W, 4), dtype=np.float32) * np.float32(1.6)
+    frag[..., 3] = 1.0
+    luma = (frag[..., :3] * np.array([0.2126, 0.7152, 0.0722], dtype=np.float32)).sum(-1, keepdims=True)
+    bright = np.where(luma > 1.0, frag, np.float32(0.0)).astype(np.float32)
+    bright[..., 3] = 1.0
+    fd, bd = torch.from_numpy(frag).to(renderer.device), torch.from_numpy(bright).to(renderer.device)
+    for name in ("bloom", "bloom_hdr_fxaa", "hdr", "gamma_fxaa"):
+        post = abi.RmPostSettings(**{"exposure": 1.0, **POST_CASES[name]})
+        got = renderer.post_process(fd, bd, post).cpu().numpy()
+        assert_bit_equal(got, h.oracle_post(frag, bright, post), f"post {name} {W}x{H}")
+
+
 def test_post_full_size_4k(renderer):
     """3840×2160: determinism, and bit equality with the oracle on a horizontal band that contains its whole
     9-tap / FXAA neighbourhood (bloom off so rows do not depend on far rows)."""
