@@ -547,8 +547,8 @@ def main():
                            "wf_surface_kernel, wf_march_kernel<2> (shadow rays), wf_light_kernel"}
         # with tile-order feedback a launch is two sort kernels (stage 0, ~0.02 ms) + the render kernel (stage 1): the roofline is
         # the render kernel's, `launch_ms` stays the whole launch
-        ordered = schedule == 1 and stages[1] > 0.0
-        render_ms = stages[1] if ordered else kernel_ms
+        ordered = schedule == 1 and stages[0] > 0.0
+        render_ms = stages[1] if stages[1] > 0.0 else kernel_ms
         # with several frames in flight (N > 1) the launches overlap and their event spans are not kernel time: the roofline is
         # then taken over the wall time one frame of this rank's shard costs
         secs = (dt / args.steps if distributed else render_ms * 1e-3)

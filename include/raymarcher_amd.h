@@ -332,9 +332,10 @@ int rm_render_clocked(const RmCamera *cam, const RmObject *objs, int numObjects,
  * hipEvents on their own stream; rm_get_* reads and resets that device's records (the on/off switch is process-wide). */
 int rm_set_timing(int on);
 int rm_get_timing(double *avgKernelMs, int *launches);
-/* Same, split by stage.  One-lane-per-pixel kernel with tile-order feedback active (rm_set_tile_order): stage 0 = the two
- * ordering launches, stage 1 = the render kernel; without it (first frame, small frames): stage 0 = the render kernel.
- * Wavefront pipeline (path 5): stage 0 = all of its kernels. */
+/* Same, split by role, both averaged over ALL the launches (total = stage 0 + stage 1): stage 1 = the render (the one-lane-per-pixel
+ * kernel, or all kernels of the wavefront pipeline), stage 0 = the tile-ordering launches that preceded it in the launches that had
+ * them (rm_set_tile_order: a new picture and the first repeats of one; a settled picture, a small frame or raster order has none).
+ * Stages 2-3 are zero. */
 int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches);
 /* Which schedule renders a frame: 0 = the measured-fastest one of the scene's class (default), 1 = one lane per pixel
  * (rm::render_kernel, every class), 5 = the wavefront pipeline of rm_wavefront.hip.h for the table-walk classes (primitives,
@@ -364,7 +365,9 @@ int rm_debug_last_path(void);
  * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely
  * waves; starting heavy tiles first removes it.  The order never changes a pixel.  mode 1 (default): every frame records each
  * tile's shader-cycle cost; the next frame of the same size on the same stream starts its tiles heaviest-first by those costs
- * when it is the SAME picture (scene tables, camera, settings, rows), and otherwise — the first frame, a moved camera, a
+ * when it is the SAME picture (scene tables, camera, settings, rows) — a picture that keeps repeating settles: from its fifth
+ * frame on the order of the fourth is reused, with no ordering launches and no cost recording (RM_TILE_ORDER_SETTLE=0: re-sort
+ * every frame) — and otherwise — the first frame, a moved camera, a
  * changed scene — by a geometric classification of the tiles (centre ray against the objects' bounding balls: silhouette rings
  * first, interiors next, background last), combined with the stale costs where a frame of that size was rendered before;
  * scenes with procedural layers or objects without a bound start new pictures in raster order.  mode 0: always raster order;

@@ -194,9 +194,10 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const uint32_t *__restri
   __syncthreads();
   if (threadIdx.x < kOrderBuckets && s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_cnt[threadIdx.x]);
 }
-// hist[0..15] = bucket sizes (from tile_hist_kernel), hist[16..31] = cursors (zero on entry).  Consumes (clears) cost[].
+// hist[0..15] = bucket sizes (from tile_hist_kernel), hist[16..31] = cursors (zero on entry).  Consumes (clears) cost[] unless
+// `keep` (the last sort of a settled picture: the costs stay as the stale costs of whatever picture comes next).
 __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict__ cost, int n, uint32_t *__restrict__ hist,
-                                                            int32_t *__restrict__ order) {
+                                                            int32_t *__restrict__ order, int keep) {
   __shared__ uint32_t s_cnt[kOrderBuckets], s_base[kOrderBuckets];
   if (threadIdx.x < kOrderBuckets) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict_
   __syncthreads();
   if (i < n) {
     order[s_base[b] + rank] = i;
-    cost[i] = 0u;  // the next frame accumulates afresh
+    if (!keep) cost[i] = 0u;  // the next frame accumulates afresh
   }
 }
 
@@ -359,6 +360,7 @@ struct TileOrderState {
   int tileCount = 0, W = 0, nRows = 0, nw = 0, tileShift = 3;
   void *mem = nullptr;
   unsigned long long sceneKey = 0;  // hash of the scene + camera + row map of the frame that recorded the costs in `mem`
+  int sorts = 0;                     // consecutive frames of that picture whose order came from measured costs
 };
 // "Tile shape": which of the two tile shapes a picture renders faster with is scene-dependent (upright objects: 4 wide × 16 tall
 // tiles straddle fewer vertical silhouettes, so whole waves agree on the table walk's shortcuts more often — C2 at 1080p 0.866 →
@@ -1089,6 +1091,13 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   uint32_t *oCost = nullptr, *oHist = nullptr;
   int32_t *oOrder = nullptr;
   bool haveCost = false, samePicture = false;
+  // A picture that repeats SETTLES: its first frames re-sort by the costs the frame before measured (each under a better order than
+  // the last); the kSettle-th such sort keeps its costs (they are the stale costs of whatever picture comes next) and from then on
+  // the same order is reused — no ordering launches (memset + two kernels, ≈25 µs a frame: 1 % of the 4K bulb frame, 8 % of its
+  // 1/8 shard) and no cost atomics in the render.  RM_TILE_ORDER_SETTLE=0: re-sort every frame (rounds 2-3).
+  static const int kSettle = [] { const char *e = std::getenv("RM_TILE_ORDER_SETTLE"); const int v = e ? std::atoi(e) : 3; return v < 0 ? 0 : (v > 1000 ? 1000 : v); }();
+  const int kSettleHold = kSettle + 1;
+  int costSorts = 0;  // this frame is the costSorts-th consecutive cost-ordered frame of its picture (0: not cost-ordered)
   if (ordered) {
     void *mem = nullptr;
     if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 8 + 256, &mem)) != RM_OK) return st;
@@ -1100,7 +1109,9 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     haveCost = ts.tileCount == now.tileCount && ts.W == W && ts.nRows == nRows && ts.nw == nw && ts.tileShift == tileShift && ts.mem == mem;
     if (!haveCost) HIP_OK(hipMemsetAsync(oCost, 0, (size_t)tileCount * 4, stream));
     samePicture = haveCost && ts.sceneKey == key;
+    costSorts = samePicture ? ts.sorts + 1 : 0;
     ts = now;
+    ts.sorts = costSorts > kSettleHold ? kSettleHold : costSorts;
   }
   // Which order this frame's tiles start in: the previous frame's measured costs when it was the same picture; otherwise — no
   // history, or the scene / camera moved — the geometric classification (tile_geom_kernel), where the scene has per-object balls
@@ -1109,10 +1120,12 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   const bool geomOn = geomMode != 0;
   static const int ringCombined = [] { const char *e = std::getenv("RM_GEOM_RING_LOG2"); const int v = e ? std::atoi(e) : 16; return v < 5 ? 5 : (v > 17 ? 17 : v); }();
   const bool byCost = ordered && samePicture;
+  const bool lastSort = byCost && kSettle > 0 && costSorts == kSettle, settled = byCost && kSettle > 0 && costSorts > kSettle;
   bool byGeom = ordered && !samePicture && geomOn && !envFeatures && numObjects > 0;
   Slot *slot;
   st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res,
-                   ordered ? ((byCost || byGeom) ? oOrder : nullptr) : ds.dbgTileOrder, ordered ? oCost : ds.dbgTileCost,
+                   ordered ? ((byCost || byGeom) ? oOrder : nullptr) : ds.dbgTileOrder,
+                   ordered ? ((lastSort || settled) ? nullptr : oCost) : ds.dbgTileCost,
                    ordered ? tileCount : ds.dbgTileCount, tileShift);
   if (st != RM_OK) return st;
   if (byGeom && !slot->host->objBallOk) {  // an object without a bounding ball (Sierpinski, 2-D Mandelbrot as an object): raster order
@@ -1166,13 +1179,13 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // instantiations <BULB, COUNT, ENV, TEX>: the bulb class and the generic table walk, plain and counted, without
     // procedural layers or textures; the generic kernel with either or both.  Features a launch does not need are
     // compiled out so the common kernels keep their register budget.
-    if (byCost || byGeom) {  // this frame's launch order — from the previous frame's tile costs or from geometry — ahead of the render
+    if ((byCost || byGeom) && !settled) {  // this frame's launch order — from the previous frame's tile costs or from geometry — ahead of the render
       const dim3 sgrid((tileCount + 255) / 256);
       if (byGeom) hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * tileW, tileH, tileCount, oCost,
                                      (geomMode == 2 && haveCost) ? 1 : 0, ((geomMode == 2 && haveCost) ? ringCombined : 16));
       HIP_OK(hipMemsetAsync(oHist, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist);
-      hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder);
+      hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder, lastSort ? 1 : 0);
       if ((st = stamp(1)) != RM_OK) return st;  // stage 0 = the ordering launches, stage 1 = the render
     }
     if (tuneTimed >= 0 && tune) {  // the tuner's timed launch of this candidate shape: events around the render kernel alone
@@ -1206,7 +1219,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       HIP_OK(hipEventRecord(tune->ev[tuneTimed][1], stream));
       tune->timed[tuneTimed] = true;
     }
-    if ((st = stamp((byCost || byGeom) ? 2 : 1)) != RM_OK) return st;
+    if ((st = stamp(((byCost || byGeom) && !settled) ? 2 : 1)) != RM_OK) return st;
   }
   HIP_OK(hipGetLastError());
   ds.lastPath = wavefront ? 5 : 1;
@@ -1436,8 +1449,10 @@ int rm_get_stage_timing(double *avgTotalMs, double avgStageMs[4], int *launches)
       continue;
     }
     total += ms;
-    for (int i = 0; i + 1 < t.n && i < 4; i++)
-      if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) stage[i] += ms;
+    // by role, whatever the launch was made of: the last interval is the render (one kernel or the wavefront pipeline's), the one
+    // before it — present only in a launch that sorted its tiles — the ordering launches
+    if (hipEventElapsedTime(&ms, t.ev[t.n - 2], t.ev[t.n - 1]) == hipSuccess) stage[1] += ms;
+    if (t.n >= 3 && hipEventElapsedTime(&ms, t.ev[0], t.ev[t.n - 2]) == hipSuccess) stage[0] += ms;
   }
   const double n = timed.empty() ? 1.0 : (double)timed.size();
   if (launches) *launches = (int)timed.size();

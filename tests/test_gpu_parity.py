@@ -1039,6 +1039,14 @@ def test_tile_order_of_new_and_repeated_pictures_never_changes_a_pixel(renderer)
             mine = renderer.render_tiles(t, s0, W, H2, 8, 1, 2)
             rows = [L.rm_shard_row_to_frame(H2, 8, 1, 2, i) for i in range(mine.shape[0])]
             assert _ieq(mine, full[torch.tensor(rows, device=full.device)])
+        # a picture that repeats settles (the fourth cost-ordered frame on reuses the third's order: no ordering launches, no cost
+        # atomics); the picture after a settled one is ordered by geometry + the costs the last sort kept
+        settle = [(bulb, sb)] * 7 + [(prim, s0)] + [(bulb, sb)] * 6 + [(moved, s0)] * 14 + [(prim, s0), (moved, s0)]
+        L.rm_set_tile_order(0)
+        want = {id(sc): renderer.render(tables_of(sc), st, W, H).clone() for sc, st in ((bulb, sb), (prim, s0), (moved, s0))}
+        L.rm_set_tile_order(1)
+        for k, (sc, st) in enumerate(settle):
+            assert _ieq(renderer.render(tables_of(sc), st, W, H), want[id(sc)]), f"frame {k} of the settling sequence"
     finally:
         L.rm_set_tile_order(-1)
 
