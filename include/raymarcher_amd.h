@@ -432,7 +432,9 @@ enum { RM_FN_SIN = 0, RM_FN_COS, RM_FN_ACOS, RM_FN_ATAN2, RM_FN_LOG2, RM_FN_EXP2
        RM_FN_DIV, RM_FN_PNOISE3, RM_FN_ASIN, RM_FN_Q16 /* round to binary16 and back */,
        RM_FN_SQRT_FAST /* device-only variant of sqrt, must equal RM_FN_SQRT bit for bit */,
        RM_FN_DIVR /* x · RN(1/y), the contract's hot-path quotient */, RM_FN_RCP /* device form of 1.0f / x */,
-       RM_FN_SMOOTHSTEP /* smoothstep(x, y, z) */, RM_FN_MIN, RM_FN_MAX, RM_FN_FRACT, RM_FN_COUNT };
+       RM_FN_SMOOTHSTEP /* smoothstep(x, y, z) */, RM_FN_MIN, RM_FN_MAX, RM_FN_FRACT,
+       RM_FN_MEDIAN_ABS /* device only: v_med3_f32(|x|, |y|, |z|), the Menger level's spelling of min(max(x,y), min(max(y,z), max(z,x))) */,
+       RM_FN_COUNT };
 int rm_probe_math(int fn, const float *d_x, const float *d_y, const float *d_z, float *d_out, int n,
                   void *stream);
 /* Evaluate sdScene (frag:1406-1430) at n world-space points: d_out[4n] = (minD, minObjIdx, trap.y, trap.z). */

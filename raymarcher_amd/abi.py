@@ -35,7 +35,7 @@ RM_OK, RM_ERR_INVALID_ARGUMENT, RM_ERR_CAPACITY, RM_ERR_UNSUPPORTED, RM_ERR_DEVI
 
 (RM_FN_SIN, RM_FN_COS, RM_FN_ACOS, RM_FN_ATAN2, RM_FN_LOG2, RM_FN_EXP2, RM_FN_POW, RM_FN_SQRT, RM_FN_DIV,
  RM_FN_PNOISE3, RM_FN_ASIN, RM_FN_Q16, RM_FN_SQRT_FAST, RM_FN_DIVR, RM_FN_RCP, RM_FN_SMOOTHSTEP, RM_FN_MIN, RM_FN_MAX, RM_FN_FRACT,
- RM_FN_COUNT) = range(20)
+ RM_FN_MEDIAN_ABS, RM_FN_COUNT) = range(21)
 
 f32 = C.c_float
 i32 = C.c_int32

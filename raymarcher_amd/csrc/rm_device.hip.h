@@ -322,11 +322,12 @@ RM_DEV float sdSierpinski(V3 p) {
 // Inside a level every operand of the three maxima and of the minimum is a freshly computed |·| (canonical, >= +0), so the
 // compiler's own v_max_f32 with |·| source modifiers / v_min3_f32 give the contract's bits (same comparator as the v_min_f32 /
 // v_max_f32 pair of rm_math, no NaN-quieting prologue needed) — and, unlike the inline-asm spellings, carry no hazard s_nops.
-// TRAP = false (shadow marches, normal and AO taps) drops the orbit-trap bookkeeping (res is then unspecified).
+// TRAP = 0 (shadow marches, normal and AO taps) drops the orbit-trap bookkeeping (res is then unspecified); 1 keeps res.z, the
+// component render() reads; 2 the whole vec4 (the sdScene probe).
 // LEVELS > 0 / STILL = true: the level count and ani == 0 as COMPILE-TIME facts — the levels are then one basic block with no
 // scalar branch between them (their candidates c are independent of one another; only the final compare / select chain is
 // serial), which is worth more than the branches look: see sdMengerSponge below.  LEVELS = 0: both read at run time.
-template <bool TRAP, int LEVELS, bool STILL>
+template <int TRAP, int LEVELS, bool STILL>
 RM_DEV float mengerImpl(const SceneBlock *sb, V3 p, V4 &res) {
   float d = sdBox(p, 1.0f, 1.0f, 1.0f);
   float ty = 1.0f, tz = 0.0f;
@@ -345,16 +346,27 @@ RM_DEV float mengerImpl(const SceneBlock *sb, V3 p, V4 &res) {
     V3 a = v3(fma(2.0f, fract_(p.x * hs), -1.0f), fma(2.0f, fract_(p.y * hs), -1.0f), fma(2.0f, fract_(p.z * hs), -1.0f));
     float rx = fabs_(fma(-3.0f, fabs_(a.x), 1.0f)), ry = fabs_(fma(-3.0f, fabs_(a.y), 1.0f)),
           rz = fabs_(fma(-3.0f, fabs_(a.z), 1.0f));
-    float da = __builtin_fmaxf(rx, ry), db = __builtin_fmaxf(ry, rz), dc = __builtin_fmaxf(rz, rx);
-    const float num = __builtin_fminf(da, __builtin_fminf(db, dc)) - 1.0f;
+    // min(max(rx,ry), min(max(ry,rz), max(rz,rx))) is the MEDIAN of the three: one v_med3_f32 where the pairwise maxima are not
+    // read, instead of three v_max + v_min3, all half-rate instructions.  Same value for every input: the median is a selection,
+    // and with NaN operands v_med3 returns min3 of the others, which is what the IEEE min / max chain leaves too.  The maxima
+    // are read by the trap's .y only, which nothing but the sdScene probe consumes (render reads .z of a Menger hit, frag:2362-2365):
+    // TRAP = 2 is that full form, TRAP = 1 (every march that reports a hit) carries .z alone, TRAP = 0 (shadow, normal, AO) nothing.
+    float da = 0.0f, db = 0.0f, dc = 0.0f, med;
+    if (TRAP == 2) {
+      da = __builtin_fmaxf(rx, ry); db = __builtin_fmaxf(ry, rz); dc = __builtin_fmaxf(rz, rx);
+      med = __builtin_fminf(da, __builtin_fminf(db, dc));
+    } else {
+      med = __builtin_amdgcn_fmed3f(rx, ry, rz);
+    }
+    const float num = med - 1.0f;
     const float c = (divc > 0.0f) ? divc_(num, divc, 1.0f / divc) : (num / sNext);
     const bool up = c > d;
     d = up ? c : d;
-    if (TRAP) {
+    if (TRAP == 2) {
       const float t = __builtin_fminf(ty, ((0.2f * da) * db) * dc);
       ty = up ? t : ty;
-      tz = up ? ((1.0f + (float)m) / 4.0f) : tz;
     }
+    if (TRAP) tz = up ? ((1.0f + (float)m) / 4.0f) : tz;
   };
   // the first eight levels written out (straight-line code, constants as immediates, one scalar test per level); deeper
   // ones — far below pixel size — in a loop with the IEEE division
@@ -377,7 +389,7 @@ RM_DEV float mengerImpl(const SceneBlock *sb, V3 p, V4 &res) {
 }
 // The two level counts that occur (the shader's 4, BASELINE config 5's 5) at iTime = 0 get their own straight-line instantiation,
 // chosen by a wave-uniform test; everything else takes the generic one.  Same bits.
-template <bool TRAP>
+template <int TRAP>
 RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
   const int levels = sb->s.mengerLevels;
   if (sb->mengerAni == 0.0f) {
@@ -402,7 +414,7 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
 // TRACK (with SKIP): also return in `second` a lower bound of every OTHER object's value at p — the runner-up of the minimum:
 // the values of the objects evaluated, and (|p_object|·(1 − ε) − boundR)·scaleFactor for the ones passed over.  The march
 // loops use it for the single-object fast path (sdSceneOne below).
-template <bool BULB, int COUNT, bool TRAP, bool SKIP, bool TRACK>
+template <bool BULB, int COUNT, int TRAP, bool SKIP, bool TRACK>  // TRAP: 0 none, 1 what render() reads, 2 the whole vec4 (probe)
 RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub, float &second) {
   SceneMin res;
   if (TRACK) second = __builtin_inff();
@@ -450,7 +462,7 @@ RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub,
       case RM_DEATHSTAR: d = sdDeathStar(po, 0.5f, 0.35f, 0.5f); break;
       case RM_RECTANGLE: d = sdBox(po, 0.5f, 0.5f, 0.0f); break;
       case RM_MANDELBROT: d = sdMandelBrot(sb, po.x, po.y); break;
-      case RM_MANDELBULB: d = sdMandelBulb<COUNT, BULB && COUNT == 0, TRAP>(sb, po, res.trap, cnt); break;
+      case RM_MANDELBULB: d = sdMandelBulb<COUNT, BULB && COUNT == 0, TRAP != 0>(sb, po, res.trap, cnt); break;
       case RM_MENGERSPONGE: d = sdMengerSponge<TRAP>(sb, po, res.trap); break;
       case RM_SIERPINSKI: d = sdSierpinski(po); break;
       default: continue;
@@ -466,7 +478,7 @@ RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub,
   }
   return res;
 }
-template <bool BULB, int COUNT, bool TRAP = true, bool SKIP = false>
+template <bool BULB, int COUNT, int TRAP = 1, bool SKIP = false>
 RM_DEV SceneMin sdScene(const SceneBlock *sb, V3 p, Counters &cnt, float ub = __builtin_inff()) {
   float unused;
   return sdSceneImpl<BULB, COUNT, TRAP, SKIP, false>(sb, p, cnt, ub, unused);

@@ -284,6 +284,7 @@ __global__ void probe_math_kernel(int fn, const float *x, const float *y, const 
     case RM_FN_MIN: r = min_(a, b); break;
     case RM_FN_MAX: r = max_(a, b); break;
     case RM_FN_FRACT: r = fract_(a); break;
+    case RM_FN_MEDIAN_ABS: r = __builtin_amdgcn_fmed3f(fabs_(a), fabs_(b), fabs_(c)); break;
   }
   out[i] = r;
 }
@@ -292,7 +293,7 @@ __global__ void probe_sdscene_kernel(const SceneBlock *__restrict__ sb, const fl
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Counters cnt{0, 0, 0, 0, 0, 0};
-  SceneMin m = sdScene<false, 0>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
+  SceneMin m = sdScene<false, 0, 2>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);  // the whole trap, as the oracle's sdScene returns it
   out[4 * i] = m.d;
   out[4 * i + 1] = (float)m.idx;
   out[4 * i + 2] = m.trap.y;

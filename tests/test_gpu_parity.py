@@ -140,6 +140,23 @@ def test_min_max_fract_bit_exact_on_every_pair_of_special_values(renderer):
         got = renderer.probe_math(fn, torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
         bad = bits(got) != bits(ref)
         assert not bad.any(), f"fn {fn}: {bad.sum()} mismatches, e.g. {bits(a[bad][:4])}, {bits(b[bad][:4])}: gpu {bits(got[bad][:4])} cpu {bits(ref[bad][:4])}"
+    # the Menger level's median (rm_device.hip.h, mengerImpl): v_med3_f32(|x|,|y|,|z|) against the shader's min / max chain
+    # (frag:1063-1064) through the oracle's contract min / max, on every triple of a set with zeros, denormals, infinities and quiet
+    # NaNs (the operands are |fma(…)|: never signalling).  A NaN result only has to be a NaN: the level's `c > d` drops it.
+    sp = np.array([0x00000000, 0x00000001, 0x007fffff, 0x00800000, 0x3f7fffff, 0x3f800000, 0x3f800001, 0x40000000, 0x7f7fffff,
+                   0x7f800000, 0x7fc00000, 0x7fc12345, 0xffc00000, 0x80000000, 0xbf800000, 0xff800000], dtype=np.uint32)
+    tv = np.concatenate([sp, rng.random(24, dtype=np.float32).view(np.uint32)]).view(np.float32)
+    ta, tb, tc = (np.ascontiguousarray(g.ravel()) for g in np.meshgrid(tv, tv, tv, indexing="ij"))
+
+    def omm(fn, p, q):
+        out = np.empty_like(p)
+        assert h.oracle().rmo_probe_math(fn, h.fptr(p), h.fptr(q), None, h.fptr(out), p.size) == 0
+        return out
+    aa, ab, ac = np.abs(ta), np.abs(tb), np.abs(tc)
+    chain = omm(abi.RM_FN_MIN, omm(abi.RM_FN_MAX, aa, ab), omm(abi.RM_FN_MIN, omm(abi.RM_FN_MAX, ab, ac), omm(abi.RM_FN_MAX, ac, aa)))
+    med = renderer.probe_math(abi.RM_FN_MEDIAN_ABS, torch.from_numpy(ta).cuda(), torch.from_numpy(tb).cuda(), torch.from_numpy(tc).cuda()).cpu().numpy()
+    bad = (bits(med) != bits(chain)) & ~(np.isnan(med) & np.isnan(chain))
+    assert not bad.any(), f"median: {bad.sum()} mismatches, e.g. {bits(ta[bad][:3])} {bits(tb[bad][:3])} {bits(tc[bad][:3])}: {bits(med[bad][:3])} vs {bits(chain[bad][:3])}"
     x = np.concatenate([vals, (rng.normal(0, 1e-7, 100000)).astype(np.float32), rng.normal(0, 100, 100000).astype(np.float32)])
     ref = np.empty_like(x)
     assert h.oracle().rmo_probe_math(abi.RM_FN_FRACT, h.fptr(x), None, None, h.fptr(ref), x.size) == 0
