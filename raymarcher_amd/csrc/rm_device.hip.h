@@ -322,8 +322,8 @@ RM_DEV float sdSierpinski(V3 p) {
 // Inside a level every operand of the three maxima and of the minimum is a freshly computed |·| (canonical, >= +0), so the
 // compiler's own v_max_f32 with |·| source modifiers / v_min3_f32 give the contract's bits (same comparator as the v_min_f32 /
 // v_max_f32 pair of rm_math, no NaN-quieting prologue needed) — and, unlike the inline-asm spellings, carry no hazard s_nops.
-// TRAP = 0 (shadow marches, normal and AO taps) drops the orbit-trap bookkeeping (res is then unspecified); 1 keeps res.z, the
-// component render() reads; 2 the whole vec4 (the sdScene probe).
+// TRAP = 0 (shadow marches, normal and AO taps) drops the orbit-trap bookkeeping (res is then unspecified); 1 is the shader's
+// vec4; 2 keeps res.z alone (see the level below).
 // LEVELS > 0 / STILL = true: the level count and ani == 0 as COMPILE-TIME facts — the levels are then one basic block with no
 // scalar branch between them (their candidates c are independent of one another; only the final compare / select chain is
 // serial), which is worth more than the branches look: see sdMengerSponge below.  LEVELS = 0: both read at run time.
@@ -348,11 +348,12 @@ RM_DEV float mengerImpl(const SceneBlock *sb, V3 p, V4 &res) {
           rz = fabs_(fma(-3.0f, fabs_(a.z), 1.0f));
     // min(max(rx,ry), min(max(ry,rz), max(rz,rx))) is the MEDIAN of the three: one v_med3_f32 where the pairwise maxima are not
     // read, instead of three v_max + v_min3, all half-rate instructions.  Same value for every input: the median is a selection,
-    // and with NaN operands v_med3 returns min3 of the others, which is what the IEEE min / max chain leaves too.  The maxima
-    // are read by the trap's .y only, which nothing but the sdScene probe consumes (render reads .z of a Menger hit, frag:2362-2365):
-    // TRAP = 2 is that full form, TRAP = 1 (every march that reports a hit) carries .z alone, TRAP = 0 (shadow, normal, AO) nothing.
+    // and with NaN operands v_med3 returns min3 of the others, which is what the IEEE min / max chain leaves too.  The maxima are
+    // read by the trap's .y — which a MANDELBULB hit reads when a sponge comes later in the table (sdScene hands back the trap of
+    // the last fractal evaluated, UB3) — so: TRAP = 1 the full trap as the shader computes it; TRAP = 2 its .z alone, for callers
+    // that read nothing else and whose tables hold no bulb (the wavefront pipeline); TRAP = 0 (shadow, normal, AO) nothing.
     float da = 0.0f, db = 0.0f, dc = 0.0f, med;
-    if (TRAP == 2) {
+    if (TRAP == 1) {
       da = __builtin_fmaxf(rx, ry); db = __builtin_fmaxf(ry, rz); dc = __builtin_fmaxf(rz, rx);
       med = __builtin_fminf(da, __builtin_fminf(db, dc));
     } else {
@@ -362,7 +363,7 @@ RM_DEV float mengerImpl(const SceneBlock *sb, V3 p, V4 &res) {
     const float c = (divc > 0.0f) ? divc_(num, divc, 1.0f / divc) : (num / sNext);
     const bool up = c > d;
     d = up ? c : d;
-    if (TRAP == 2) {
+    if (TRAP == 1) {
       const float t = __builtin_fminf(ty, ((0.2f * da) * db) * dc);
       ty = up ? t : ty;
     }
@@ -414,7 +415,7 @@ RM_DEV float sdMengerSponge(const SceneBlock *sb, V3 p, V4 &res) {
 // TRACK (with SKIP): also return in `second` a lower bound of every OTHER object's value at p — the runner-up of the minimum:
 // the values of the objects evaluated, and (|p_object|·(1 − ε) − boundR)·scaleFactor for the ones passed over.  The march
 // loops use it for the single-object fast path (sdSceneOne below).
-template <bool BULB, int COUNT, int TRAP, bool SKIP, bool TRACK>  // TRAP: 0 none, 1 what render() reads, 2 the whole vec4 (probe)
+template <bool BULB, int COUNT, int TRAP, bool SKIP, bool TRACK>  // TRAP: 0 none, 1 the shader's, 2 the sponge's .z alone (mengerImpl)
 RM_DEV SceneMin sdSceneImpl(const SceneBlock *sb, V3 p, Counters &cnt, float ub, float &second) {
   SceneMin res;
   if (TRACK) second = __builtin_inff();

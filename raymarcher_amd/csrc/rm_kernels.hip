@@ -293,7 +293,7 @@ __global__ void probe_sdscene_kernel(const SceneBlock *__restrict__ sb, const fl
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Counters cnt{0, 0, 0, 0, 0, 0};
-  SceneMin m = sdScene<false, 0, 2>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);  // the whole trap, as the oracle's sdScene returns it
+  SceneMin m = sdScene<false, 0>(sb, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), cnt);
   out[4 * i] = m.d;
   out[4 * i + 1] = (float)m.idx;
   out[4 * i + 2] = m.trap.y;

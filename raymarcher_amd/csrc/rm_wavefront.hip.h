@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64, wfMarchWaves(KIND)) void wf_march_kernel(const 
     float hitD = 0.0f, hitTz = 0.0f;
     int hitObj = -1;
     if (st == ST_MARCH) {
-      const SceneMin c = sdScene<false, 0, KIND != 2, SKIP>(sb, madd(rd, depth, ro), none, ub);
+      // trap mode 2: a hit record carries trap.z alone (the sponge's palette index) and this pipeline's tables hold no bulb
+      const SceneMin c = sdScene<false, 0, KIND != 2 ? 2 : 0, SKIP>(sb, madd(rd, depth, ro), none, ub);
       const bool hit = fabs_(c.d) < kSurfaceDist;
       bool fin = hit || depth > end;
       if (!fin) {

@@ -428,6 +428,31 @@ def test_menger_bit_exact(renderer, levels, bounces, itime):
     assert_bit_equal(out.cpu().numpy(), ref, "menger")
 
 
+@pytest.mark.parametrize("order", ["bulb_first", "sponge_first"])
+@pytest.mark.parametrize("itime", [0.0, 4.2])
+def test_bulb_hit_reads_the_trap_of_the_last_fractal_in_the_table(renderer, order, itime):
+    """sdScene hands back the trap of the LAST fractal it evaluated, whichever object is nearest (UB3): a Mandelbulb hit in a table
+    with a Menger sponge after it is coloured by the sponge's trap — all of it, .y (the product of the pairwise maxima) included.
+    (Found by the round-4 soak: a sponge evaluation that kept only the .z a sponge hit reads differed on such pixels.)"""
+    W, H = 72, 54
+    cam = h.make_camera((1.6, 1.3, 4.0), (-1.6, -1.3, -4.0), (0, 1, 0), 40.0, W, H)
+    # the two INTERSECT (the bulb pokes out of the sponge's faces): on most of the bulb's visible surface the sponge's level loop has
+    # raised its running maximum at least once, so its trap — .y included — is not the initial one
+    bulb = h.make_object(abi.RM_MANDELBULB, ambient=(.3, .2, .3), diffuse=(.9, 1, .8), specular=(1, 1, 1), shininess=30.0,
+                         reflective=(.3, .3, .3))
+    sponge = h.make_object(abi.RM_MENGERSPONGE, model=h.translate(0.1, -0.05, 0.0) @ h.scale(0.95, 0.95, 0.95), scale_factor=0.95,
+                           ambient=(.3, .3, .3), diffuse=(1, 1, 1), specular=(1, 1, 1), shininess=25.0, reflective=(.4, .4, .4))
+    objs = (abi.RmObject * 2)(*((bulb, sponge) if order == "bulb_first" else (sponge, bulb)))
+    lights = (abi.RmLight * 2)(h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-1, -1.5, -0.7)),
+                               h.make_light(abi.RM_LIGHT_POINT, (.8, .8, 1), pos=(2, 3, 4), func=(0.8, 0.05, 0.0)))
+    scene = (cam, objs, 2, lights, 2, h.make_globals(itime=itime))
+    for over in ({}, {"enableReflection": 1, "numReflection": 2, "mengerLevels": 5, "fractalIters": 8}):
+        s = abi.default_settings(**over)
+        ref = h.oracle_render(scene, s, W, H)
+        assert_bit_equal(renderer.render(tables_of(scene), s, W, H).cpu().numpy(), ref, f"bulb + sponge, {order}, iTime {itime}")
+    assert ref[..., :3].std() > 0.05
+
+
 def test_mandelbrot_2d_and_julia(renderer):
     W, H = 64, 48
     scene = list(h.scene_mandelbulb(W, H))
