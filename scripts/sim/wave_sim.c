@@ -17,6 +17,7 @@
  * Output: per schedule, total wave-instructions and lane utilisation (lane-level useful instructions / 64·wave-level).
  * Build: see scripts/sim/run_wave_sim.py.
  */
+#include <stdio.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -523,6 +524,14 @@ void sim_histograms(double *byActive, double *byStep) {
  * schedule — lanes meet at every march of the code (k-th march of every lane together; the normal taps ride with the march
  * before them) — and (b) a per-lane queue where every lane runs its own marches back to back (one evaluation per trip).
  * out: [0] lane-level evaluations, [1] wave-level evaluation trips (a), [2] trips (b), [3] waves, [4] pixels. */
+/* optional: 2 doubles per 8×8 wave (whole-wave length, longest quarter), set by the caller before sim_generic */
+static double *g_waveLen = NULL;
+static double g_dumpAbove = 1e300;
+static double *g_packLen = NULL;
+static int g_packStride = 0;
+void sim_set_pack_len_buffer(double *buf, int stride) { g_packLen = buf; g_packStride = stride; }
+void sim_set_dump_above(double v) { g_dumpAbove = v; }
+void sim_set_wave_len_buffer(double *buf) { g_waveLen = buf; }
 int sim_generic(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, int W, int H, int stride, double *out, int threads) {
   RmResources none;
@@ -586,6 +595,105 @@ int sim_generic(const RmCamera *cam, const RmObject *objs, int numObjects, const
           pos[l] = k;
         }
         tripsC += mxR + mxS;
+      }
+    }
+    /* (e) the wave's own length under schedule (c) — whole, and cut into four 16-lane parts that run as waves of their own (what
+     * a launcher could do with the tiles the previous frame measured heaviest): the part with the longest chain. */
+    if (g_waveLen) {
+      double best = 0;
+      for (int part = -1; part < 4; part++) {
+        int pos[64], done = 0;
+        double len = 0;
+        for (int l = 0; l < 64; l++) pos[l] = 0;
+        while (!done) {
+          int mxR = 0, mxS = 0;
+          done = 1;
+          for (int l = 0; l < 64; l++) {
+            if (part >= 0 && (l >> 4) != part) continue;
+            int k = pos[l];
+            if (k >= st[l].n) continue;
+            done = 0;
+            if (st[l].evals[k] > mxR) mxR = st[l].evals[k];
+            k++;
+            int sh = 0;
+            while (k < st[l].n && st[l].kind[k] == 1) sh += st[l].evals[k++];
+            if (sh > mxS) mxS = sh;
+            pos[l] = k;
+          }
+          len += mxR + mxS;
+        }
+        if (part < 0) g_waveLen[2 * b] = len;
+        else if (len > best) best = len;
+      }
+      g_waveLen[2 * b + 1] = best;
+      if (g_packLen) {
+        /* (f) the shadow rays of one shading round PACKED: lanes still meet at every raymarch, but the shadow rays that follow it —
+         * (pixel, light) pairs in pixel-major order — are dealt to the 64 lanes 64 at a time, one march per pass */
+        int pos[64], done = 0;
+        double len = 0;
+        for (int l = 0; l < 64; l++) pos[l] = 0;
+        while (!done) {
+          int mxR = 0, nray = 0, passMax = 0;
+          double sh = 0;
+          done = 1;
+          for (int l = 0; l < 64; l++) {
+            int k = pos[l];
+            if (k >= st[l].n) continue;
+            done = 0;
+            if (st[l].evals[k] > mxR) mxR = st[l].evals[k];
+            k++;
+            while (k < st[l].n && st[l].kind[k] == 1) {
+              if (st[l].evals[k] > passMax) passMax = st[l].evals[k];
+              if (++nray == 64) { sh += passMax; nray = 0; passMax = 0; }
+              k++;
+            }
+            pos[l] = k;
+          }
+          if (nray) sh += passMax;
+          len += mxR + sh;
+        }
+        g_packLen[b] = len;
+        /* (g) the same rays as a WAVE-level queue: a lane that finishes its ray takes the next one of the list (list scheduling
+         * on 64 lanes): the round's shadow phase lasts as long as its busiest lane */
+        {
+          int pos2[64], fin = 0;
+          double len2 = 0;
+          for (int l = 0; l < 64; l++) pos2[l] = 0;
+          while (!fin) {
+            int mxR = 0;
+            double busy[64];
+            for (int l = 0; l < 64; l++) busy[l] = 0;
+            fin = 1;
+            for (int l = 0; l < 64; l++) {
+              int k = pos2[l];
+              if (k >= st[l].n) continue;
+              fin = 0;
+              if (st[l].evals[k] > mxR) mxR = st[l].evals[k];
+              k++;
+              while (k < st[l].n && st[l].kind[k] == 1) {
+                int best = 0;
+                for (int q = 1; q < 64; q++) if (busy[q] < busy[best]) best = q;
+                busy[best] += st[l].evals[k] + 2; /* + the hand-over */
+                k++;
+              }
+              pos2[l] = k;
+            }
+            double mk = 0;
+            for (int q = 0; q < 64; q++) if (busy[q] > mk) mk = busy[q];
+            len2 += mxR + mk;
+          }
+          g_packLen[g_packStride + b] = len2;
+        }
+      }
+      if (g_waveLen[2 * b] >= g_dumpAbove) {  /* the wave's longest lane: its marches (kind:evaluations) */
+        int bl = 0, bt = -1;
+        for (int l = 0; l < 64; l++) { int tot = 0; for (int k = 0; k < st[l].n; k++) tot += st[l].evals[k]; if (tot > bt) { bt = tot; bl = l; } }
+#pragma omp critical
+        {
+          fprintf(stderr, "wave %d: %.0f trips; longest lane %d (%d evaluations):", b, g_waveLen[2 * b], bl, bt);
+          for (int k = 0; k < st[bl].n; k++) fprintf(stderr, " %d:%d", st[bl].kind[k], st[bl].evals[k]);
+          fprintf(stderr, "\n");
+        }
       }
     }
     /* (d) per-lane queue WITH the price of the blocks between marches, in units of one evaluation: after a raymarch that is
