@@ -1347,7 +1347,7 @@ def _random_case(rng, W, H):
 def test_random_scenes_bit_exact(renderer):
     """24 seeded random scenes over the whole ABI surface (every primitive and fractal type, all four light kinds, object
     textures, sky box, night sky, sea, every option and loop-bound knob): the GPU equals the oracle in every bit."""
-    W, H = 56, 40
+    W, H = (int(v) for v in os.environ.get("RM_FUZZ_SIZE", "56x40").split("x"))  # 512x320: ordered tiles, see the wide test below
     rng = np.random.default_rng(int(os.environ.get("RM_FUZZ_SEED", "20261003")))
     kinds = set()
     for i in range(int(os.environ.get("RM_FUZZ_CASES", "24"))):  # a long soak: RM_FUZZ_CASES=400 RM_FUZZ_SEED=…
@@ -1359,6 +1359,9 @@ def test_random_scenes_bit_exact(renderer):
         out, br = renderer.render(t, s, W, H, bright=True)
         assert_bit_equal(out.cpu().numpy(), ref, f"random scene {i}")
         assert_bit_equal(br.cpu().numpy(), ref_b, f"random scene {i} bright")
+        if (W // 8) * (H // 8) >= 2048:
+            for rep in range(3):
+                assert _ieq(renderer.render(t, s, W, H), out), f"random scene {i}: repeat {rep + 1} differs"
         kinds |= {scene[1][k].type for k in range(scene[2])}
     assert len(kinds) >= 10
 
@@ -1482,7 +1485,9 @@ def test_random_tablewalk_scenes_bit_exact(renderer):
     (scripts/gpu_fuzz_soak.sh, summary in profiles/).  Every bit of fragColor and BrightColor equals the oracle's; every
     fourth refraction-free scene also runs through the wavefront pipeline's instantiations of the same tests."""
     from raymarcher_amd import lib
-    W, H = 56, 40
+    # RM_FUZZ_SIZE=512x320 (>= 2048 tiles): the launcher then also orders the tiles — by geometry for the new picture, by measured
+    # costs for its repeats — and its tuner alternates the tile shape: every scene is rendered four times, all the same frame
+    W, H = (int(v) for v in os.environ.get("RM_FUZZ_SIZE", "56x40").split("x"))
     seed = int(os.environ.get("RM_FUZZ_SEED", "20261012"))
     rng = np.random.default_rng(seed)
     cases = int(os.environ.get("RM_FUZZ_CASES", "128"))
@@ -1493,6 +1498,9 @@ def test_random_tablewalk_scenes_bit_exact(renderer):
         out, br = renderer.render(tables_of(scene), s, W, H, bright=True)
         assert_bit_equal(out.cpu().numpy(), ref, f"seed {seed} wide table-walk scene {i} ({scene[2]} objects)")
         assert_bit_equal(br.cpu().numpy(), ref_b, f"seed {seed} wide table-walk scene {i} bright")
+        if (W // 8) * (H // 8) >= 2048:
+            for rep in range(3):
+                assert _ieq(renderer.render(tables_of(scene), s, W, H), out), f"seed {seed} scene {i}: repeat {rep + 1} differs"
         stats["objects"] += scene[2]
         stats["max_objects"] = max(stats["max_objects"], scene[2])
         if not s.enableRefraction and i % 4 == 0:
