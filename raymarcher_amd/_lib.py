@@ -61,6 +61,8 @@ SIGNATURES = {
     "rm_get_stage_timing": (C.c_int, [_P(C.c_double), _P(C.c_double), _P(C.c_int)]),
     "rm_set_kernel_path": (C.c_int, [C.c_int]),
     "rm_debug_last_path": (C.c_int, []),
+    "rm_debug_last_split": (C.c_int, []),
+    "rm_debug_set_light_split": (C.c_int, [C.c_int]),
     "rm_debug_set_tile_shape": (C.c_int, [C.c_int]),
     "rm_set_root_relief": (C.c_int, [C.c_int]),
     "rm_get_root_relief": (C.c_int, []),

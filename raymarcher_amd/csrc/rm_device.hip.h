@@ -114,6 +114,11 @@ struct SceneBlock {
   const int32_t *tileOrder;
   uint32_t *tileCost;
   int32_t tileCount;
+  // "Light split" (rm_kernels.hip): the first splitTiles tiles of tileOrder — the heaviest of a settled picture — are rendered by
+  // numLights workgroups each, one shadow march per pixel apiece (results in splitStore: per tile 64 pixels × numLights × (object
+  // bits, penumbra / distance)), and finished by a second launch that reads them instead of marching.  0 / null otherwise.
+  int32_t splitTiles;
+  float *splitStore;
   // Uniforms of sdMengerSponge's prologue (frag:1052-1053: ani = smoothstep(−0.2, 0.2, −cos(0.5·iTime)), off = 1.5·sin(0.01·iTime)),
   // evaluated ONCE per launch by scene_prep_kernel with the contract's own sin / cos instead of once per evaluation per lane
   // (≈45 of the ≈230 vector instructions of a 5-level evaluation); only read when the table holds a Menger sponge.
@@ -130,6 +135,9 @@ struct RowMap {
   }
 };
 
+// What a kernel of the light split hands down to getPhong: part >= 0 — march light `part` only and store its result in slot
+// (SPLIT = 1, a heavy tile's partial workgroup); SPLIT = 2 — read every light's result from slot instead of marching.
+struct LightSplit { int part; float *slot; };
 struct SceneMin { int idx; float d; V4 trap; };
 struct MarchRes { int obj; float d; V4 trap; };
 struct Hit { V3 rd, p, n; int obj; };
@@ -965,13 +973,15 @@ RM_DEV uint32_t shadowQueue(const SceneBlock *sb, V3 so, uint32_t need, float fa
 // RES = true adds the area-light branch (frag:1884-1905); `objs` is only read there.
 // CULLS: end marches at the scene's bounds and pass over far objects in the table walk (off in the ENV instantiations, whose
 // register budget it would break).
-template <bool BULB, int COUNT, bool RES, bool CULLS>
+// SPLIT (table-walk kernels without samplers or secondary rays only): see LightSplit.
+template <bool BULB, int COUNT, bool RES, bool CULLS, int SPLIT = 0>
 RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt,
-                   float ubPos = __builtin_inff()) {
+                   float ubPos = __builtin_inff(), LightSplit split = LightSplit{-1, nullptr}) {
   constexpr bool SKIP = CULLS && !BULB && COUNT != 1;
+  const bool partial = SPLIT == 1 && split.part >= 0;  // wave-uniform
   const float ka = sb->g.ka, ks = sb->g.ks;
   float ao = 1.0f;
-  if (sb->s.enableAmbientOcclusion) ao = calcAO<BULB, COUNT, SKIP>(sb, p, N, cnt, ubPos);
+  if (sb->s.enableAmbientOcclusion && !partial) ao = calcAO<BULB, COUNT, SKIP>(sb, p, N, cnt, ubPos);
   // the shadow rays start 0.005·|N| from p
   const float ubSo = SKIP ? fma(0.005f, (sb->cullLip * len(N)) * 1.001f, ubPos) : ubPos;
   V3 total = v3((mat.amb.x * ka) * ao, (mat.amb.y * ka) * ao, (mat.amb.z * ka) * ao);
@@ -1022,7 +1032,19 @@ RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &m
     // work so that the counters stay the algorithmic ones).
     MarchRes sh;
     sh.obj = -1; sh.d = 1.0f; sh.trap = v4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (COUNT == 1 || !(dot(N, g.L) <= 0.005f)) sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt, ubSo);
+    const bool need = COUNT == 1 || !(dot(N, g.L) <= 0.005f);
+    if (partial) {  // this workgroup's one light: the very march every other schedule runs for it; its result travels by memory
+      if (i == split.part && need) {
+        sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt, ubSo);
+        split.slot[2 * i] = __int_as_float(sh.obj);
+        split.slot[2 * i + 1] = sh.d;
+      }
+      continue;
+    }
+    if (need) {
+      if (SPLIT == 2) { sh.obj = __float_as_int(split.slot[2 * i]); sh.d = split.slot[2 * i + 1]; }
+      else sh = march<BULB, COUNT, true, CULLS>(sb, so, g.L, g.maxT, 1.0f, cnt, ubSo);
+    }
     V3 cur;
     if (lightTerm(li, g, mat, N, V, ks, sh.obj, sh.d, soft, cur)) total = add(total, cur);
   }
@@ -1039,9 +1061,9 @@ RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
 }
 
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
-template <bool BULB, int COUNT, bool TEX, bool CULLS>
+template <bool BULB, int COUNT, bool TEX, bool CULLS, int SPLIT = 0>
 RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
-                        V3 bg, Counters &cnt) {
+                        V3 bg, Counters &cnt, LightSplit split = LightSplit{-1, nullptr}) {
   RenderOut out;
   info.obj = -1;
   MarchRes res = march<BULB, COUNT, false, CULLS>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
@@ -1076,7 +1098,7 @@ RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd
   mat.spec = v3(o.cSpecular[0], o.cSpecular[1], o.cSpecular[2]);
   mat.shininess = o.shininess;
   const int type = BULB ? (int)RM_MANDELBULB : o.type;
-  V3 ph = getPhong<BULB, COUNT, TEX, CULLS>(sb, objs, mat, pn, p, rd, maxT, cnt, ubP);
+  V3 ph = getPhong<BULB, COUNT, TEX, CULLS, SPLIT>(sb, objs, mat, pn, p, rd, maxT, cnt, ubP, split);
   V3 col = ph;
   if (type == RM_MANDELBULB) {  // frag:2354-2361
     V3 c = bulbTrapColor(res.trap.y, res.trap.z, res.trap.w);
@@ -1153,9 +1175,9 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
 // SEC = false compiles main's secondary rays out (reflection loop, refraction): the launcher picks it when the settings or the
 // materials rule them out for the whole frame, so that what render() hands over for them (hit point, normal, direction) is not
 // carried across the shadow marches — fewer registers spilled around the hot loops, the same pixels.
-template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true>
+template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true, int SPLIT = 0>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
-                       V4 &bright, Counters &cnt, bool &hitFlag) {
+                       V4 &bright, Counters &cnt, bool &hitFlag, LightSplit split = LightSplit{-1, nullptr}) {
   float ndcx, ndcy;
   pixelNdc(px, py, W, H, ndcx, ndcy);
   bright = v4(0.0f, 0.0f, 0.0f, 1.0f);
@@ -1174,7 +1196,7 @@ RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int p
   const float iTime = sb->g.iTime;
 
   Hit info;
-  RenderOut ri = render<BULB, COUNT, TEX, !ENV>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt);  // frag:2443
+  RenderOut ri = render<BULB, COUNT, TEX, !ENV, SPLIT>(sb, objs, ro, rd, info, 1.0f, far, bg, cnt, split);  // frag:2443
   EnvOut e;
   e.terrainHit = false; e.cloudHit = false; e.seaHit = false;
   if (env) e = envLayers(feat, sb->noise, iTime, W, ro, rd, ri.d, bg, cnt);  // frag:2444-2456

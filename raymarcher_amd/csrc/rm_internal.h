@@ -29,7 +29,7 @@ int require_device_pointers(std::initializer_list<std::pair<const char *, const 
 // Grow-only device scratch memory owned by the library, one buffer per (current device, stream, user tag): calls on
 // different streams of one device may run concurrently on the GPU and therefore never share scratch.  Growing
 // synchronises `stream` (nothing else uses the old buffer) and reallocates.  Returns an rm_status.
-enum { kWsPost = 2, kWsTileOrder = 3, kWsWavefront = 4 };
+enum { kWsPost = 2, kWsTileOrder = 3, kWsWavefront = 4, kWsLightSplit = 5 };
 int stream_workspace(int tag, hipStream_t stream, size_t need, void **out);
 #endif
 

@@ -82,7 +82,11 @@ static_assert(RM_TILE_W == 4 || RM_TILE_W == 8 || RM_TILE_W == 16, "tile width: 
 #ifndef RM_TEX_WAVES
 #define RM_TEX_WAVES 6
 #endif
-template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true>
+// SPLIT ("light split", launch_render): 1 = the main launch of a frame whose heaviest tiles are rendered one light per workgroup —
+// a 1-D grid: workgroups 0 … splitTiles·numLights − 1 are those tiles' partial workgroups (tile = tileOrder[b / numLights], light
+// b mod numLights: primary march, surface, THAT light's shadow march, its result to splitStore, no pixel), the rest render the
+// other tiles whole; 2 = the launch after it that finishes the split tiles, reading the shadow results instead of marching.
+template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true, int SPLIT = 0>
 __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVES) : (ENV ? (SEC ? RM_ENV_WAVES : RM_ENV_NOSEC_WAVES) : (BULB ? (SEC ? RM_BULB_WAVES : RM_BULB_NOSEC_WAVES) : (SEC ? RM_GENERIC_WAVES : RM_GENERIC_NOSEC_WAVES))))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
                                                       float4 *__restrict__ bright,
@@ -105,12 +109,26 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
   // tile order: the workgroups of a grid start in blockIdx order; sb->tileOrder (if any) says which tile each one renders
   int tile = blockIdx.y * gridDim.x + blockIdx.x;
   const int32_t *order = sb->tileOrder;
-  if (order && sb->tileCount == (int)(gridDim.x * gridDim.y)) tile = order[tile];
-  const int tbx = tile % (int)gridDim.x, tby = tile / (int)gridDim.x;
+  const int tsh = sb->tileShift, tw = 1 << tsh;  // wave-uniform (scalar): the tile is tw pixels wide, 64 / tw tall
+  int tilesX = (int)gridDim.x;
+  LightSplit split{-1, nullptr};
+  if (SPLIT) {  // one-wave workgroups, 1-D grid (launch_render)
+    const int nl = sb->numLights, K = sb->splitTiles, b = (int)blockIdx.x;
+    tilesX = (W + tw - 1) / tw;
+    int h = b;  // position of the tile in tileOrder
+    if (SPLIT == 1) {
+      if (b < K * nl) { h = b / nl; split.part = b - h * nl; }
+      else h = K + (b - K * nl);
+    }
+    tile = order[h];
+    if (h < K) split.slot = sb->splitStore + ((size_t)h * 64 + lane) * (size_t)(2 * nl);
+  } else if (order && sb->tileCount == (int)(gridDim.x * gridDim.y)) {
+    tile = order[tile];
+  }
+  const int tbx = tile % tilesX, tby = tile / tilesX;
   // the wave's start stamp waits in LDS (not in two scalar registers across the whole kernel — the register budget is tight)
   __shared__ unsigned long long s_c0[4];
-  if (sb->tileCost && lane == 0) s_c0[wave] = __builtin_amdgcn_s_memtime();
-  const int tsh = sb->tileShift, tw = 1 << tsh;  // wave-uniform (scalar): the tile is tw pixels wide, 64 / tw tall
+  if (!SPLIT && sb->tileCost && lane == 0) s_c0[wave] = __builtin_amdgcn_s_memtime();
   const int x = (tbx * (blockDim.x >> 6) + wave) * tw + (lane & (tw - 1));
   const int r = tby * (64 >> tsh) + (lane >> tsh);
   if (x >= W || r >= nRows) return;
@@ -118,7 +136,8 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
   V4 col, br;
   Counters cnt{0, 0, 0, 0, 0, 0};
   bool hit;
-  shadePixel<BULB, CM, ENV, TEX, SEC>(sb, s_objs, x, y, W, H, col, br, cnt, hit);
+  shadePixel<BULB, CM, ENV, TEX, SEC, SPLIT>(sb, s_objs, x, y, W, H, col, br, cnt, hit, split);
+  if (SPLIT == 1 && split.part >= 0) return;  // a partial workgroup writes no pixel
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
     if (cnt.fbmd8) atomicAdd(&counters[8], cnt.fbmd8);
     if (cnt.shapes) atomicAdd(&counters[9], cnt.shapes);
   }
-  if (sb->tileCost && sb->tileCount == (int)(gridDim.x * gridDim.y)) {  // wave-uniform
+  if (!SPLIT && sb->tileCost && sb->tileCount == (int)(gridDim.x * gridDim.y)) {  // wave-uniform
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     int t2 = blockIdx.y * gridDim.x + blockIdx.x;  // recomputed rather than kept live
     if (sb->tileOrder) t2 = sb->tileOrder[t2];
@@ -398,12 +417,14 @@ struct DeviceState {
   uint32_t *dbgTileCost = nullptr;
   int dbgTileCount = 0;
   int lastPath = 0;  // rm_debug_last_path: the schedule of the most recent render launch on this device
+  int lastSplit = 0; // rm_debug_last_split: tiles that launch rendered one light per workgroup (0: none)
 };
 std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_ORDER or the default
 constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
 std::atomic<bool> g_timing{false};
 std::atomic<int> g_tileShape{-1};  // rm_debug_set_tile_shape: -1 = the RM_TILE_SHAPE environment variable (default 0 = tune), 0 tune, 3 8×8, 2 4×16
+std::atomic<int> g_lightSplit{-1};  // rm_debug_set_light_split: -1 = the RM_LIGHT_SPLIT environment variable (default 256), 0 off, n: the heaviest 1/n of the tiles
 std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one lane per pixel, 5 wavefront pipeline
 
 #define HIP_OK(expr)                                                                              \
@@ -867,7 +888,7 @@ void scene_eval_records(SceneBlock *h) {
 int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const RmLight *lights, int numLights,
                 const RmGlobals *g, const RmSettings *s, hipStream_t stream, DeviceState &ds, Slot **slotOut,
                 const RmResources &res, const int32_t *tileOrder = nullptr, uint32_t *tileCost = nullptr,
-                int tileCount = 0, int tileShift = 3) {  // caller holds ds.mu
+                int tileCount = 0, int tileShift = 3, int splitTiles = 0, float *splitStore = nullptr) {  // caller holds ds.mu
   Slot *slot;
   int st = acquire_slot(ds, &slot);
   if (st != RM_OK) return st;
@@ -886,6 +907,7 @@ int stage_scene(const RmCamera *cam, const RmObject *objs, int numObjects, const
   ray_planes(h);
   h->tileOrder = tileOrder; h->tileCost = tileCost; h->tileCount = tileCount;
   h->tileShift = tileShift;
+  h->splitTiles = splitTiles; h->splitStore = splitStore;
   h->mengerAni = 0.0f; h->mengerOff = 0.0f;
   HIP_OK(hipMemcpyAsync(slot->dev, h, sizeof(SceneBlock), hipMemcpyHostToDevice, stream));
   bool menger = false;
@@ -1123,11 +1145,30 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   const bool byCost = ordered && samePicture;
   const bool lastSort = byCost && kSettle > 0 && costSorts == kSettle, settled = byCost && kSettle > 0 && costSorts > kSettle;
   bool byGeom = ordered && !samePicture && geomOn && !envFeatures && numObjects > 0;
+  // "Light split": a settled picture of the plain table-walk class (no secondary rays, samplers or layers) with several lights is
+  // bound by the life of its heaviest waves, and those are whole tiles whose every pixel runs one long shadow march per light back to
+  // back (C2: 26-40 evaluations of primary march, then three soft-shadow marches of 256 — profiles/r04_r_c2_chain_sim.txt).  The
+  // first tileCount / kSplitDiv tiles of the settled order are therefore rendered by numLights workgroups each — every one repeats
+  // the primary march and the surface point and marches ONE light, its result going to memory — and a second, short launch finishes
+  // those tiles from the stored results.  The same marches, the same sums in the same order: the same pixels.  RM_LIGHT_SPLIT=0: off.
+  static const int envSplitDiv = [] { const char *e = std::getenv("RM_LIGHT_SPLIT"); const int v = e ? std::atoi(e) : 256; return v < 0 ? 0 : v; }();
+  const int kSplitDiv = g_lightSplit.load() >= 0 ? g_lightSplit.load() : envSplitDiv;  // rm_debug_set_light_split
+  int splitK = 0;
+  float *splitStore = nullptr;
+  if (settled && kSplitDiv > 0 && !bulb && !envFeatures && !textured && !secondary && count == 0 && nw == 1 && numLights >= 2 &&
+      numLights <= 8 && tuneTimed < 0) {
+    splitK = tileCount / kSplitDiv;
+    if (splitK > 0) {
+      void *mem = nullptr;
+      if (stream_workspace(kWsLightSplit, stream, (size_t)splitK * 64 * 2 * numLights * sizeof(float), &mem) == RM_OK) splitStore = static_cast<float *>(mem);
+      else splitK = 0;  // no memory for it: the plain launch
+    }
+  }
   Slot *slot;
   st = stage_scene(cam, objs, numObjects, lights, numLights, g, s, stream, ds, &slot, res,
                    ordered ? ((byCost || byGeom) ? oOrder : nullptr) : ds.dbgTileOrder,
                    ordered ? ((lastSort || settled) ? nullptr : oCost) : ds.dbgTileCost,
-                   ordered ? tileCount : ds.dbgTileCount, tileShift);
+                   ordered ? tileCount : ds.dbgTileCount, tileShift, splitK, splitStore);
   if (st != RM_OK) return st;
   if (byGeom && !slot->host->objBallOk) {  // an object without a bounding ball (Sierpinski, 2-D Mandelbrot as an object): raster order
     byGeom = false;
@@ -1212,7 +1253,14 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       else if (count == 2) RM_LAUNCH(false, 2, false, false);
       else if (count == 3) RM_LAUNCH(false, 3, false, false);
       else if (secondary) RM_LAUNCH(false, 0, false, false);
-      else RM_LAUNCH_NOSEC(false, false, false);
+      else if (splitK > 0) {
+        // light split: the heavy tiles one light per workgroup first, every other tile behind them in the same grid; then the heavy
+        // tiles' finish.  (The finish on a side stream, overlapping the other tiles' tail, was measured: no gain, 1/64 of the tiles
+        // 3040 → 2850 Mpixel/s on C2 — two grids that both start heaviest-first compete from the first cycle.)
+        hipLaunchKernelGGL((render_kernel<false, 0, false, false, false, 1>), dim3((unsigned)(splitK * numLights + tileCount - splitK)), dim3(64), 0, stream,
+                           slot->dev, map, W, H, nRows, o, b, dc);
+        hipLaunchKernelGGL((render_kernel<false, 0, false, false, false, 2>), dim3((unsigned)splitK), dim3(64), 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
+      } else RM_LAUNCH_NOSEC(false, false, false);
     }
 #undef RM_LAUNCH
 #undef RM_LAUNCH_NOSEC
@@ -1224,6 +1272,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   }
   HIP_OK(hipGetLastError());
   ds.lastPath = wavefront ? 5 : 1;
+  ds.lastSplit = wavefront ? 0 : splitK;
   if (timing) { ds.timed.push_back(tl); timedGuard.kept = true; }
   HIP_OK(hipEventRecord(slot->done, stream));
   if (count) {
@@ -1551,6 +1600,17 @@ int rm_debug_last_path(void) {
   if (current_device_state(&ds)) return -1;
   std::lock_guard<std::mutex> lock(ds->mu);
   return ds->lastPath;
+}
+int rm_debug_set_light_split(int div) {
+  if (div < -1) { set_error("light split: -1 (default), 0 (off) or the divisor n >= 1"); return RM_ERR_INVALID_ARGUMENT; }
+  g_lightSplit.store(div);
+  return RM_OK;
+}
+int rm_debug_last_split(void) {
+  DeviceState *ds;
+  if (current_device_state(&ds) != RM_OK) return -1;
+  std::lock_guard<std::mutex> lock(ds->mu);
+  return ds->lastSplit;
 }
 int rm_set_kernel_path(int path) {
   if (path != 0 && path != 1 && path != 5) { set_error("kernel path must be 0, 1 or 5 (2-4, the bulb pipelines, were removed in round 4)"); return RM_ERR_INVALID_ARGUMENT; }

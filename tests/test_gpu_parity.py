@@ -1093,6 +1093,64 @@ def test_tile_order_of_new_and_repeated_pictures_never_changes_a_pixel(renderer)
         L.rm_set_tile_order(-1)
 
 
+@pytest.mark.parametrize("soft,ao,shape", [(1, 1, 3), (0, 0, 3), (1, 0, 2)])
+def test_light_split_of_a_settled_picture_never_changes_a_pixel(renderer, soft, ao, shape):
+    """A settled picture of the plain table-walk class with several lights renders its heaviest tiles one light per workgroup and
+    finishes them in a second launch from the stored shadow results (rm_kernels.hip, "light split").  Every frame of the sequence —
+    new picture, cost-ordered repeats, settled and split — is the first frame, which is the oracle's; lights of every plain kind,
+    one of them facing away from most of the scene (dropped by N·L on many pixels), soft and hard shadows, both tile shapes, a
+    ragged frame size, and a row range."""
+    from raymarcher_amd import lib
+    L = lib()
+    W, H = 636, 388  # 80 x 49 8×8 tiles, ragged on both edges
+    prim = all_primitives_scene(W, H)
+    lights = (abi.RmLight * 4)(
+        h.make_light(abi.RM_LIGHT_DIRECTIONAL, (1, 1, 1), (-0.4, -1, -0.5)),
+        h.make_light(abi.RM_LIGHT_POINT, (1, .9, .7), pos=(3, 2, 4), func=(0.7, 0.05, 0.01)),
+        h.make_light(abi.RM_LIGHT_SPOT, (.6, .8, 1), direction=(0, -1, -0.3), pos=(0, 5, 1.5), func=(1, 0, 0),
+                     angle=np.deg2rad(30.0), penumbra=np.deg2rad(10.0)),
+        h.make_light(abi.RM_LIGHT_DIRECTIONAL, (.5, .5, .4), (0.9, 0.2, 0.1)))
+    scene = (prim[0], prim[1], prim[2], lights, 4, prim[5])
+    s = abi.default_settings(maxSteps=96, enableSoftShadow=soft, enableAmbientOcclusion=ao)
+    t = tables_of(scene)
+    try:
+        assert L.rm_debug_set_tile_shape(shape) == 0
+        assert L.rm_debug_set_light_split(32) == 0  # the heaviest 1/32 of the tiles (default 1/256)
+        first = renderer.render(t, s, W, H).clone()
+        assert_bit_equal(first.cpu().numpy(), h.oracle_render(scene, s, W, H), "first frame vs oracle")
+        assert L.rm_debug_last_split() == 0
+        split = 0
+        for k in range(8):
+            assert _ieq(renderer.render(t, s, W, H), first), f"repeat {k + 1} differs"
+            split = max(split, L.rm_debug_last_split())
+        tiles = (-(-W // 8)) * (-(-H // 8)) if shape == 3 else (-(-W // 4)) * (-(-H // 16))
+        assert split == tiles // 32, "the settled picture was not split"
+        # a row range is another picture: it settles and splits on its own
+        for k in range(7):
+            assert _ieq(renderer.render(t, s, W, H, row_begin=40, row_end=364), first[40:364]), f"row range, frame {k}"
+        assert L.rm_debug_last_split() > 0
+        # a frame whose pixels can spawn secondary rays is not eligible
+        prim2 = all_primitives_scene(W, H)
+        for c in range(3):
+            prim2[1][3].cReflective[c] = 0.4
+        t2 = tables_of((prim2[0], prim2[1], prim2[2], lights, 4, prim2[5]))
+        s2 = abi.default_settings(maxSteps=96, enableSoftShadow=soft, enableAmbientOcclusion=ao, enableReflection=1)
+        ref2 = renderer.render(t2, s2, W, H).clone()
+        for k in range(6):
+            assert _ieq(renderer.render(t2, s2, W, H), ref2)
+        assert L.rm_debug_last_split() == 0
+        # every tile split, and none
+        assert L.rm_debug_set_light_split(1) == 0
+        for k in range(6):
+            assert _ieq(renderer.render(t, s, W, H), first)
+        assert L.rm_debug_last_split() == tiles
+        assert L.rm_debug_set_light_split(0) == 0
+        assert _ieq(renderer.render(t, s, W, H), first) and L.rm_debug_last_split() == 0
+    finally:
+        L.rm_debug_set_tile_shape(-1)
+        L.rm_debug_set_light_split(-1)
+
+
 def test_tile_shape_tuner_never_changes_a_pixel(renderer):
     """The launcher measures, per stream and picture, whether 8×8 or 4 wide × 16 tall pixel tiles are faster (frames 0-7 of a
     picture alternate the two shapes in pairs, then the choice sticks; rm_kernels.hip "tile shape").  Every frame of such a
@@ -1501,6 +1559,17 @@ def test_random_tablewalk_scenes_bit_exact(renderer):
         if (W // 8) * (H // 8) >= 2048:
             for rep in range(3):
                 assert _ieq(renderer.render(tables_of(scene), s, W, H), out), f"seed {seed} scene {i}: repeat {rep + 1} differs"
+            # … and with the tile shape pinned the picture settles by its fifth frame: the sixth has its heaviest eighth of the tiles
+            # rendered one light per workgroup where the scene is eligible (no secondary rays, 2-8 lights)
+            try:
+                lib().rm_debug_set_tile_shape(3)
+                lib().rm_debug_set_light_split(8)
+                for rep in range(6):
+                    assert _ieq(renderer.render(tables_of(scene), s, W, H), out), f"seed {seed} scene {i}: pinned repeat {rep + 1} differs"
+                stats["split"] = stats.get("split", 0) + (1 if lib().rm_debug_last_split() > 0 else 0)
+            finally:
+                lib().rm_debug_set_tile_shape(-1)
+                lib().rm_debug_set_light_split(-1)
         stats["objects"] += scene[2]
         stats["max_objects"] = max(stats["max_objects"], scene[2])
         if not s.enableRefraction and i % 4 == 0:
@@ -1512,7 +1581,7 @@ def test_random_tablewalk_scenes_bit_exact(renderer):
             finally:
                 lib().rm_set_kernel_path(0)
     print(f"FUZZ_SUMMARY seed={seed} cases={cases} mismatched_words=0 mean_objects={stats['objects'] / max(cases, 1):.1f} "
-          f"max_objects={stats['max_objects']} wavefront_cases={stats['wavefront']}")
+          f"max_objects={stats['max_objects']} wavefront_cases={stats['wavefront']} light_split_cases={stats.get('split', 0)}")
     assert stats["max_objects"] >= 20 or cases < 32
 
 
