@@ -368,7 +368,9 @@ int rm_debug_last_path(void);
  * =n makes the heaviest 1/n of the tiles split; default 256 — C2: 0.79 → 0.65 ms with 1/128 … 1/512, less with more).  0: none;
  * -1 on error. */
 int rm_debug_last_split(void);
-/* Tests / experiments: the divisor above for the process (0 = off, -1 = back to RM_LIGHT_SPLIT / the default). */
+/* Tests / experiments: the divisor above for the process — n >= 1 also splits WITHOUT the measurement that normally decides per
+ * picture whether the split pays (settled frames 0-1 plain, 2-3 split, the better of the two from then on); 0 = off, -1 = back to
+ * RM_LIGHT_SPLIT / the default, measured. */
 int rm_debug_set_light_split(int div);
 /* Launch order of a frame's tiles (workgroups).  Tile costs span three orders of magnitude and a single ray that never
  * converges is a sequential chain of ~1 ms, so a kernel whose heaviest tiles start late ends in a tail of a few lonely

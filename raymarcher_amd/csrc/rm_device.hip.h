@@ -115,8 +115,9 @@ struct SceneBlock {
   uint32_t *tileCost;
   int32_t tileCount;
   // "Light split" (rm_kernels.hip): the first splitTiles tiles of tileOrder — the heaviest of a settled picture — are rendered by
-  // numLights workgroups each, one shadow march per pixel apiece (results in splitStore: per tile 64 pixels × numLights × (object
-  // bits, penumbra / distance)), and finished by a second launch that reads them instead of marching.  0 / null otherwise.
+  // numLights workgroups each, one shadow march per pixel apiece (results in splitStore: per tile 64 pixels × (numLights × (object
+  // bits, penumbra / distance) + the primary march's result, 6 words)), and finished by a second launch that reads them instead of
+  // marching.  0 / null otherwise.
   int32_t splitTiles;
   float *splitStore;
   // Uniforms of sdMengerSponge's prologue (frag:1052-1053: ani = smoothstep(−0.2, 0.2, −cos(0.5·iTime)), off = 1.5·sin(0.01·iTime)),
@@ -136,8 +137,9 @@ struct RowMap {
 };
 
 // What a kernel of the light split hands down to getPhong: part >= 0 — march light `part` only and store its result in slot
-// (SPLIT = 1, a heavy tile's partial workgroup); SPLIT = 2 — read every light's result from slot instead of marching.
-struct LightSplit { int part; float *slot; };
+// (SPLIT = 1, a heavy tile's partial workgroup); SPLIT = 2 — read every light's result (and the primary march's) from slot
+// instead of marching: what the last of a tile's partial workgroups runs to finish it.
+struct LightSplit { int part; float *slot; int tileIndex; };
 struct SceneMin { int idx; float d; V4 trap; };
 struct MarchRes { int obj; float d; V4 trap; };
 struct Hit { V3 rd, p, n; int obj; };
@@ -976,7 +978,7 @@ RM_DEV uint32_t shadowQueue(const SceneBlock *sb, V3 so, uint32_t need, float fa
 // SPLIT (table-walk kernels without samplers or secondary rays only): see LightSplit.
 template <bool BULB, int COUNT, bool RES, bool CULLS, int SPLIT = 0>
 RM_DEV V3 getPhong(const SceneBlock *sb, const RmObject *objs, const Material &mat, V3 N, V3 p, V3 rd, float far, Counters &cnt,
-                   float ubPos = __builtin_inff(), LightSplit split = LightSplit{-1, nullptr}) {
+                   float ubPos = __builtin_inff(), LightSplit split = LightSplit{-1, nullptr, 0}) {
   constexpr bool SKIP = CULLS && !BULB && COUNT != 1;
   const bool partial = SPLIT == 1 && split.part >= 0;  // wave-uniform
   const float ka = sb->g.ka, ks = sb->g.ks;
@@ -1063,10 +1065,23 @@ RM_DEV V3 bulbTrapColor(float ty, float tz, float tw) {
 // frag:2318-2375.  `objs` is the per-lane-indexable copy of the object table (LDS).
 template <bool BULB, int COUNT, bool TEX, bool CULLS, int SPLIT = 0>
 RM_DEV RenderOut render(const SceneBlock *sb, const RmObject *objs, V3 ro, V3 rd, Hit &info, float side, float maxT,
-                        V3 bg, Counters &cnt, LightSplit split = LightSplit{-1, nullptr}) {
+                        V3 bg, Counters &cnt, LightSplit split = LightSplit{-1, nullptr, 0}) {
   RenderOut out;
   info.obj = -1;
-  MarchRes res = march<BULB, COUNT, false, CULLS>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
+  MarchRes res;
+  if (SPLIT == 2) {
+    // the finishing launch of the light split: the primary march was run — identically — by each of the tile's partial workgroups
+    // and stored by the first; running it here again would put it back in series with theirs (a grazing primary ray is as long a
+    // chain as a shadow march)
+    const float *q = split.slot + 2 * sb->numLights;
+    res.obj = __float_as_int(q[0]); res.d = q[1]; res.trap = v4(q[2], q[3], q[4], q[5]);
+  } else {
+    res = march<BULB, COUNT, false, CULLS>(sb, ro, rd, maxT, side, cnt);  // a miss returns maxT, not res.d
+    if (SPLIT == 1 && split.part == 0) {
+      float *q = split.slot + 2 * sb->numLights;
+      q[0] = __int_as_float(res.obj); q[1] = res.d; q[2] = res.trap.x; q[3] = res.trap.y; q[4] = res.trap.z; q[5] = res.trap.w;
+    }
+  }
   if (res.obj == -1) {
     out.col = (TEX && sb->s.enableSkyBox) ? sampleCube(sb->skybox, rd) : bg;  // frag:2325-2327
     out.isEnv = 1;
@@ -1177,7 +1192,7 @@ RM_DEV V3 backgroundColor(const SceneBlock *sb, V3 rd) {  // frag:2405-2419
 // carried across the shadow marches — fewer registers spilled around the hot loops, the same pixels.
 template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true, int SPLIT = 0>
 RM_DEV void shadePixel(const SceneBlock *sb, const RmObject *objs, int px, int py, int W, int H, V4 &fragColor,
-                       V4 &bright, Counters &cnt, bool &hitFlag, LightSplit split = LightSplit{-1, nullptr}) {
+                       V4 &bright, Counters &cnt, bool &hitFlag, LightSplit split = LightSplit{-1, nullptr, 0}) {
   float ndcx, ndcy;
   pixelNdc(px, py, W, H, ndcx, ndcy);
   bright = v4(0.0f, 0.0f, 0.0f, 1.0f);

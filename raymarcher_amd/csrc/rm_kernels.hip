@@ -82,10 +82,10 @@ static_assert(RM_TILE_W == 4 || RM_TILE_W == 8 || RM_TILE_W == 16, "tile width: 
 #ifndef RM_TEX_WAVES
 #define RM_TEX_WAVES 6
 #endif
-// SPLIT ("light split", launch_render): 1 = the main launch of a frame whose heaviest tiles are rendered one light per workgroup —
-// a 1-D grid: workgroups 0 … splitTiles·numLights − 1 are those tiles' partial workgroups (tile = tileOrder[b / numLights], light
-// b mod numLights: primary march, surface, THAT light's shadow march, its result to splitStore, no pixel), the rest render the
-// other tiles whole; 2 = the launch after it that finishes the split tiles, reading the shadow results instead of marching.
+// SPLIT ("light split", launch_render): 1 = the launch of a frame whose heaviest tiles are rendered one light per workgroup — a 1-D
+// grid: workgroups 0 … splitTiles·numLights − 1 are those tiles' partial workgroups (tile = tileOrder[b / numLights], light b mod
+// numLights: primary march, surface, THAT light's shadow march, its result to splitStore), the last of which to arrive finishes
+// the tile's pixels from the stored results (shadePixel's mode 2: no march); the rest render the other tiles whole.
 template <bool BULB, int COUNT, bool ENV, bool TEX, bool SEC = true, int SPLIT = 0>
 __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVES) : (ENV ? (SEC ? RM_ENV_WAVES : RM_ENV_NOSEC_WAVES) : (BULB ? (SEC ? RM_BULB_WAVES : RM_BULB_NOSEC_WAVES) : (SEC ? RM_GENERIC_WAVES : RM_GENERIC_NOSEC_WAVES))))) void render_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H,
                                                       int nRows, float4 *__restrict__ out,
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
   const int32_t *order = sb->tileOrder;
   const int tsh = sb->tileShift, tw = 1 << tsh;  // wave-uniform (scalar): the tile is tw pixels wide, 64 / tw tall
   int tilesX = (int)gridDim.x;
-  LightSplit split{-1, nullptr};
+  LightSplit split{-1, nullptr, 0};
   if (SPLIT) {  // one-wave workgroups, 1-D grid (launch_render)
     const int nl = sb->numLights, K = sb->splitTiles, b = (int)blockIdx.x;
     tilesX = (W + tw - 1) / tw;
@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
       else h = K + (b - K * nl);
     }
     tile = order[h];
-    if (h < K) split.slot = sb->splitStore + ((size_t)h * 64 + lane) * (size_t)(2 * nl);
+    if (h < K) {  // K arrival counters, then per tile 64 pixels × (nl shadow results + the primary march's)
+      split.tileIndex = h;
+      split.slot = sb->splitStore + (((size_t)K + 63) & ~(size_t)63) + ((size_t)h * 64 + lane) * (size_t)(2 * nl + 6);
+    }
   } else if (order && sb->tileCount == (int)(gridDim.x * gridDim.y)) {
     tile = order[tile];
   }
@@ -137,7 +140,21 @@ __global__ __launch_bounds__(256, (TEX ? (SEC ? RM_TEX_WAVES : RM_TEX_NOSEC_WAVE
   Counters cnt{0, 0, 0, 0, 0, 0};
   bool hit;
   shadePixel<BULB, CM, ENV, TEX, SEC, SPLIT>(sb, s_objs, x, y, W, H, col, br, cnt, hit, split);
-  if (SPLIT == 1 && split.part >= 0) return;  // a partial workgroup writes no pixel
+  if (SPLIT == 1 && split.part >= 0) {
+    // A partial workgroup: its results are in memory.  The LAST of the tile's numLights workgroups to get here finishes the tile —
+    // surface point, AO and the light sum from the stored results, no march (shadePixel in mode 2) — the others are done.  Release /
+    // acquire at device scope around a counter per tile: the stores of the others are visible to the one that reads old == nl − 1.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's records are written back before its arrival counts
+    uint32_t *arrived = reinterpret_cast<uint32_t *>(sb->splitStore) + split.tileIndex;  // the counters precede the records (launch_render zeroes them)
+    const int leader = __builtin_ctzll(__ballot(1));
+    uint32_t old = 0;
+    if ((int)__lane_id() == leader) old = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, leader);
+    if ((int)old != sb->numLights - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // only the finisher invalidates its view before it reads the others' records
+    split.part = -1;
+    shadePixel<BULB, CM, ENV, TEX, SEC, 2>(sb, s_objs, x, y, W, H, col, br, cnt, hit, split);
+  }
   const size_t o = (size_t)r * W + x;
   out[o] = make_float4(col.x, col.y, col.z, col.w);
   if (bright) bright[o] = make_float4(br.x, br.y, br.z, br.w);
@@ -401,6 +418,23 @@ struct ShapeTune {
     for (bool &t : timed) t = false;
   }
 };
+// "Light split" (launch_render) helps frames that are bound by the life of their heaviest waves when those waves are shadow marches
+// (C2 at 1080p: −35 %) and costs others a few per cent (redundant primary marches, cache write-backs: 4K frames +3…+9 %,
+// depth_of_field.json +10 %; profiles/r04_s_light_split.md).  So it is MEASURED per stream and settled picture like the tile shape:
+// settled frames 0-1 plain (frame 1 timed), 2-3 split (frame 3 timed), then the split stays only if it won by 3 %; plain while the
+// timings are outstanding.  A decision is shared by the device's other streams.
+struct SplitTune {
+  unsigned long long key = 0;
+  int W = 0, nRows = 0, tileShift = 0, div = 0;
+  int frame = 0;    // settled frames of this picture enqueued so far
+  int chosen = -1;  // -1 measuring, 0 plain, 1 split
+  hipEvent_t ev[2][2] = {};  // [0 plain, 1 split][start, stop]
+  bool timed[2] = {false, false};
+  void drop() {
+    for (auto &p : ev) for (auto &e : p) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    timed[0] = timed[1] = false;
+  }
+};
 struct TimedLaunch { hipEvent_t ev[5]; int n; };  // n = 2 (one stage) or 3 (tile-order sort + render kernel)
 struct DeviceState {
   std::mutex mu;                 // guards everything below; held for the host-side enqueue of ONE launch on this device
@@ -418,12 +452,15 @@ struct DeviceState {
   int dbgTileCount = 0;
   int lastPath = 0;  // rm_debug_last_path: the schedule of the most recent render launch on this device
   int lastSplit = 0; // rm_debug_last_split: tiles that launch rendered one light per workgroup (0: none)
+  std::map<hipStream_t, SplitTune> splitTune;  // the light split's tuner per stream
+  std::map<std::tuple<unsigned long long, int, int, int, int>, int> splitChoice;  // decisions by (picture, W, rows, tile shape, divisor)
 };
 std::atomic<int> g_tileOrderMode{-1};  // rm_set_tile_order: -1 = take RM_TILE_ORDER or the default
 constexpr int kDefaultTileOrder = 1;
 DeviceState g_dev[64];
 std::atomic<bool> g_timing{false};
 std::atomic<int> g_tileShape{-1};  // rm_debug_set_tile_shape: -1 = the RM_TILE_SHAPE environment variable (default 0 = tune), 0 tune, 3 8×8, 2 4×16
+std::atomic<bool> g_lightSplitForce{false};  // rm_debug_set_light_split with a divisor: split without measuring
 std::atomic<int> g_lightSplit{-1};  // rm_debug_set_light_split: -1 = the RM_LIGHT_SPLIT environment variable (default 256), 0 off, n: the heaviest 1/n of the tiles
 std::atomic<int> g_kernelPath{0};  // rm_set_kernel_path: 0 auto, 1 one lane per pixel, 5 wavefront pipeline
 
@@ -1149,18 +1186,48 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   // bound by the life of its heaviest waves, and those are whole tiles whose every pixel runs one long shadow march per light back to
   // back (C2: 26-40 evaluations of primary march, then three soft-shadow marches of 256 — profiles/r04_r_c2_chain_sim.txt).  The
   // first tileCount / kSplitDiv tiles of the settled order are therefore rendered by numLights workgroups each — every one repeats
-  // the primary march and the surface point and marches ONE light, its result going to memory — and a second, short launch finishes
-  // those tiles from the stored results.  The same marches, the same sums in the same order: the same pixels.  RM_LIGHT_SPLIT=0: off.
+  // the primary march and the surface point and marches ONE light, its result going to memory (the first one's primary result too)
+  // — and the last of them to arrive finishes the tile from the stored results: surface point, AO and the light sum, no march.  The same marches, the same sums in the same order: the same pixels.  RM_LIGHT_SPLIT=0: off.
   static const int envSplitDiv = [] { const char *e = std::getenv("RM_LIGHT_SPLIT"); const int v = e ? std::atoi(e) : 256; return v < 0 ? 0 : v; }();
   const int kSplitDiv = g_lightSplit.load() >= 0 ? g_lightSplit.load() : envSplitDiv;  // rm_debug_set_light_split
-  int splitK = 0;
+  int splitK = 0, splitTimed = -1;  // splitTimed: 0 / 1 = time this launch as the tuner's plain / split candidate
   float *splitStore = nullptr;
+  SplitTune *splitTune = nullptr;
   if (settled && kSplitDiv > 0 && !bulb && !envFeatures && !textured && !secondary && count == 0 && nw == 1 && numLights >= 2 &&
       numLights <= 8 && tuneTimed < 0) {
     splitK = tileCount / kSplitDiv;
+    if (splitK > 0 && !g_lightSplitForce.load()) {  // measured, unless a test forces it (rm_debug_set_light_split)
+      splitTune = &ds.splitTune[stream];
+      SplitTune &tn = *splitTune;
+      if (tn.key != key || tn.W != W || tn.nRows != nRows || tn.tileShift != tileShift || tn.div != kSplitDiv) {
+        tn.drop();
+        tn.key = key; tn.W = W; tn.nRows = nRows; tn.tileShift = tileShift; tn.div = kSplitDiv; tn.frame = 0; tn.chosen = -1;
+        const auto known = ds.splitChoice.find(std::make_tuple(key, W, nRows, tileShift, kSplitDiv));
+        if (known != ds.splitChoice.end()) tn.chosen = known->second;
+      }
+      if (tn.chosen < 0 && tn.frame >= 4 && tn.timed[0] && tn.timed[1] && hipEventQuery(tn.ev[0][1]) == hipSuccess &&
+          hipEventQuery(tn.ev[1][1]) == hipSuccess) {
+        float plainMs = 0.0f, splitMs = 0.0f;
+        const bool ok = hipEventElapsedTime(&plainMs, tn.ev[0][0], tn.ev[0][1]) == hipSuccess &&
+                        hipEventElapsedTime(&splitMs, tn.ev[1][0], tn.ev[1][1]) == hipSuccess;
+        tn.chosen = (ok && splitMs < 0.97f * plainMs) ? 1 : 0;
+        tn.drop();
+        if (ds.splitChoice.size() >= 256) ds.splitChoice.clear();
+        ds.splitChoice[std::make_tuple(key, W, nRows, tileShift, kSplitDiv)] = tn.chosen;
+      }
+      (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+      bool useSplit = tn.chosen == 1;
+      if (tn.chosen < 0) {
+        const int f = tn.frame;
+        useSplit = f == 2 || f == 3;
+        if (f == 1 || f == 3) splitTimed = f >> 1;
+      }
+      tn.frame++;
+      if (!useSplit) splitK = 0;
+    }
     if (splitK > 0) {
       void *mem = nullptr;
-      if (stream_workspace(kWsLightSplit, stream, (size_t)splitK * 64 * 2 * numLights * sizeof(float), &mem) == RM_OK) splitStore = static_cast<float *>(mem);
+      if (stream_workspace(kWsLightSplit, stream, ((((size_t)splitK + 63) & ~(size_t)63) + (size_t)splitK * 64 * (2 * numLights + 6)) * sizeof(float), &mem) == RM_OK) splitStore = static_cast<float *>(mem);
       else splitK = 0;  // no memory for it: the plain launch
     }
   }
@@ -1230,6 +1297,11 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder, lastSort ? 1 : 0);
       if ((st = stamp(1)) != RM_OK) return st;  // stage 0 = the ordering launches, stage 1 = the render
     }
+    if (splitTimed >= 0 && splitTune) {
+      if (hipEventCreate(&splitTune->ev[splitTimed][0]) == hipSuccess && hipEventCreate(&splitTune->ev[splitTimed][1]) == hipSuccess)
+        HIP_OK(hipEventRecord(splitTune->ev[splitTimed][0], stream));
+      else splitTimed = -1;
+    }
     if (tuneTimed >= 0 && tune) {  // the tuner's timed launch of this candidate shape: events around the render kernel alone
       if (hipEventCreate(&tune->ev[tuneTimed][0]) == hipSuccess && hipEventCreate(&tune->ev[tuneTimed][1]) == hipSuccess)
         HIP_OK(hipEventRecord(tune->ev[tuneTimed][0], stream));
@@ -1254,12 +1326,12 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
       else if (count == 3) RM_LAUNCH(false, 3, false, false);
       else if (secondary) RM_LAUNCH(false, 0, false, false);
       else if (splitK > 0) {
-        // light split: the heavy tiles one light per workgroup first, every other tile behind them in the same grid; then the heavy
-        // tiles' finish.  (The finish on a side stream, overlapping the other tiles' tail, was measured: no gain, 1/64 of the tiles
-        // 3040 → 2850 Mpixel/s on C2 — two grids that both start heaviest-first compete from the first cycle.)
+        // light split: the heavy tiles one light per workgroup first, every other tile behind them in the same grid; the last of a
+        // tile's workgroups to finish its march finishes the tile.  (A second launch for the finish cost 35-45 µs per frame —
+        // more than the split gains on throughput-bound frames; the same launch on a side stream gained nothing.)
+        HIP_OK(hipMemsetAsync(splitStore, 0, (size_t)splitK * sizeof(uint32_t), stream));  // the tiles' arrival counters
         hipLaunchKernelGGL((render_kernel<false, 0, false, false, false, 1>), dim3((unsigned)(splitK * numLights + tileCount - splitK)), dim3(64), 0, stream,
                            slot->dev, map, W, H, nRows, o, b, dc);
-        hipLaunchKernelGGL((render_kernel<false, 0, false, false, false, 2>), dim3((unsigned)splitK), dim3(64), 0, stream, slot->dev, map, W, H, nRows, o, b, dc);
       } else RM_LAUNCH_NOSEC(false, false, false);
     }
 #undef RM_LAUNCH
@@ -1267,6 +1339,10 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     if (tuneTimed >= 0 && tune) {
       HIP_OK(hipEventRecord(tune->ev[tuneTimed][1], stream));
       tune->timed[tuneTimed] = true;
+    }
+    if (splitTimed >= 0 && splitTune) {
+      HIP_OK(hipEventRecord(splitTune->ev[splitTimed][1], stream));
+      splitTune->timed[splitTimed] = true;
     }
     if ((st = stamp(((byCost || byGeom) && !settled) ? 2 : 1)) != RM_OK) return st;
   }
@@ -1604,6 +1680,7 @@ int rm_debug_last_path(void) {
 int rm_debug_set_light_split(int div) {
   if (div < -1) { set_error("light split: -1 (default), 0 (off) or the divisor n >= 1"); return RM_ERR_INVALID_ARGUMENT; }
   g_lightSplit.store(div);
+  g_lightSplitForce.store(div > 0);  // an explicit divisor splits without measuring (tests); -1 / the environment variable: measured
   return RM_OK;
 }
 int rm_debug_last_split(void) {
@@ -1640,6 +1717,9 @@ int rm_release_workspaces(unsigned long long *freedBytes) {
   for (auto &kv : ds->shapeTune) kv.second.drop();
   ds->shapeTune.clear();
   ds->shapeChoice.clear();
+  for (auto &kv : ds->splitTune) kv.second.drop();
+  ds->splitTune.clear();
+  ds->splitChoice.clear();
   ds->wfDenied.clear();
   if (freedBytes) *freedBytes = freed;
   return RM_OK;
