@@ -417,6 +417,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     schedule = L.rm_debug_last_path()
+    split_tiles = L.rm_debug_last_split()  # > 0: the launcher kept the light split for this picture (its heaviest tiles one light per workgroup)
     timed_frame = frame_holder["f"].clone() if rank == 0 else None  # what the timed region produced (checked below)
     import ctypes as C
     kms, kn = C.c_double(), C.c_int()
@@ -571,6 +572,8 @@ def main():
                         "bytes_per_pixel": 16, "what": "algorithmic bytes (one float4 store per pixel) over the same time"}}
         if ordered:
             roof["stage_ms"] = {"tile_order_sort": round(stages[0], 4), "render_kernel": round(stages[1], 4)}
+        if split_tiles > 0:
+            roof["light_split_tiles"] = split_tiles
         if flops_exec is not None:
             # executed = the work the one-lane-per-pixel kernel really does (bounding-ball culls, no shadow march for dropped lights)
             executed = flops_exec / world / secs / 1e12 if secs > 0 else 0.0

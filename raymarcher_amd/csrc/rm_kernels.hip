@@ -1187,7 +1187,9 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   // back (C2: 26-40 evaluations of primary march, then three soft-shadow marches of 256 — profiles/r04_r_c2_chain_sim.txt).  The
   // first tileCount / kSplitDiv tiles of the settled order are therefore rendered by numLights workgroups each — every one repeats
   // the primary march and the surface point and marches ONE light, its result going to memory (the first one's primary result too)
-  // — and the last of them to arrive finishes the tile from the stored results: surface point, AO and the light sum, no march.  The same marches, the same sums in the same order: the same pixels.  RM_LIGHT_SPLIT=0: off.
+  // — and the last of them to arrive finishes the tile from the stored results: surface point, AO and the light sum, no march.  The
+  // same marches, the same sums in the same order: the same pixels.  Whether it pays is measured per picture (SplitTune above).
+  // RM_LIGHT_SPLIT=0: off; =n: the heaviest 1/n of the tiles.
   static const int envSplitDiv = [] { const char *e = std::getenv("RM_LIGHT_SPLIT"); const int v = e ? std::atoi(e) : 256; return v < 0 ? 0 : v; }();
   const int kSplitDiv = g_lightSplit.load() >= 0 ? g_lightSplit.load() : envSplitDiv;  // rm_debug_set_light_split
   int splitK = 0, splitTimed = -1;  // splitTimed: 0 / 1 = time this launch as the tuner's plain / split candidate
