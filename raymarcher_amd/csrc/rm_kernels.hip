@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(uint32_t *__restrict_
 // 4K frames (scripts/cold_order_probe.py, profiles/r04_k_geometric_order.md): bulb 2.85 → 2.26 ms (measured costs: 1.99),
 // directional_light_2.json 1.89 → 1.77-1.81, reflections_complex.json 8.70 → 8.39-8.44.  Same pixels.
 __global__ __launch_bounds__(256) void tile_geom_kernel(const SceneBlock *__restrict__ sb, RowMap map, int W, int H, int nRows, int tilesX,
-                                                        int tileW, int tileH, int n, uint32_t *__restrict__ cost, int combine, int ringLog2) {
+                                                        int tileW, int tileH, int n, const uint32_t *__restrict__ stale,
+                                                        uint32_t *__restrict__ cost, int combine, int ringLog2, int dilate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int x = (i % tilesX) * tileW + tileW / 2, r = (i / tilesX) * tileH + tileH / 2;
@@ -292,8 +293,20 @@ __global__ __launch_bounds__(256) void tile_geom_kernel(const SceneBlock *__rest
   }
   const uint32_t gv = cls == 2 ? (1u << ringLog2) : (cls == 1 ? (1u << 11) : (1u << 4));
   // combine: a frame of the same size rendered a DIFFERENT picture before (a moving camera) — its measured costs are stale but near;
-  // the heavier of the two estimates decides
-  cost[i] = (combine && cost[i] > gv) ? cost[i] : gv;
+  // the heavier of the two estimates decides.  dilate: the stale estimate of a tile is the heaviest within that many tiles of it (a
+  // silhouette that the camera's motion shifted by a few tiles is still where its heavy tiles are looked for)
+  uint32_t sv = 0u;
+  if (combine) {
+    const int tx = i % tilesX, ty = i / tilesX, tilesY = (n + tilesX - 1) / tilesX;
+    for (int dy = -dilate; dy <= dilate; dy++)
+      for (int dx = -dilate; dx <= dilate; dx++) {
+        const int nx = tx + dx, ny = ty + dy;
+        if (nx < 0 || ny < 0 || nx >= tilesX || ny >= tilesY || ny * tilesX + nx >= n) continue;
+        const uint32_t c = stale[ny * tilesX + nx];
+        sv = c > sv ? c : sv;
+      }
+  }
+  cost[i] = sv > gv ? sv : gv;
 }
 
 __global__ void probe_math_kernel(int fn, const float *x, const float *y, const float *z, float *out, int n) {
@@ -1148,7 +1161,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   // 0.80 -> 0.59 ms, textured floor / sky box at 4K 2.5 -> 2.3 ms, terrain + cloud horizon view 4.31 -> 4.04 ms, sea unchanged)
   const bool ordered = orderMode > 0 && !wavefront && !g->isTwoD && count == 0 &&
                        tileCount >= 2048 && !ds.dbgTileOrder && !ds.dbgTileCost;
-  uint32_t *oCost = nullptr, *oHist = nullptr;
+  uint32_t *oCost = nullptr, *oHist = nullptr, *oCost2 = nullptr;
   int32_t *oOrder = nullptr;
   bool haveCost = false, samePicture = false;
   // A picture that repeats SETTLES: its first frames re-sort by the costs the frame before measured (each under a better order than
@@ -1160,10 +1173,11 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   int costSorts = 0;  // this frame is the costSorts-th consecutive cost-ordered frame of its picture (0: not cost-ordered)
   if (ordered) {
     void *mem = nullptr;
-    if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 8 + 256, &mem)) != RM_OK) return st;
+    if ((st = stream_workspace(kWsTileOrder, stream, (size_t)tileCount * 12 + 256, &mem)) != RM_OK) return st;
     oHist = static_cast<uint32_t *>(mem);
     oCost = oHist + 64;
     oOrder = reinterpret_cast<int32_t *>(oCost + tileCount);
+    oCost2 = oCost + 2 * (size_t)tileCount;  // a new picture's estimates (tile_geom_kernel), so that it can read its neighbours' stale costs
     TileOrderState &ts = ds.tileOrder[stream];
     const TileOrderState now{tileCount, W, nRows, nw, tileShift, mem, key};
     haveCost = ts.tileCount == now.tileCount && ts.W == W && ts.nRows == nRows && ts.nw == nw && ts.tileShift == tileShift && ts.mem == mem;
@@ -1179,6 +1193,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   static const int geomMode = [] { const char *e = std::getenv("RM_TILE_ORDER_GEOMETRIC"); return e ? std::atoi(e) : 2; }();  // 0 off (raster), 1 geometry alone, 2 geometry + stale costs (measured best, default)
   const bool geomOn = geomMode != 0;
   static const int ringCombined = [] { const char *e = std::getenv("RM_GEOM_RING_LOG2"); const int v = e ? std::atoi(e) : 16; return v < 5 ? 5 : (v > 17 ? 17 : v); }();
+  static const int geomDilate = [] { const char *e = std::getenv("RM_GEOM_DILATE"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : (v > 16 ? 16 : v); }();
   const bool byCost = ordered && samePicture;
   const bool lastSort = byCost && kSettle > 0 && costSorts == kSettle, settled = byCost && kSettle > 0 && costSorts > kSettle;
   bool byGeom = ordered && !samePicture && geomOn && !envFeatures && numObjects > 0;
@@ -1292,11 +1307,16 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
     // compiled out so the common kernels keep their register budget.
     if ((byCost || byGeom) && !settled) {  // this frame's launch order — from the previous frame's tile costs or from geometry — ahead of the render
       const dim3 sgrid((tileCount + 255) / 256);
-      if (byGeom) hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * tileW, tileH, tileCount, oCost,
-                                     (geomMode == 2 && haveCost) ? 1 : 0, ((geomMode == 2 && haveCost) ? ringCombined : 16));
+      uint32_t *sortCost = oCost;
+      if (byGeom) {  // estimates into their own array (the kernel reads the stale costs of a tile's neighbourhood), stale costs cleared after
+        hipLaunchKernelGGL(tile_geom_kernel, sgrid, dim3(256), 0, stream, slot->dev, map, W, H, nRows, (int)rgrid.x, nw * tileW, tileH, tileCount, oCost, oCost2,
+                           (geomMode == 2 && haveCost) ? 1 : 0, ((geomMode == 2 && haveCost) ? ringCombined : 16), geomDilate);
+        HIP_OK(hipMemsetAsync(oCost, 0, (size_t)tileCount * sizeof(uint32_t), stream));
+        sortCost = oCost2;
+      }
       HIP_OK(hipMemsetAsync(oHist, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
-      hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist);
-      hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, oCost, tileCount, oHist, oOrder, lastSort ? 1 : 0);
+      hipLaunchKernelGGL(tile_hist_kernel, sgrid, dim3(256), 0, stream, sortCost, tileCount, oHist);
+      hipLaunchKernelGGL(tile_scatter_kernel, sgrid, dim3(256), 0, stream, sortCost, tileCount, oHist, oOrder, lastSort ? 1 : 0);
       if ((st = stamp(1)) != RM_OK) return st;  // stage 0 = the ordering launches, stage 1 = the render
     }
     if (splitTimed >= 0 && splitTune) {
