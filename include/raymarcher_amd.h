@@ -362,7 +362,7 @@ int rm_release_workspaces(unsigned long long *freedBytes);
 /* Tests: the schedule (numbering above; never 0) the most recent render launch on the current device ran, -1 on error. */
 int rm_debug_last_path(void);
 /* Tests: how many tiles the most recent render launch on the current device rendered one light per workgroup ("light split": the
- * heaviest tiles of a SETTLED picture of the plain table-walk class with 2-8 lights are rendered by numLights workgroups each, one
+ * heaviest tiles of a SETTLED picture of the plain table-walk class with two or more lights are rendered by numLights workgroups each, one
  * shadow march per pixel apiece, and finished by a second short launch from the stored results — the same marches and the same sums
  * in the same order, so the same pixels; it shortens the longest waves of latency-bound frames.  RM_LIGHT_SPLIT=0 turns it off,
  * =n makes the heaviest 1/n of the tiles split; default 256 — C2: 0.79 → 0.65 ms with 1/128 … 1/512, less with more).  0: none;

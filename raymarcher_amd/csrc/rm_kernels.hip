@@ -1211,7 +1211,7 @@ int launch_render(const RmCamera *cam, const RmObject *objs, int numObjects, con
   float *splitStore = nullptr;
   SplitTune *splitTune = nullptr;
   if (settled && kSplitDiv > 0 && !bulb && !envFeatures && !textured && !secondary && count == 0 && nw == 1 && numLights >= 2 &&
-      numLights <= 8 && tuneTimed < 0) {
+      numLights <= RM_MAX_LIGHTS && tuneTimed < 0) {
     splitK = tileCount / kSplitDiv;
     if (splitK > 0 && !g_lightSplitForce.load()) {  // measured, unless a test forces it (rm_debug_set_light_split)
       splitTune = &ds.splitTune[stream];

@@ -17,7 +17,7 @@ def main():
     L = lib()
     S = os.path.join(ROOT, "tests", "golden", "scenes", "lighting")
     rows = ["| scene | size | shadows | split off, ms | forced, 1/256 of the tiles | measured by the launcher (default) | tiles split by default |", "|---|---|---|---|---|---|---|"]
-    for name in ("directional_light_2", "point_light_2", "spot_light_2", "hdr", "depth_of_field", "shadow_test"):
+    for name in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("directional_light_2", "point_light_2", "spot_light_2", "hdr", "depth_of_field", "shadow_test")):
         for W, H in ((1920, 1080), (3840, 2160)):
             for soft in (0, 1):
                 t = Scene(path=os.path.join(S, name + ".json")).tables(W, H, load_textures=False)

@@ -1562,7 +1562,7 @@ def test_random_tablewalk_scenes_bit_exact(renderer):
             for rep in range(3):
                 assert _ieq(renderer.render(tables_of(scene), s, W, H), out), f"seed {seed} scene {i}: repeat {rep + 1} differs"
             # … and with the tile shape pinned the picture settles by its fifth frame: the sixth has its heaviest eighth of the tiles
-            # rendered one light per workgroup where the scene is eligible (no secondary rays, 2-8 lights)
+            # rendered one light per workgroup where the scene is eligible (no secondary rays, two or more lights)
             try:
                 lib().rm_debug_set_tile_shape(3)
                 lib().rm_debug_set_light_split(8)
