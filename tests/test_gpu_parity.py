@@ -1148,6 +1148,13 @@ def test_light_split_of_a_settled_picture_never_changes_a_pixel(renderer, soft, 
         assert L.rm_debug_last_split() == tiles
         assert L.rm_debug_set_light_split(0) == 0
         assert _ieq(renderer.render(t, s, W, H), first) and L.rm_debug_last_split() == 0
+        # the default: the launcher measures (two plain frames, two split, then the better) — whatever it decides, the same frame
+        assert L.rm_debug_set_light_split(-1) == 0
+        seen = set()
+        for k in range(20):
+            assert _ieq(renderer.render(t, s, W, H), first), f"measured mode, frame {k}"
+            seen.add(L.rm_debug_last_split())
+        assert seen <= {0, tiles // 256} and tiles // 256 in seen  # its two split frames ran
     finally:
         L.rm_debug_set_tile_shape(-1)
         L.rm_debug_set_light_split(-1)
