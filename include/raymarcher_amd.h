@@ -362,11 +362,11 @@ int rm_release_workspaces(unsigned long long *freedBytes);
 /* Tests: the schedule (numbering above; never 0) the most recent render launch on the current device ran, -1 on error. */
 int rm_debug_last_path(void);
 /* Tests: how many tiles the most recent render launch on the current device rendered one light per workgroup ("light split": the
- * heaviest tiles of a SETTLED picture of the plain table-walk class with two or more lights are rendered by numLights workgroups each, one
- * shadow march per pixel apiece, and finished by a second short launch from the stored results — the same marches and the same sums
- * in the same order, so the same pixels; it shortens the longest waves of latency-bound frames.  RM_LIGHT_SPLIT=0 turns it off,
- * =n makes the heaviest 1/n of the tiles split; default 256 — C2: 0.79 → 0.65 ms with 1/128 … 1/512, less with more).  0: none;
- * -1 on error. */
+ * heaviest tiles of a SETTLED picture of the plain table-walk class with two or more lights are rendered by numLights workgroups
+ * each, one shadow march per pixel apiece, and finished — by whichever of them arrives last — from the stored results: the same
+ * marches and the same sums in the same order, so the same pixels; it shortens the longest waves of latency-bound frames, C2 0.79 →
+ * 0.51 ms.  Whether it pays is measured per picture.  RM_LIGHT_SPLIT=0 turns it off, =n makes the heaviest 1/n of the tiles the
+ * candidates; default 256).  0: none; -1 on error. */
 int rm_debug_last_split(void);
 /* Tests / experiments: the divisor above for the process — n >= 1 also splits WITHOUT the measurement that normally decides per
  * picture whether the split pays (settled frames 0-1 plain, 2-3 split, the better of the two from then on); 0 = off, -1 = back to
