@@ -477,7 +477,7 @@ def main():
             "value": round(W * H / ms / 1e3, 2), "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "kernel_ms": round(k, 4), "steps": nv,
             "what": "RM_FEAT_BULB_POWER8_ALGEBRAIC: w^8 by complex squarings instead of acos/atan/sin/cos/pow; same function, "
                     "|ΔDE| median 4e-8, 0.08 % of frame pixels differ by > 1e-3 from the headline frame"}
-    if single and cfg in ("c2", "c3", "c5"):
+    if single and cfg in ("c1", "c2", "c3", "c4", "c5"):
         # three frames in flight, each on its own stream and into its own buffer: a frame's last straggler rays (a serial
         # chain of ≈0.7 ms; for the wavefront pipeline the tail of each of its dozen kernels) overlap the next frames' full
         # waves — what a caller that renders a sequence gets; never `value`
