@@ -16,7 +16,9 @@ reason).  Those lines run on np.float32 arrays with NumPy's IEEE operations; eve
 
 Scope: exactly what a frame of scenefiles/simple/unit_mandelbulb.json (C3) or unit_mengersponge.json (C5: sdMengerSponge,
 frag:1049-1071, its palette and main's reflection loop, frag:2491-2524) executes with the reference's default #defines
-(WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, refraction, sky box off): one object, DIRECTIONAL lights.  Anything else raises."""
+(WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, refraction, sky box off): one object, DIRECTIONAL lights — render_frame — and,
+at the end of the file, tables of untextured cubes / cones / cylinders / spheres under directional and point lights with soft
+shadows and ambient occlusion (C2's class, ten of the reference's scenefiles) — render_frame_table.  Anything else raises."""
 import numpy as np
 
 SURFACE_DIST = 1e-3          # frag:32
@@ -299,3 +301,164 @@ def render_frame(tables, settings, W, H):
             go = ~env                                   # `if (res.isEnv) break;`
             idx, p, n, d = idx[go], P2[go], N2[go], r[go]
     return out.reshape(H, W, 4), (~is_env).reshape(H, W)
+
+
+# ---------------------------------------------------------------------------------------------- tables of primitives (C2)
+# Round 4, late: the lighting configuration (scenefiles/lighting/directional_light_2.json with soft shadows and ambient occlusion)
+# transcribed independently as well — sdScene over a table (frag:1406-1430), sdMatch's cube / cone / cylinder / sphere (frag:832-872,
+# 1262-1271), softshadow with its penumbra factor (frag:1703-1725; UB1 of DESIGN.md §4: r.d is the factor on a miss too), calcAO
+# (frag:1729-1740), getPhong with directional and point lights (frag:1842-1933, 445-447).
+RM_CUBE, RM_CONE, RM_CYLINDER, RM_SPHERE, RM_LIGHT_POINT = 0, 1, 2, 3, 0
+
+
+def _len2(a, b):
+    return np.sqrt(a * a + b * b)
+
+
+def sd_cube(p):      # sdBox(p, vec3(0.5)), frag:843-846
+    q = np.abs(p) - 0.5
+    return np.sqrt(_dot(np.maximum(q, 0.0), np.maximum(q, 0.0))) + np.minimum(np.max(q, axis=-1), 0.0)
+
+
+def sd_cone(p, r=0.5, h=0.5):  # frag:853-862
+    po = np.stack([_len2(p[:, 0], p[:, 2]) - r, p[:, 1] + h], -1)
+    e = np.array([-r, 2.0 * h])
+    q = po - e * np.clip((po @ e) / (e @ e), 0.0, 1.0)[:, None]
+    d = _len2(q[:, 0], q[:, 1])
+    return np.where(np.maximum(q[:, 0], q[:, 1]) > 0.0, d, -np.minimum(d, po[:, 1]))
+
+
+def sd_cylinder(p, h=0.5, r=0.5):  # frag:869-872
+    d = np.abs(np.stack([_len2(p[:, 0], p[:, 2]), p[:, 1]], -1)) - np.array([r, h])
+    return np.minimum(np.maximum(d[:, 0], d[:, 1]), 0.0) + _len2(np.maximum(d[:, 0], 0.0), np.maximum(d[:, 1], 0.0))
+
+
+def sd_sphere(p, r=0.5):  # frag:832-834
+    return np.sqrt(_dot(p, p)) - r
+
+
+class Table:
+    """sdScene (frag:1406-1430) over a table of primitives: the minimum of sdMatch(po)·scaleFactor with a strict `<` (the first of
+    equal objects wins); the index of the minimum travels in the first component of what the fractal classes call the trap."""
+    SDF = {RM_CUBE: sd_cube, RM_CONE: sd_cone, RM_CYLINDER: sd_cylinder, RM_SPHERE: sd_sphere}
+
+    def __init__(self, objects):
+        self.objs = [(self.SDF[t], np.asarray(M, np.float64), float(sf)) for t, M, sf in objects]
+
+    def __call__(self, p):
+        best = np.full(len(p), 1000000.0)
+        idx = np.full(len(p), -1.0)
+        for k, (f, M, sf) in enumerate(self.objs):
+            d = f(p @ M[:3, :3].T + M[:3, 3]) * sf
+            closer = d < best
+            best, idx = np.where(closer, d, best), np.where(closer, float(k), idx)
+        return best, np.stack([idx, np.zeros_like(idx), np.zeros_like(idx), np.zeros_like(idx)], -1)
+
+
+def softshadow(sd, ro, rd, maxt, max_steps, k=8.0):
+    """frag:1703-1725 with mint = 0: (hit, res).  res = min over the steps of k·d/t — the first step divides by t = 0: +inf for d > 0,
+    which min drops, as in the shader."""
+    n = len(ro)
+    t, res, d = np.zeros(n), np.ones(n), np.full(n, 1000000.0)
+    idx = np.arange(n)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for _ in range(max_steps):
+            if len(idx) == 0:
+                break
+            dd = sd(ro[idx] + rd[idx] * t[idx, None])[0]
+            d[idx] = dd
+            go = ~((np.abs(dd) < SURFACE_DIST) | (t[idx] > maxt[idx]))
+            g = idx[go]
+            res[g] = np.minimum(res[g], k * dd[go] / t[g])
+            t[g] += np.abs(dd[go])
+            idx = g
+    return np.abs(d) < SURFACE_DIST, res
+
+
+def calc_ao(sd, pos, nor):  # frag:1729-1740
+    occ, sca = np.zeros(len(pos)), 1.0
+    live = np.ones(len(pos), bool)
+    for i in range(5):
+        hgt = 0.01 + 0.12 * float(i) / 4.0
+        d = sd(pos + hgt * nor)[0]
+        occ = np.where(live, occ + (hgt - d) * sca, occ)
+        sca *= 0.95
+        live = live & ~(occ > 0.35)
+    return np.clip(1.0 - 3.0 * occ, 0.0, 1.0) * (0.5 + 0.5 * nor[:, 1])
+
+
+def get_phong_table(sd, N, mats, lights, g, p, rd, far, settings):
+    """frag:1842-1933 for untextured objects (one material ROW per point in `mats`), directional and point lights, with the soft
+    shadow factor and ambient occlusion when the settings ask for them."""
+    ka, kd, ks = g
+    ao = calc_ao(sd, p, N) if settings.enableAmbientOcclusion else np.ones(len(p))
+    total = mats["cAmbient"] * ka * ao[:, None]
+    V = _normalize(-rd)
+    for li in lights:
+        if li["type"] == RM_LIGHT_POINT:
+            to = li["pos"] - p
+            dist = np.sqrt(_dot(to, to))
+            L, maxt = to / dist[:, None], dist
+            f = li["func"]
+            with np.errstate(divide="ignore"):
+                f_att = np.minimum(1.0 / (f[0] + dist * f[1] + dist * dist * f[2]), 1.0)  # attenuationFactor, frag:445-447
+        else:
+            L = np.broadcast_to(_normalize(-li["dir"]), p.shape)
+            maxt, f_att = np.full(len(p), far), np.ones(len(p))
+        occluded, pen = softshadow(sd, p + N * SURFACE_DIST * 5.0, L, maxt, settings.maxSteps)  # frag:1908
+        ndl = _dot(N, L)
+        lit = ~occluded & ~(ndl <= 0.005)
+        col = (kd * mats["cDiffuse"]) * np.clip(ndl, 0.0, 1.0)[:, None] * li["color"]
+        R = (-L) - 2.0 * _dot(N, -L)[:, None] * N
+        rdv = np.clip(_dot(R, V), 0.0, 1.0)
+        sh = mats["shininess"]
+        with np.errstate(invalid="ignore"):
+            spec = np.where(sh == 0.0, ks * rdv, ks * np.power(rdv, np.where(sh == 0.0, 1.0, sh)))  # getSpecular, frag:1787-1792
+        col = (col + spec[:, None] * mats["cSpecular"] * li["color"]) * f_att[:, None]
+        if settings.enableSoftShadow:
+            col = col * pen[:, None]  # frag:1928 (UB1: the penumbra factor, hit or miss)
+        total = total + np.where(lit[:, None], col, 0.0)
+    return total
+
+
+def render_frame_table(tables, settings, W, H):
+    """fragColor of every pixel of a table of untextured cubes / cones / cylinders / spheres under directional and point lights:
+    (H, W, 4) float64 and the hit mask.  No bump map is applied unless PERLIN_BUMP is set; reflection / refraction must be off."""
+    assert not (settings.enableReflection or settings.enableRefraction or settings.enableSkyBox) and not tables.globals_.isTwoD
+    assert settings.features & RM_FEAT_WHITE_BACKGROUND
+    objs, mats = [], {"cAmbient": [], "cDiffuse": [], "cSpecular": [], "shininess": []}
+    for i in range(tables.num_objects):
+        o = tables.objects[i]
+        assert o.type in Table.SDF and o.texLoc == -1 and not o.isEmissive
+        objs.append((o.type, np.array(list(o.invModel), np.float64).reshape(4, 4).T, o.scaleFactor))
+        for k in ("cAmbient", "cDiffuse", "cSpecular"):
+            mats[k].append(list(getattr(o, k)))
+        mats["shininess"].append(float(o.shininess))
+    mats = {k: np.array(v, np.float64) for k, v in mats.items()}
+    lights = []
+    for i in range(tables.num_lights):
+        li = tables.lights[i]
+        assert li.type in (RM_LIGHT_DIRECTIONAL, RM_LIGHT_POINT)
+        lights.append({"type": li.type, "dir": np.array(list(li.dir), np.float64), "pos": np.array(list(li.pos), np.float64),
+                       "func": np.array(list(li.func), np.float64), "color": np.array(list(li.color), np.float64)})
+    gl = tables.globals_
+    sd = Table(objs)
+    inv_pv = np.array(list(tables.camera.invProjView), np.float64).reshape(4, 4).T
+    far = float(tables.camera.initialFar)
+    ys, xs = np.mgrid[0:H, 0:W]
+    ndc = np.stack([(xs.ravel() + 0.5) / W * 2.0 - 1.0, (ys.ravel() + 0.5) / H * 2.0 - 1.0], -1)
+    near = np.concatenate([ndc, np.full((len(ndc), 1), -1.0), np.ones((len(ndc), 1))], -1) @ inv_pv.T
+    farc = np.concatenate([ndc, np.ones((len(ndc), 1)), np.ones((len(ndc), 1))], -1) @ inv_pv.T
+    ro = near[:, :3] / near[:, 3:]
+    rd = _normalize(farc[:, :3] / farc[:, 3:] - ro)
+    out = np.ones((len(ndc), 4))
+    hit, depth, trap = raymarch(sd, ro, rd, far, settings.maxSteps)
+    if hit.any():
+        p = ro[hit] + rd[hit] * depth[hit, None]
+        pn = get_normal(sd, p)
+        if settings.features & RM_FEAT_PERLIN_BUMP:
+            pn = bump_normal(pn, p)
+        k = trap[hit, 0].astype(int)
+        m = {key: v[k] for key, v in mats.items()}
+        out[hit, :3] = get_phong_table(sd, pn, m, lights, (gl.ka, gl.kd, gl.ks), p, rd[hit], far, settings)
+    return out.reshape(H, W, 4), hit.reshape(H, W)
