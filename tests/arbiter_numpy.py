@@ -17,8 +17,9 @@ reason).  Those lines run on np.float32 arrays with NumPy's IEEE operations; eve
 Scope: exactly what a frame of scenefiles/simple/unit_mandelbulb.json (C3) or unit_mengersponge.json (C5: sdMengerSponge,
 frag:1049-1071, its palette and main's reflection loop, frag:2491-2524) executes with the reference's default #defines
 (WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, refraction, sky box off): one object, DIRECTIONAL lights — render_frame — and,
-at the end of the file, tables of untextured cubes / cones / cylinders / spheres under directional and point lights with soft
-shadows and ambient occlusion (C2's class, ten of the reference's scenefiles) — render_frame_table.  Anything else raises."""
+at the end of the file, tables of any of sdMatch's nine primitives (untextured) under directional, point and spot lights with soft
+shadows and ambient occlusion (C2's class: the geometry of 38 of the reference's scenefiles) — render_frame_table.  Anything else
+raises."""
 import numpy as np
 
 SURFACE_DIST = 1e-3          # frag:32
@@ -305,10 +306,10 @@ def render_frame(tables, settings, W, H):
 
 # ---------------------------------------------------------------------------------------------- tables of primitives (C2)
 # Round 4, late: the lighting configuration (scenefiles/lighting/directional_light_2.json with soft shadows and ambient occlusion)
-# transcribed independently as well — sdScene over a table (frag:1406-1430), sdMatch's cube / cone / cylinder / sphere (frag:832-872,
-# 1262-1271), softshadow with its penumbra factor (frag:1703-1725; UB1 of DESIGN.md §4: r.d is the factor on a miss too), calcAO
-# (frag:1729-1740), getPhong with directional and point lights (frag:1842-1933, 445-447).
-RM_CUBE, RM_CONE, RM_CYLINDER, RM_SPHERE, RM_LIGHT_POINT = 0, 1, 2, 3, 0
+# transcribed independently as well — sdScene over a table (frag:1406-1430), sdMatch's nine primitives (frag:832-896, 991-1019,
+# 1262-1280), softshadow with its penumbra factor (frag:1703-1725; UB1 of DESIGN.md §4: r.d is the factor on a miss too), calcAO
+# (frag:1729-1740), getPhong with directional, point and spot lights (frag:1842-1933, 439-461).
+RM_CUBE, RM_CONE, RM_CYLINDER, RM_SPHERE, RM_LIGHT_POINT, RM_LIGHT_SPOT = 0, 1, 2, 3, 0, 2
 
 
 def _len2(a, b):
@@ -337,10 +338,44 @@ def sd_sphere(p, r=0.5):  # frag:832-834
     return np.sqrt(_dot(p, p)) - r
 
 
+def sd_octahedron(p, s=0.5):  # frag:877-888
+    p = np.abs(p)
+    m = p[:, 0] + p[:, 1] + p[:, 2] - s
+    r = 3.0 * p - m[:, None]
+    q = np.where((r[:, 0] < 0.0)[:, None], p, np.where((r[:, 1] < 0.0)[:, None], p[:, [1, 2, 0]], p[:, [2, 0, 1]]))
+    k = np.clip(0.5 * (q[:, 2] - q[:, 1] + s), 0.0, s)
+    inside = np.sqrt(q[:, 0] ** 2 + (q[:, 1] - s + k) ** 2 + (q[:, 2] - k) ** 2)
+    return np.where((r[:, 0] < 0.0) | (r[:, 1] < 0.0) | (r[:, 2] < 0.0), inside, m * 0.57735027)
+
+
+def sd_torus(p, t=(0.5, 0.5 / 4)):  # frag:893-896
+    return _len2(_len2(p[:, 0], p[:, 2]) - t[0], p[:, 1]) - t[1]
+
+
+def sd_capsule(p, h=0.5, r=0.1):  # frag:991-994
+    y = p[:, 1] - np.clip(p[:, 1], 0.0, h)
+    return np.sqrt(p[:, 0] ** 2 + y ** 2 + p[:, 2] ** 2) - r
+
+
+def sd_deathstar(p2, ra=0.5, rb=0.35, d=0.5):  # frag:1005-1019
+    px, py = p2[:, 0], _len2(p2[:, 1], p2[:, 2])
+    a = (ra * ra - rb * rb + d * d) / (2.0 * d)
+    b = np.sqrt(max(ra * ra - a * a, 0.0))
+    rim = _len2(px - a, py - b)
+    body = np.maximum(_len2(px, py) - ra, -(_len2(px - d, py) - rb))
+    return np.where(px * b - py * a > d * np.maximum(b - py, 0.0), rim, body)
+
+
+def sd_rectangle(p):  # sdBox(p, vec3(0.5, 0.5, 0)), frag:1279
+    q = np.abs(p) - np.array([0.5, 0.5, 0.0])
+    return np.sqrt(_dot(np.maximum(q, 0.0), np.maximum(q, 0.0))) + np.minimum(np.max(q, axis=-1), 0.0)
+
+
 class Table:
     """sdScene (frag:1406-1430) over a table of primitives: the minimum of sdMatch(po)·scaleFactor with a strict `<` (the first of
     equal objects wins); the index of the minimum travels in the first component of what the fractal classes call the trap."""
-    SDF = {RM_CUBE: sd_cube, RM_CONE: sd_cone, RM_CYLINDER: sd_cylinder, RM_SPHERE: sd_sphere}
+    SDF = {RM_CUBE: sd_cube, RM_CONE: sd_cone, RM_CYLINDER: sd_cylinder, RM_SPHERE: sd_sphere, 4: sd_octahedron, 5: sd_torus,
+           6: sd_capsule, 7: sd_deathstar, 8: sd_rectangle}  # scenedata.h's PrimitiveType order ≡ frag:53-66
 
     def __init__(self, objects):
         self.objs = [(self.SDF[t], np.asarray(M, np.float64), float(sf)) for t, M, sf in objects]
@@ -395,13 +430,19 @@ def get_phong_table(sd, N, mats, lights, g, p, rd, far, settings):
     total = mats["cAmbient"] * ka * ao[:, None]
     V = _normalize(-rd)
     for li in lights:
-        if li["type"] == RM_LIGHT_POINT:
+        if li["type"] in (RM_LIGHT_POINT, RM_LIGHT_SPOT):
             to = li["pos"] - p
             dist = np.sqrt(_dot(to, to))
             L, maxt = to / dist[:, None], dist
             f = li["func"]
             with np.errstate(divide="ignore"):
                 f_att = np.minimum(1.0 / (f[0] + dist * f[1] + dist * dist * f[2]), 1.0)  # attenuationFactor, frag:445-447
+            if li["type"] == RM_LIGHT_SPOT:  # angularFalloff, frag:439-461
+                cosalpha = _dot(np.broadcast_to(-_normalize(li["dir"]), p.shape), L)
+                inner = li["angle"] - li["penumbra"]
+                tt = (np.arccos(np.clip(cosalpha, -1.0, 1.0)) - inner) / (li["angle"] - inner)
+                fall = 1.0 - (-2.0 * tt ** 3 + 3.0 * tt ** 2)
+                f_att = f_att * np.where(cosalpha <= np.cos(li["angle"]), 0.0, np.where(cosalpha > np.cos(inner), 1.0, fall))
         else:
             L = np.broadcast_to(_normalize(-li["dir"]), p.shape)
             maxt, f_att = np.full(len(p), far), np.ones(len(p))
@@ -438,9 +479,10 @@ def render_frame_table(tables, settings, W, H):
     lights = []
     for i in range(tables.num_lights):
         li = tables.lights[i]
-        assert li.type in (RM_LIGHT_DIRECTIONAL, RM_LIGHT_POINT)
+        assert li.type in (RM_LIGHT_DIRECTIONAL, RM_LIGHT_POINT, RM_LIGHT_SPOT)
         lights.append({"type": li.type, "dir": np.array(list(li.dir), np.float64), "pos": np.array(list(li.pos), np.float64),
-                       "func": np.array(list(li.func), np.float64), "color": np.array(list(li.color), np.float64)})
+                       "func": np.array(list(li.func), np.float64), "color": np.array(list(li.color), np.float64),
+                       "angle": float(li.angle), "penumbra": float(li.penumbra)})
     gl = tables.globals_
     sd = Table(objs)
     inv_pv = np.array(list(tables.camera.invProjView), np.float64).reshape(4, 4).T

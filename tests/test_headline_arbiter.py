@@ -91,27 +91,37 @@ def test_menger_and_the_reflection_loop_against_the_independent_arbiter(over, mi
     assert (d[ok] <= 1e-3).mean() >= (0.985 if over else 0.995)
 
 
-TABLE_SCENES = ["lighting/directional_light_1", "lighting/directional_light_2", "lighting/point_light_1", "lighting/point_light_2",
-                "lighting/reflections_basic", "lighting/reflections_complex", "lighting/simple_shadow", "lighting/test_reflectiveness",
-                "simple/parse_matrix", "simple/phong_total"]
+TABLE_SCENES = ['cubemap/beach', 'lighting/depth_of_field', 'lighting/directional_light_1', 'lighting/directional_light_2', 'lighting/hdr',
+                'lighting/point_light_1', 'lighting/point_light_2', 'lighting/reflections_basic', 'lighting/reflections_complex',
+                'lighting/refract1', 'lighting/refract2', 'lighting/shadow_test', 'lighting/simple_shadow', 'lighting/spot_light_1',
+                'lighting/spot_light_2', 'lighting/test_reflectiveness', 'simple/parse_matrix', 'simple/phong_total',
+                'simple/recursive_sphere_2', 'simple/unit_capsule', 'simple/unit_cone', 'simple/unit_cube', 'simple/unit_cylinder',
+                'simple/unit_deathstar', 'simple/unit_octa', 'simple/unit_sphere', 'simple/unit_torus',
+                'textures_tests/directional_light_textured', 'textures_tests/texture_cone', 'textures_tests/texture_cone2',
+                'textures_tests/texture_cube', 'textures_tests/texture_cube2', 'textures_tests/texture_cube_sample', 'textures_tests/texture_cyl',
+                'textures_tests/texture_cyl2', 'textures_tests/texture_cyl3', 'textures_tests/texture_sphere', 'textures_tests/texture_sphere2']
 
 
 @pytest.mark.parametrize("name", TABLE_SCENES)
-@pytest.mark.parametrize("over", [{}, {"enableSoftShadow": 1, "enableAmbientOcclusion": 1}], ids=["hard_shadows", "c2_soft_shadows_ao"])
-def test_tables_of_primitives_against_the_independent_arbiter(name, over):
-    """C2's class (round 4, late): sdScene over a table, the cube / cone / cylinder / sphere of sdMatch, softshadow's penumbra
-    factor (UB1), calcAO and getPhong with directional and point lights, transcribed independently (arbiter_numpy.render_frame_table)
-    — every scenefile of the reference that holds nothing else, C2's own (`directional_light_2.json` with soft shadows + AO) among
-    them.  The two binary64 transcriptions agree to 1e-6 on EVERY pixel (measured ≤ 5e-7); the binary32 oracle is within the north
-    star's 1e-3 of them on ≥ 99.9 % (measured: all pixels but two of one scenefile)."""
+def test_tables_of_primitives_against_the_independent_arbiter(name):
+    """C2's class (round 4, late), transcribed independently (arbiter_numpy.render_frame_table): sdScene over a table, all nine
+    primitives of sdMatch, softshadow's penumbra factor (UB1), calcAO and getPhong with directional, point and spot lights — on the
+    GEOMETRY AND LIGHTS of every scenefile of the reference that holds nothing else (38 of its 52; their textures switched off: the
+    samplers are not transcribed), soft shadows + ambient occlusion on, C2's own `directional_light_2.json` also with hard shadows.
+    The two binary64 transcriptions agree to 1e-6 on EVERY pixel (measured ≤ 5.1e-7); the binary32 oracle is within the north star's
+    1e-3 of them on ≥ 99.9 % of the pixels (measured ≥ 99.98 %: one or two silhouette pixels in six of the scenes)."""
     t = Scene(path=os.path.join(GOLD, "scenes", name + ".json")).tables(W, H, load_textures=False)
+    for i in range(t.num_objects):
+        t.objects[i].texLoc = -1
     scene = (t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_)
-    s = abi.default_settings(**over)  # reflection / refraction off: the primary shading point is what is transcribed
-    f64, hit64 = an.render_frame_table(t, s, W, H)
-    o32, c64 = h.oracle_render(scene, s, W, H), h.arbiter_render(scene, s, W, H)
-    assert np.isfinite(f64).all() and 0.04 < hit64.mean() < 0.8
-    dd = np.abs(c64 - f64).max(-1)
-    assert (dd <= 1e-6).all(), f"the C arbiter and the NumPy arbiter differ by {dd.max():.2e}"
-    d = np.abs(o32 - f64).max(-1)
-    assert (d <= 1e-3).mean() >= 0.999, f"{(d > 1e-3).sum()} of {d.size} pixels beyond 1e-3 of the independent arbiter (max {d.max():.2e})"
-    assert ((o32[..., :3] != 1.0).any(-1) != hit64).mean() <= 0.002  # the same silhouette
+    overs = [{"enableSoftShadow": 1, "enableAmbientOcclusion": 1}] + ([{}] if name == "lighting/directional_light_2" else [])
+    for over in overs:
+        s = abi.default_settings(**over)  # reflection / refraction off: the primary shading point is what is transcribed
+        f64, hit64 = an.render_frame_table(t, s, W, H)
+        o32, c64 = h.oracle_render(scene, s, W, H), h.arbiter_render(scene, s, W, H)
+        assert np.isfinite(f64).all() and 0.03 < hit64.mean() <= 1.0
+        dd = np.abs(c64 - f64).max(-1)
+        assert (dd <= 1e-6).all(), f"the C arbiter and the NumPy arbiter differ by {dd.max():.2e}"
+        d = np.abs(o32 - f64).max(-1)
+        assert (d <= 1e-3).mean() >= 0.999, f"{(d > 1e-3).sum()} of {d.size} pixels beyond 1e-3 of the independent arbiter (max {d.max():.2e})"
+        assert ((o32[..., :3] != 1.0).any(-1) != hit64).mean() <= 0.002  # the same silhouette
