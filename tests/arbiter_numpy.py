@@ -18,8 +18,8 @@ Scope: exactly what a frame of scenefiles/simple/unit_mandelbulb.json (C3) or un
 frag:1049-1071, its palette and main's reflection loop, frag:2491-2524) executes with the reference's default #defines
 (WHITE_BACKGROUND, PERLIN_BUMP; soft shadows, AO, refraction, sky box off): one object, DIRECTIONAL lights — render_frame — and,
 at the end of the file, tables of any of sdMatch's nine primitives (untextured) under directional, point and spot lights with soft
-shadows and ambient occlusion (C2's class: the geometry of 38 of the reference's scenefiles) — render_frame_table.  Anything else
-raises."""
+shadows and ambient occlusion and main's reflection loop (C2's class: the geometry of 38 of the reference's scenefiles) —
+render_frame_table.  Anything else raises."""
 import numpy as np
 
 SURFACE_DIST = 1e-3          # frag:32
@@ -462,17 +462,36 @@ def get_phong_table(sd, N, mats, lights, g, p, rd, far, settings):
     return total
 
 
+def _table_rays(sd, mats, lights, g, ro, rd, far, settings):
+    """render() (frag:2318-2375) of a table of primitives for a batch of rays: (rgb, isEnv, hit point, shading normal, object)."""
+    n = len(ro)
+    rgb = np.ones((n, 3))                                   # WHITE_BACKGROUND
+    P, N, K = np.zeros((n, 3)), np.zeros((n, 3)), np.full(n, -1)
+    hit, depth, trap = raymarch(sd, ro, rd, far, settings.maxSteps)
+    if hit.any():
+        p = ro[hit] + rd[hit] * depth[hit, None]
+        pn = get_normal(sd, p)
+        if settings.features & RM_FEAT_PERLIN_BUMP:
+            pn = bump_normal(pn, p)
+        k = trap[hit, 0].astype(int)
+        m = {key: v[k] for key, v in mats.items() if key != "cReflective"}
+        rgb[hit] = get_phong_table(sd, pn, m, lights, (g.ka, g.kd, g.ks), p, rd[hit], far, settings)
+        P[hit], N[hit], K[hit] = p, pn, k
+    return rgb, ~hit, P, N, K
+
+
 def render_frame_table(tables, settings, W, H):
-    """fragColor of every pixel of a table of untextured cubes / cones / cylinders / spheres under directional and point lights:
-    (H, W, 4) float64 and the hit mask.  No bump map is applied unless PERLIN_BUMP is set; reflection / refraction must be off."""
-    assert not (settings.enableReflection or settings.enableRefraction or settings.enableSkyBox) and not tables.globals_.isTwoD
+    """fragColor of every pixel of a table of untextured primitives under directional, point and spot lights: (H, W, 4) float64 and
+    the hit mask; main's reflection loop (frag:2491-2524: the FIRST hit's cReflective filters every bounce) when it is enabled.
+    Refraction must be off."""
+    assert not (settings.enableRefraction or settings.enableSkyBox) and not tables.globals_.isTwoD
     assert settings.features & RM_FEAT_WHITE_BACKGROUND
-    objs, mats = [], {"cAmbient": [], "cDiffuse": [], "cSpecular": [], "shininess": []}
+    objs, mats = [], {"cAmbient": [], "cDiffuse": [], "cSpecular": [], "cReflective": [], "shininess": []}
     for i in range(tables.num_objects):
         o = tables.objects[i]
         assert o.type in Table.SDF and o.texLoc == -1 and not o.isEmissive
         objs.append((o.type, np.array(list(o.invModel), np.float64).reshape(4, 4).T, o.scaleFactor))
-        for k in ("cAmbient", "cDiffuse", "cSpecular"):
+        for k in ("cAmbient", "cDiffuse", "cSpecular", "cReflective"):
             mats[k].append(list(getattr(o, k)))
         mats["shininess"].append(float(o.shininess))
     mats = {k: np.array(v, np.float64) for k, v in mats.items()}
@@ -494,13 +513,21 @@ def render_frame_table(tables, settings, W, H):
     ro = near[:, :3] / near[:, 3:]
     rd = _normalize(farc[:, :3] / farc[:, 3:] - ro)
     out = np.ones((len(ndc), 4))
-    hit, depth, trap = raymarch(sd, ro, rd, far, settings.maxSteps)
-    if hit.any():
-        p = ro[hit] + rd[hit] * depth[hit, None]
-        pn = get_normal(sd, p)
-        if settings.features & RM_FEAT_PERLIN_BUMP:
-            pn = bump_normal(pn, p)
-        k = trap[hit, 0].astype(int)
-        m = {key: v[k] for key, v in mats.items()}
-        out[hit, :3] = get_phong_table(sd, pn, m, lights, (gl.ka, gl.kd, gl.ks), p, rd[hit], far, settings)
-    return out.reshape(H, W, 4), hit.reshape(H, W)
+    rgb, is_env, P, N, K = _table_rays(sd, mats, lights, gl, ro, rd, far, settings)
+    out[:, :3] = rgb
+    if settings.enableReflection:  # frag:2491-2524
+        c_refl = mats["cReflective"][np.maximum(K, 0)]
+        idx = np.nonzero(~is_env & (np.sqrt(_dot(c_refl, c_refl)) != 0.0))[0]
+        p, n, d, cr = P[idx], N[idx], rd[idx], c_refl[idx]
+        fil = np.ones((len(idx), 3))
+        for _ in range(settings.numReflection):
+            if len(idx) == 0:
+                break
+            r = d - 2.0 * _dot(n, d)[:, None] * n
+            fil = fil * cr
+            rgb2, env, P2, N2, _k2 = _table_rays(sd, mats, lights, gl, p + r * SURFACE_DIST * 3.0, r, far, settings)
+            out[idx, :3] += gl.ks * fil * rgb2
+            out[idx, 3] += 1.0
+            go = ~env
+            idx, p, n, d, cr, fil = idx[go], P2[go], N2[go], r[go], cr[go], fil[go]
+    return out.reshape(H, W, 4), (~is_env).reshape(H, W)

@@ -125,3 +125,28 @@ def test_tables_of_primitives_against_the_independent_arbiter(name):
         d = np.abs(o32 - f64).max(-1)
         assert (d <= 1e-3).mean() >= 0.999, f"{(d > 1e-3).sum()} of {d.size} pixels beyond 1e-3 of the independent arbiter (max {d.max():.2e})"
         assert ((o32[..., :3] != 1.0).any(-1) != hit64).mean() <= 0.002  # the same silhouette
+
+
+@pytest.mark.parametrize("name", ["lighting/reflections_basic", "lighting/reflections_complex", "lighting/test_reflectiveness",
+                                  "simple/recursive_sphere_2", "lighting/refract2", "lighting/shadow_test"])
+@pytest.mark.parametrize("bounces,min_arb,min_o32", [(1, 0.9995, 0.995), (3, 0.99, 0.95)])
+def test_reflection_loop_over_tables_against_the_independent_arbiter(name, bounces, min_arb, min_o32):
+    """main's reflection loop (frag:2491-2524) over tables of primitives — the first hit's cReflective filters every bounce, every
+    bounce is a full render() with soft shadows and AO — transcribed independently too.  One bounce: the two binary64 transcriptions
+    agree to 1e-6 on ≥ 99.98 % of the pixels and the binary32 oracle is within 1e-3 on ≥ 99.6 %.  Three bounces between curved
+    mirrors amplify every rounding (a reflected ray's hit / miss flips): the binary64 evaluations themselves part on up to 0.9 % of
+    the pixels (`reflections_complex.json`), the binary32 one on up to 4.7 % — the bounds below are those measurements with margin;
+    the bounce COUNT (alpha) agrees between the arbiters on every pixel but those."""
+    t = Scene(path=os.path.join(GOLD, "scenes", name + ".json")).tables(W, H, load_textures=False)
+    for i in range(t.num_objects):
+        t.objects[i].texLoc = -1
+    scene = (t.camera, t.objects, t.num_objects, t.lights, t.num_lights, t.globals_)
+    s = abi.default_settings(enableSoftShadow=1, enableAmbientOcclusion=1, enableReflection=1, numReflection=bounces)
+    f64, hit64 = an.render_frame_table(t, s, W, H)
+    o32, c64 = h.oracle_render(scene, s, W, H), h.arbiter_render(scene, s, W, H)
+    assert np.isfinite(f64).all() and (f64[..., 3] > 1.0).mean() > 0.1  # reflective surfaces are in view
+    dd = np.abs(c64 - f64).max(-1)
+    assert (dd <= 1e-6).mean() >= min_arb, f"the C arbiter and the NumPy arbiter agree on {(dd <= 1e-6).mean():.4f} of the pixels only"
+    assert (c64[..., 3] != f64[..., 3]).mean() <= 1.0 - min_arb
+    d = np.abs(o32 - f64).max(-1)
+    assert (d <= 1e-3).mean() >= min_o32, f"{(d > 1e-3).sum()} of {d.size} pixels beyond 1e-3 of the independent arbiter"
