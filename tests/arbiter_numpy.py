@@ -462,6 +462,31 @@ def get_phong_table(sd, N, mats, lights, g, p, rd, far, settings):
     return total
 
 
+def _refract(I, Nn, eta):  # GLSL refract (spec 8.5): k = 1 − η²(1 − (N·I)²); k < 0 → 0, else η·I − (η·(N·I) + √k)·N
+    eta = np.asarray(eta, np.float64) * np.ones(len(I))
+    ni = _dot(Nn, I)
+    k = 1.0 - eta * eta * (1.0 - ni * ni)
+    with np.errstate(invalid="ignore"):
+        r = eta[:, None] * I - (eta * ni + np.sqrt(k))[:, None] * Nn
+    return np.where((k < 0.0)[:, None], 0.0, r)
+
+
+def _raymarch_depth(sd, ro, rd, end, max_steps, side):
+    """raymarch(…).d (frag:1453-1484) with `side`: rayDepth − minD on a hit, rayDepth on a miss (UB2)."""
+    n = len(ro)
+    t, d = np.zeros(n), np.full(n, 1000000.0)
+    idx = np.arange(n)
+    for _ in range(max_steps):
+        if len(idx) == 0:
+            break
+        dd = sd(ro[idx] + rd[idx] * t[idx, None])[0]
+        d[idx] = dd
+        go = ~((np.abs(dd) < SURFACE_DIST) | (t[idx] > end))
+        t[idx[go]] += dd[go] * side
+        idx = idx[go]
+    return np.where(np.abs(d) < SURFACE_DIST, t - d, t)
+
+
 def _table_rays(sd, mats, lights, g, ro, rd, far, settings):
     """render() (frag:2318-2375) of a table of primitives for a batch of rays: (rgb, isEnv, hit point, shading normal, object)."""
     n = len(ro)
@@ -474,7 +499,7 @@ def _table_rays(sd, mats, lights, g, ro, rd, far, settings):
         if settings.features & RM_FEAT_PERLIN_BUMP:
             pn = bump_normal(pn, p)
         k = trap[hit, 0].astype(int)
-        m = {key: v[k] for key, v in mats.items() if key != "cReflective"}
+        m = {key: v[k] for key, v in mats.items() if key in ("cAmbient", "cDiffuse", "cSpecular", "shininess")}
         rgb[hit] = get_phong_table(sd, pn, m, lights, (g.ka, g.kd, g.ks), p, rd[hit], far, settings)
         P[hit], N[hit], K[hit] = p, pn, k
     return rgb, ~hit, P, N, K
@@ -482,18 +507,19 @@ def _table_rays(sd, mats, lights, g, ro, rd, far, settings):
 
 def render_frame_table(tables, settings, W, H):
     """fragColor of every pixel of a table of untextured primitives under directional, point and spot lights: (H, W, 4) float64 and
-    the hit mask; main's reflection loop (frag:2491-2524: the FIRST hit's cReflective filters every bounce) when it is enabled.
-    Refraction must be off."""
-    assert not (settings.enableRefraction or settings.enableSkyBox) and not tables.globals_.isTwoD
+    the hit mask; main's reflection loop (frag:2491-2524: the FIRST hit's cReflective filters every bounce) and its two-interface
+    refraction (frag:2526-2570) when they are enabled."""
+    assert not settings.enableSkyBox and not tables.globals_.isTwoD
     assert settings.features & RM_FEAT_WHITE_BACKGROUND
-    objs, mats = [], {"cAmbient": [], "cDiffuse": [], "cSpecular": [], "cReflective": [], "shininess": []}
+    objs, mats = [], {"cAmbient": [], "cDiffuse": [], "cSpecular": [], "cReflective": [], "cTransparent": [], "shininess": [], "ior": []}
     for i in range(tables.num_objects):
         o = tables.objects[i]
         assert o.type in Table.SDF and o.texLoc == -1 and not o.isEmissive
         objs.append((o.type, np.array(list(o.invModel), np.float64).reshape(4, 4).T, o.scaleFactor))
-        for k in ("cAmbient", "cDiffuse", "cSpecular", "cReflective"):
+        for k in ("cAmbient", "cDiffuse", "cSpecular", "cReflective", "cTransparent"):
             mats[k].append(list(getattr(o, k)))
         mats["shininess"].append(float(o.shininess))
+        mats["ior"].append(float(o.ior))
     mats = {k: np.array(v, np.float64) for k, v in mats.items()}
     lights = []
     for i in range(tables.num_lights):
@@ -530,4 +556,21 @@ def render_frame_table(tables, settings, W, H):
             out[idx, 3] += 1.0
             go = ~env
             idx, p, n, d, cr, fil = idx[go], P2[go], N2[go], r[go], cr[go], fil[go]
+    if settings.enableRefraction:  # frag:2526-2570: two interfaces, air → medium → air, from the PRIMARY hit (oi)
+        k0 = np.maximum(K, 0)
+        c_refr = mats["cTransparent"][k0]
+        idx = np.nonzero(~is_env & (np.sqrt(_dot(c_refr, c_refr)) != 0.0))[0]
+        if len(idx):
+            ior, ct = mats["ior"][k0][idx], c_refr[idx]
+            rd_in = _refract(rd[idx], N[idx], 1.0 / ior)
+            p_enter = P[idx] - N[idx] * SURFACE_DIST * 3.0
+            d_in = _raymarch_depth(sd, p_enter, rd_in, far, settings.maxSteps, side=-1.0)  # INSIDE; UB2: the depth travelled on a miss
+            p_exit = p_enter + rd_in * d_in[:, None]
+            n_exit = -get_normal(sd, p_exit)
+            rd_out = _refract(rd_in, n_exit, ior)
+            ok = np.sqrt(_dot(rd_out, rd_out)) != 0.0  # otherwise total internal reflection: refr = vec4(0)
+            if ok.any():
+                rgb3, _e, _p, _n, _k = _table_rays(sd, mats, lights, gl, (p_exit - n_exit * SURFACE_DIST * 5.0)[ok], rd_out[ok], far, settings)
+                out[idx[ok], :3] += gl.kt * ct[ok] * rgb3
+                out[idx[ok], 3] += 1.0
     return out.reshape(H, W, 4), (~is_env).reshape(H, W)
