@@ -371,11 +371,27 @@ def sd_rectangle(p):  # sdBox(p, vec3(0.5, 0.5, 0)), frag:1279
     return np.sqrt(_dot(np.maximum(q, 0.0), np.maximum(q, 0.0))) + np.minimum(np.max(q, axis=-1), 0.0)
 
 
+def sd_sierpinski(p):  # frag:807-826: 14 fold-and-scale iterations (Scale 1.85, Offset 2), length(p)·Scale^−14
+    # Scale is the shader's binary32 constant 1.85 (1.850000023841858): fourteen scalings amplify the 2.4e-8 between it and the
+    # binary64 1.85 to 1e-3 of a pixel — the constant is part of the function, not of the precision it is evaluated in
+    scale = float(np.float32(1.85))
+    p = p.copy()
+    for _ in range(14):
+        f = p[:, 0] + p[:, 1] < 0.0
+        p[f, 0], p[f, 1] = -p[f, 1], -p[f, 0]       # p.xy = −p.yx
+        f = p[:, 0] + p[:, 2] < 0.0
+        p[f, 0], p[f, 2] = -p[f, 2], -p[f, 0]       # p.xz = −p.zx
+        f = p[:, 1] + p[:, 2] < 0.0
+        p[f, 2], p[f, 1] = -p[f, 1], -p[f, 2]       # p.zy = −p.yz
+        p = p * scale - 2.0 * (scale - 1.0)
+    return np.sqrt(_dot(p, p)) * np.power(scale, -14.0)
+
+
 class Table:
     """sdScene (frag:1406-1430) over a table of primitives: the minimum of sdMatch(po)·scaleFactor with a strict `<` (the first of
     equal objects wins); the index of the minimum travels in the first component of what the fractal classes call the trap."""
     SDF = {RM_CUBE: sd_cube, RM_CONE: sd_cone, RM_CYLINDER: sd_cylinder, RM_SPHERE: sd_sphere, 4: sd_octahedron, 5: sd_torus,
-           6: sd_capsule, 7: sd_deathstar, 8: sd_rectangle}  # scenedata.h's PrimitiveType order ≡ frag:53-66
+           6: sd_capsule, 7: sd_deathstar, 8: sd_rectangle, 12: sd_sierpinski}  # scenedata.h's PrimitiveType order ≡ frag:53-66
 
     def __init__(self, objects):
         self.objs = [(self.SDF[t], np.asarray(M, np.float64), float(sf)) for t, M, sf in objects]
