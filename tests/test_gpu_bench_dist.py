@@ -21,10 +21,13 @@ def _free_port():
 
 
 def run_bench(*flags):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline", *flags],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(3):  # the port found free can be taken before the child binds it (seen once: EADDRINUSE): another port then
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline", *flags],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
+            break
     assert p.returncode == 0, f"bench.py failed ({p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"rank 0 must print ONE JSON line, got {len(lines)}"
